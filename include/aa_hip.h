@@ -1,0 +1,219 @@
+/*
+ * aa_hip.h -- C ABI of libaa_hip.so: the MI355X (gfx950) implementation of the
+ * archetypal-analysis / GPNH-convex-coding inner solver of `convex_dim_red`.
+ *
+ * The reference (azedarach/matrix-factorization-case-studies) has NO native/FFI layer:
+ * its hot path is numba-JIT Python behind the module surface of
+ * src/convex_dim_red.  This header is therefore the boundary a maintainer would
+ * bind with ctypes from that package; every entry point cites
+ * the reference code it replaces (paths relative to src/convex_dim_red/).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative AA_ERR_* code otherwise;
+ *     aa_last_error() returns a message for the calling thread's last failure;
+ *   - nothing throws across the ABI; plain pointers and sizes only;
+ *   - host buffers are caller-owned, row-major, float64 unless said otherwise,
+ *     and are only read or filled during the call; device memory is owned by
+ *     the context; a context is NOT thread-safe (one per estimator call);
+ *   - "n" = samples (rows of X), "p" = features, "k" = components (k <= 64).
+ */
+#ifndef AA_HIP_H
+#define AA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AA_OK            0
+#define AA_ERR_ARG      -1   /* bad argument / unsupported size                 */
+#define AA_ERR_HIP      -2   /* a HIP runtime call failed (no GPU, OOM, fault)   */
+#define AA_ERR_STATE    -3   /* call order violated (e.g. update before set_data)*/
+#define AA_ERR_COMM     -4   /* RCCL failure                                     */
+
+#define AA_F32 0             /* X stored + contracted in float32 (MFMA f32)      */
+#define AA_F64 1             /* X stored + contracted in float64 (reference dtype)*/
+
+#define AA_FORM_DATA   0     /* ArchetypalAnalysis: data matrix X (n x p)        */
+#define AA_FORM_KERNEL 1     /* KernelAA: kernel matrix K (n x n)                */
+
+#define AA_MAX_K 64
+
+typedef struct aa_ctx aa_ctx;   /* opaque */
+
+/* Parameters of the per-sample simplex QP solver.
+ * Replaces the keyword arguments of quad_simplex_spg (spg.py:286-291) as forwarded
+ * by _update_kernel_aa_weights (archetypal_analysis.py:372-383) and
+ * _update_gpnh_weights (gpnh_convex_coding.py:257-268). */
+typedef struct {
+    double gamma;
+    int    memory;
+    double sigma_one, sigma_two, lambda_min;
+    double alpha0, alpha_min, alpha_max;
+    double epsilon_one, epsilon_two;
+    int    max_iterations, max_feval;
+} aa_qp_params;
+
+/* Parameters of the dictionary SPG solver: keyword arguments of spg()
+ * (spg.py:46-51).  alpha0 < 0 means "None" (derive from the first projected
+ * gradient step, spg.py:178-189). */
+typedef struct {
+    double gamma;
+    int    memory;
+    double sigma_one, sigma_two, lambda_min;
+    double alpha0, alpha_min, alpha_max;
+    double epsilon_one, epsilon_two;
+    int    use_infinity_norm;
+    int    max_iterations, max_feval;
+} aa_spg_params;
+
+#define AA_SPG_FLAG_CONVERGED      1   /* spg.py:259-266                         */
+#define AA_SPG_FLAG_LAMBDA_MIN     2   /* warning at spg.py:225-229              */
+#define AA_SPG_FLAG_MAX_FEVAL      4   /* warning at spg.py:272-276              */
+#define AA_SPG_FLAG_MAX_ITER       8   /* warning at spg.py:278-281              */
+#define AA_SPG_FLAG_PROJ_UNCONV   16   /* internal: projection pass cap reached  */
+
+typedef struct {
+    double f;          /* spg() return value 2: f at the returned point          */
+    int    n_iter;     /* spg() return value 3: 0-based index of the last pass   */
+    int    n_feval;    /* spg() return value 4                                   */
+    int    flags;      /* AA_SPG_FLAG_*                                          */
+    double res_norm;   /* ||P(x - g) - x||_2 at exit                             */
+} aa_spg_stats;
+
+typedef struct {
+    long   total_passes;   /* sum over samples of SPG loop passes                */
+    int    max_passes;     /* largest per-sample pass count                      */
+    int    reserved;
+} aa_qp_stats;
+
+/* ------------------------------------------------------------------ misc */
+const char *aa_last_error(void);
+int aa_version(void);
+int aa_device_count(int *count);
+
+/* -------------------------------------------- stateless ops (unit-test surface) */
+
+/* Euclidean projection of every row of `in` (rows x cols) onto the unit simplex.
+ * Replaces simplex_project_rows (simplex_projection.py:40-47) /
+ * simplex_project_vector (:13-27). */
+int aa_simplex_project_rows(int device, const double *in, double *out, long rows, long cols);
+
+/* Z[t] = argmin_{z in simplex} 0.5 z'Az + b_t'z,  b_t[j] = -B[j*stride_j + t*stride_t],
+ * started from Z0[t]; t = 0..n-1.  A: k x k.  iters (nullable): loop passes per sample.
+ * Replaces _gu_update_kernel_aa_weights (archetypal_analysis.py:344-366; stride_j = n,
+ * stride_t = 1) and _gu_update_gpnh_weights (gpnh_convex_coding.py:229-251; stride_j = 1,
+ * stride_t = k), i.e. n calls of quad_simplex_spg (spg.py:286-398). */
+int aa_quad_simplex_spg_batch(int device, const double *A, const double *B,
+                              long stride_j, long stride_t,
+                              const double *Z0, double *Zout, long n, int k,
+                              const aa_qp_params *params, int *iters);
+
+/* ------------------------------------------------------ resident solver context */
+int aa_ctx_create(aa_ctx **ctx, int device, int dtype);
+int aa_ctx_destroy(aa_ctx *ctx);
+
+/* Multi-GPU (one process per GPU, rows of X sharded): rank 0 calls
+ * aa_comm_get_unique_id and hands the 128 bytes to the other ranks out of band;
+ * every rank then calls aa_ctx_comm_init.  Collectives (RCCL all-reduce, sum/max)
+ * run only on the small k x k / k x p Gram products and packed scalars. */
+int aa_comm_get_unique_id(void *id128);
+int aa_ctx_comm_init(aa_ctx *ctx, const void *id128, int rank, int world);
+/* all-reduce of a small host vector through the context's communicator (used by
+ * bench.py for the barrier + max-over-ranks timing); op: 0 = sum, 1 = max. */
+int aa_ctx_allreduce_host(aa_ctx *ctx, double *buf, int count, int op);
+
+/* Upload this rank's row block of the data matrix (form DATA: n x p) or kernel
+ * matrix (form KERNEL: n x n, p == n; single rank only).  host_dtype: AA_F32/AA_F64
+ * element type of `X` (converted to the context dtype on upload).  The matrix stays
+ * resident across restarts.  `n_global`/`row_offset` describe the shard.
+ * Replaces the `X`/`K` argument of _iterate_aa / _iterate_kernel_aa
+ * (archetypal_analysis.py:534, :399) and `X` of _iterate_gpnh_convex_coding
+ * (gpnh_convex_coding.py:282). */
+int aa_set_data(aa_ctx *ctx, const void *X, int host_dtype, long n, long p, long ld,
+                int form, long n_global, long row_offset);
+/* ||X||_F^2 (form DATA; = trace(X X'), archetypal_analysis.py:552 without the n x n
+ * temporary) or trace(K) (form KERNEL, :412), summed over all ranks. */
+int aa_data_trace(aa_ctx *ctx, double *trace);
+
+/* Factors: C (k x n, this rank's COLUMN block k x n_local, row-major with leading
+ * dimension ldc), Z (n_local x k), alpha (k).  Replaces the weights/dictionary/alpha
+ * arguments and return values of _iterate_aa (archetypal_analysis.py:534-536,669). */
+int aa_set_state(aa_ctx *ctx, int k, const double *C, long ldc, const double *Z, const double *alpha);
+int aa_get_state(aa_ctx *ctx, double *C, long ldc, double *Z, double *alpha);
+int aa_set_alpha(aa_ctx *ctx, const double *alpha);
+
+/* Recompute every Gram product from (X, C, Z, alpha) and return the cost
+ * 0.5 (tr XX' - 2 tr(D C XX' Z) + tr(D Z'Z D C XX' C')) / n.
+ * Replaces archetypal_analysis.py:543-558 (:403-418 for the kernel form). */
+int aa_prepare(aa_ctx *ctx, double *cost);
+/* Cost from the current Gram products and alpha (archetypal_analysis.py:623-627). */
+int aa_cost(aa_ctx *ctx, double *cost);
+/* k x k Gram products for the host-side scale-factor update
+ * (archetypal_analysis.py:243-258): ZtZ, C XX' C', C XX' Z, and the data trace. */
+int aa_get_grams(aa_ctx *ctx, double *ZtZ, double *CKCt, double *CKZ, double *trace);
+/* Override the dictionary-update inputs with caller-supplied values:
+ * KZ = XX'Z or KZ (n_local x k), ZtZ (k x k), trace.  Needed to mirror the
+ * test-visible _update_kernel_aa_dictionary(K, C, alpha, trace_K, KZ, ZtZ)
+ * (archetypal_analysis.py:304) / _update_aa_dictionary (:324). */
+int aa_set_dictionary_inputs(aa_ctx *ctx, const double *KZ, const double *ZtZ, double trace);
+
+/* SPG update of the dictionary with row-simplex constraint, then refresh of
+ * CX, C XX', C XX' C', C XX' Z.  Replaces _update_aa_dictionary
+ * (archetypal_analysis.py:324-341, cost :261-270, gradient :293-301), or
+ * _update_kernel_aa_dictionary (:304-321, :273-290) in the kernel form, plus the
+ * refresh at :618-621 (:484-486). */
+int aa_dictionary_update(aa_ctx *ctx, const aa_spg_params *params, aa_spg_stats *stats);
+/* Per-sample QP update of the weights, then refresh of Z'Z, X'Z, XX'Z, C XX' Z.
+ * Replaces _update_kernel_aa_weights (archetypal_analysis.py:369-396) plus the
+ * refresh at :640-643 (:501-503). */
+int aa_weights_update(aa_ctx *ctx, const aa_qp_params *params, aa_qp_stats *stats);
+
+/* n_outer full outer iterations (dictionary, weights) without returning to the
+ * caller; costs[2*i], costs[2*i+1] = cost after the dictionary / weights update of
+ * iteration i.  delta == 0 only (no scale-factor update).  Replaces the loop body
+ * archetypal_analysis.py:586-657 for benchmarking. */
+int aa_outer_iterations(aa_ctx *ctx, int n_outer, const aa_spg_params *spg,
+                        const aa_qp_params *qp, double *costs);
+
+/* 0.5 ||X - Z diag(alpha) C X||_F^2 / n evaluated in residual form (no trace
+ * cancellation); the reconstruction error reported by bench.py. */
+int aa_reconstruction_cost(aa_ctx *ctx, double *cost);
+
+/* archetypes = diag(alpha?) C X (k x p): archetypal_analysis.py:1144. */
+int aa_get_archetypes(aa_ctx *ctx, double *CX, long ld);
+
+/* FurthestSum support (furthest_sum.py:23-127 needs column j of the n x n
+ * dissimilarity matrix, archetypal_analysis.py:95-100): d[i] =
+ * sqrt(K_ii - 2 K_ij + K_jj) for this rank's rows i, K = XX' never formed
+ * (form DATA) or the stored K (form KERNEL).  j is a GLOBAL row index. */
+int aa_distance_column(aa_ctx *ctx, long j, double *d);
+
+/* ------------------------------------------------------------------ GPNH */
+/* Dictionary W (p x k) is passed transposed, Wt (k x p, leading dimension ld).
+ * aa_gpnh_set_factors uploads Wt and/or Z (either may be NULL to keep the current
+ * one) and, when Wt is given, computes XW = X W (n x k).
+ * Replaces gpnh_convex_coding.py:292,352 (WtXt) and :270 (XW). */
+int aa_gpnh_set_factors(aa_ctx *ctx, int k, const double *Wt, long ld, const double *Z);
+int aa_gpnh_get_weights(aa_ctx *ctx, double *Z);
+/* Z'X (k x p, summed over ranks), Z'Z (k x k), and tr(W'X'Z) = sum(XW * Z).
+ * Replaces gpnh_convex_coding.py:219 (ZtX), :293,:374 (ZtZ), :303,:355,:376. */
+int aa_gpnh_reduce(aa_ctx *ctx, double *ZtX, long ld, double *ZtZ, double *trace_WtXtZ);
+/* QP update of the weights: A = WtW (k x k, host-supplied), b_t = -XW[t].
+ * Replaces _update_gpnh_weights (gpnh_convex_coding.py:254-279). */
+int aa_gpnh_weights_update(aa_ctx *ctx, const double *WtW, const aa_qp_params *params,
+                           aa_qp_stats *stats);
+/* 0.5 ||X - Z W'||_F^2 / n in residual form: _gpnh_cost (gpnh_convex_coding.py:199-210)
+ * without the penalty term (added on the host). */
+int aa_gpnh_residual_cost(aa_ctx *ctx, double *cost);
+
+/* ------------------------------------------------------------ measurement */
+/* Time `reps` launches of one hot-path GEMM kernel with HIP events on the
+ * context's stream.  which: 0 = reduce-over-rows (C X, X'Z; k x p out),
+ * 1 = row-local (CX X', X X'Z; n x k out), 2 = QP weights kernel on current state.
+ * ms_avg = average duration of one launch in milliseconds. */
+int aa_time_kernel(aa_ctx *ctx, int which, int reps, double *ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AA_HIP_H */

@@ -1,0 +1,424 @@
+"""ctypes binding of libaa_hip.so (include/aa_hip.h) -- the only way this package
+computes.  There is NO CPU fallback: if the library is missing, or no MI355X is
+visible, every numeric entry point raises ``RuntimeError``.
+
+Host code is plain NumPy (the reference package is NumPy-only); device memory is
+owned by an ``aa_ctx`` created and destroyed inside each estimator call, so estimator
+instances hold no device handles and stay ``copy.deepcopy``-safe (the drivers deepcopy
+models: bin/run_hadisst_aa.py:171).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+AA_F32, AA_F64 = 0, 1
+FORM_DATA, FORM_KERNEL = 0, 1
+MAX_K = 64
+
+SPG_FLAG_CONVERGED = 1
+SPG_FLAG_LAMBDA_MIN = 2
+SPG_FLAG_MAX_FEVAL = 4
+SPG_FLAG_MAX_ITER = 8
+SPG_FLAG_PROJ_UNCONV = 16
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                         "libaa_hip.so")
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+class QPParams(ctypes.Structure):
+    """aa_qp_params: keyword arguments of quad_simplex_spg (reference spg.py:287-291)."""
+    _fields_ = [("gamma", ctypes.c_double), ("memory", ctypes.c_int),
+                ("sigma_one", ctypes.c_double), ("sigma_two", ctypes.c_double),
+                ("lambda_min", ctypes.c_double), ("alpha0", ctypes.c_double),
+                ("alpha_min", ctypes.c_double), ("alpha_max", ctypes.c_double),
+                ("epsilon_one", ctypes.c_double), ("epsilon_two", ctypes.c_double),
+                ("max_iterations", ctypes.c_int), ("max_feval", ctypes.c_int)]
+
+
+class SPGParams(ctypes.Structure):
+    """aa_spg_params: keyword arguments of spg (reference spg.py:46-51)."""
+    _fields_ = [("gamma", ctypes.c_double), ("memory", ctypes.c_int),
+                ("sigma_one", ctypes.c_double), ("sigma_two", ctypes.c_double),
+                ("lambda_min", ctypes.c_double), ("alpha0", ctypes.c_double),
+                ("alpha_min", ctypes.c_double), ("alpha_max", ctypes.c_double),
+                ("epsilon_one", ctypes.c_double), ("epsilon_two", ctypes.c_double),
+                ("use_infinity_norm", ctypes.c_int),
+                ("max_iterations", ctypes.c_int), ("max_feval", ctypes.c_int)]
+
+
+class SPGStats(ctypes.Structure):
+    _fields_ = [("f", ctypes.c_double), ("n_iter", ctypes.c_int), ("n_feval", ctypes.c_int),
+                ("flags", ctypes.c_int), ("res_norm", ctypes.c_double)]
+
+
+class QPStats(ctypes.Structure):
+    _fields_ = [("total_passes", ctypes.c_long), ("max_passes", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/aa_hip.h declares
+_vp = ctypes.c_void_p
+_SIGNATURES = {
+    "aa_last_error": (ctypes.c_char_p, []),
+    "aa_version": (ctypes.c_int, []),
+    "aa_device_count": (ctypes.c_int, [_ip]),
+    "aa_simplex_project_rows": (ctypes.c_int, [ctypes.c_int, _dp, _dp, ctypes.c_long, ctypes.c_long]),
+    "aa_quad_simplex_spg_batch": (ctypes.c_int, [ctypes.c_int, _dp, _dp, ctypes.c_long, ctypes.c_long,
+                                                 _dp, _dp, ctypes.c_long, ctypes.c_int,
+                                                 ctypes.POINTER(QPParams), _ip]),
+    "aa_ctx_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int]),
+    "aa_ctx_destroy": (ctypes.c_int, [_vp]),
+    "aa_comm_get_unique_id": (ctypes.c_int, [_vp]),
+    "aa_ctx_comm_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+    "aa_ctx_allreduce_host": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int]),
+    "aa_set_data": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_long,
+                                   ctypes.c_int, ctypes.c_long, ctypes.c_long]),
+    "aa_data_trace": (ctypes.c_int, [_vp, _dp]),
+    "aa_set_state": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp, _dp]),
+    "aa_get_state": (ctypes.c_int, [_vp, _dp, ctypes.c_long, _dp, _dp]),
+    "aa_set_alpha": (ctypes.c_int, [_vp, _dp]),
+    "aa_prepare": (ctypes.c_int, [_vp, _dp]),
+    "aa_cost": (ctypes.c_int, [_vp, _dp]),
+    "aa_get_grams": (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp]),
+    "aa_set_dictionary_inputs": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_double]),
+    "aa_dictionary_update": (ctypes.c_int, [_vp, ctypes.POINTER(SPGParams), ctypes.POINTER(SPGStats)]),
+    "aa_weights_update": (ctypes.c_int, [_vp, ctypes.POINTER(QPParams), ctypes.POINTER(QPStats)]),
+    "aa_outer_iterations": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(SPGParams),
+                                           ctypes.POINTER(QPParams), _dp]),
+    "aa_reconstruction_cost": (ctypes.c_int, [_vp, _dp]),
+    "aa_get_archetypes": (ctypes.c_int, [_vp, _dp, ctypes.c_long]),
+    "aa_distance_column": (ctypes.c_int, [_vp, ctypes.c_long, _dp]),
+    "aa_gpnh_set_factors": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp]),
+    "aa_gpnh_get_weights": (ctypes.c_int, [_vp, _dp]),
+    "aa_gpnh_reduce": (ctypes.c_int, [_vp, _dp, ctypes.c_long, _dp, _dp]),
+    "aa_gpnh_weights_update": (ctypes.c_int, [_vp, _dp, ctypes.POINTER(QPParams), ctypes.POINTER(QPStats)]),
+    "aa_gpnh_residual_cost": (ctypes.c_int, [_vp, _dp]),
+    "aa_time_kernel": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libaa_hip.so and bind every entry point.  Raises RuntimeError (never
+    falls back) when the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            "convex_dim_red (MI355X build): %s not found -- build it with "
+            "`python __graft_entry__.py` or `make -C matrix-factorization-case-studies_amd/csrc`. "
+            "This package has no CPU fallback." % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load_library().aa_last_error()
+        raise RuntimeError("libaa_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def device_index():
+    env = os.environ.get("CONVEX_DIM_RED_DEVICE")
+    if env is not None:
+        return int(env)
+    return int(os.environ.get("LOCAL_RANK", "0")) if "CONVEX_DIM_RED_USE_LOCAL_RANK" in os.environ else 0
+
+
+def default_dtype():
+    v = os.environ.get("CONVEX_DIM_RED_DTYPE", "float64")
+    if v not in ("float64", "float32"):
+        raise ValueError("CONVEX_DIM_RED_DTYPE must be float64 or float32, got %r" % v)
+    return v
+
+
+def dtype_code(dtype):
+    if dtype is None:
+        dtype = default_dtype()
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return AA_F64
+    if dtype == np.float32:
+        return AA_F32
+    raise ValueError("unsupported dtype %r (float64 or float32)" % (dtype,))
+
+
+def require_gpu():
+    lib = load_library()
+    n = ctypes.c_int(0)
+    rc = lib.aa_device_count(ctypes.byref(n))
+    if rc != 0 or n.value < 1:
+        msg = lib.aa_last_error()
+        raise RuntimeError("convex_dim_red (MI355X build): no HIP device available (%s); "
+                           "this package has no CPU fallback"
+                           % (msg.decode() if msg else "device count = %d" % n.value))
+    return n.value
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def qp_params(**kw):
+    """Defaults of _update_kernel_aa_weights (reference archetypal_analysis.py:372-383)."""
+    return QPParams(kw.get("gamma", 1e-4), int(kw.get("memory", 1)),
+                    kw.get("sigma_one", 0.1), kw.get("sigma_two", 0.9),
+                    kw.get("lambda_min", 1e-10), kw.get("alpha0", -1.0),
+                    kw.get("alpha_min", 1e-5), kw.get("alpha_max", 1e3),
+                    kw.get("epsilon_one", 1e-10), kw.get("epsilon_two", 1e-6),
+                    int(kw.get("max_iterations", 1000)), int(kw.get("max_feval", 2000)))
+
+
+_SPG_KEYS = ("gamma", "memory", "sigma_one", "sigma_two", "lambda_min", "alpha0", "alpha_min",
+             "alpha_max", "epsilon_one", "epsilon_two", "use_infinity_norm", "verbose",
+             "max_iterations", "max_feval")
+
+
+def spg_params(**kw):
+    """Defaults of spg (reference spg.py:46-51); unknown keywords raise TypeError like the
+    reference's call would."""
+    for key in kw:
+        if key not in _SPG_KEYS:
+            raise TypeError("spg() got an unexpected keyword argument %r" % key)
+    alpha0 = kw.get("alpha0", None)
+    return SPGParams(kw.get("gamma", 1e-4), int(kw.get("memory", 1)),
+                     kw.get("sigma_one", 0.1), kw.get("sigma_two", 0.9),
+                     kw.get("lambda_min", 1e-10), -1.0 if alpha0 is None else float(alpha0),
+                     kw.get("alpha_min", 1e-5), kw.get("alpha_max", 1e3),
+                     kw.get("epsilon_one", 1e-10), kw.get("epsilon_two", 1e-6),
+                     1 if kw.get("use_infinity_norm", True) else 0,
+                     int(kw.get("max_iterations", 10000)), int(kw.get("max_feval", 1000000)))
+
+
+# ---------------------------------------------------------------- stateless ops
+def simplex_project_rows(A):
+    require_gpu()
+    A = _c64(A)
+    if A.ndim != 2:
+        raise ValueError("expected a 2-D array")
+    out = np.empty_like(A)
+    _check(load_library().aa_simplex_project_rows(device_index(), _ptr(A), _ptr(out),
+                                                  A.shape[0], A.shape[1]))
+    return out
+
+
+def qp_batch(A, B, Z0, layout, return_iters=False, **kw):
+    """layout 'kn': B is k x n, b_t = -B[:, t]; 'nk': B is n x k, b_t = -B[t]."""
+    require_gpu()
+    A, B, Z0 = _c64(A), _c64(B), _c64(Z0)
+    n, k = Z0.shape
+    if k > MAX_K:
+        raise ValueError("n_components = %d exceeds the HIP backend limit of %d" % (k, MAX_K))
+    sj, st = (n, 1) if layout == "kn" else (1, k)
+    Z = np.empty_like(Z0)
+    iters = np.zeros(n, dtype=np.int32)
+    p = qp_params(**kw)
+    _check(load_library().aa_quad_simplex_spg_batch(
+        device_index(), _ptr(A), _ptr(B), sj, st, _ptr(Z0), _ptr(Z), n, k, ctypes.byref(p),
+        iters.ctypes.data_as(_ip)))
+    return (Z, iters) if return_iters else Z
+
+
+# ---------------------------------------------------------------- resident solver
+class Context(object):
+    """RAII wrapper of aa_ctx.  Use as a context manager."""
+
+    def __init__(self, dtype=None, device=None):
+        require_gpu()
+        self.lib = load_library()
+        self.h = _vp()
+        self.dtype_code = dtype_code(dtype)
+        _check(self.lib.aa_ctx_create(ctypes.byref(self.h),
+                                      device_index() if device is None else device,
+                                      self.dtype_code))
+        self.k = 0
+        self.n = 0
+        self.p = 0
+        self.world = 1
+
+    def close(self):
+        if self.h:
+            self.lib.aa_ctx_destroy(self.h)
+            self.h = _vp()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- comm
+    def comm_init(self, unique_id, rank, world):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        _check(self.lib.aa_ctx_comm_init(self.h, ctypes.cast(buf, _vp), rank, world))
+        self.world = world
+
+    def allreduce_host(self, values, op="sum"):
+        a = _c64(np.atleast_1d(values)).copy()
+        _check(self.lib.aa_ctx_allreduce_host(self.h, _ptr(a), a.size, 1 if op == "max" else 0))
+        return a
+
+    # -- data / state
+    def set_data(self, X, form=FORM_DATA, n_global=None, row_offset=0):
+        X = np.asarray(X)
+        if X.dtype == np.float32:
+            host = AA_F32
+        else:
+            X = np.asarray(X, dtype=np.float64)
+            host = AA_F64
+        X = np.ascontiguousarray(X)
+        n, p = X.shape
+        _check(self.lib.aa_set_data(self.h, X.ctypes.data_as(_vp), host, n, p, p, form,
+                                    n if n_global is None else n_global, row_offset))
+        self.n, self.p = n, p
+
+    def data_trace(self):
+        t = ctypes.c_double(0)
+        _check(self.lib.aa_data_trace(self.h, ctypes.byref(t)))
+        return t.value
+
+    def set_state(self, C, Z, alpha):
+        C, Z, alpha = _c64(C), _c64(Z), _c64(alpha)
+        k = C.shape[0]
+        _check(self.lib.aa_set_state(self.h, k, _ptr(C), C.shape[1], _ptr(Z), _ptr(alpha)))
+        self.k = k
+
+    def get_state(self):
+        C = np.empty((self.k, self.n))
+        Z = np.empty((self.n, self.k))
+        alpha = np.empty(self.k)
+        _check(self.lib.aa_get_state(self.h, _ptr(C), self.n, _ptr(Z), _ptr(alpha)))
+        return C, Z, alpha
+
+    def set_alpha(self, alpha):
+        alpha = _c64(alpha)
+        _check(self.lib.aa_set_alpha(self.h, _ptr(alpha)))
+
+    def prepare(self):
+        c = ctypes.c_double(0)
+        _check(self.lib.aa_prepare(self.h, ctypes.byref(c)))
+        return c.value
+
+    def cost(self):
+        c = ctypes.c_double(0)
+        _check(self.lib.aa_cost(self.h, ctypes.byref(c)))
+        return c.value
+
+    def grams(self):
+        k = self.k
+        ZtZ, CKCt, CKZ = np.empty((k, k)), np.empty((k, k)), np.empty((k, k))
+        t = ctypes.c_double(0)
+        _check(self.lib.aa_get_grams(self.h, _ptr(ZtZ), _ptr(CKCt), _ptr(CKZ), ctypes.byref(t)))
+        return ZtZ, CKCt, CKZ, t.value
+
+    def set_dictionary_inputs(self, KZ, ZtZ, trace):
+        KZ, ZtZ = _c64(KZ), _c64(ZtZ)
+        _check(self.lib.aa_set_dictionary_inputs(self.h, _ptr(KZ), _ptr(ZtZ), float(trace)))
+
+    def dictionary_update(self, **spg_kw):
+        p = spg_params(**spg_kw)
+        st = SPGStats()
+        _check(self.lib.aa_dictionary_update(self.h, ctypes.byref(p), ctypes.byref(st)))
+        return st
+
+    def weights_update(self, **qp_kw):
+        p = qp_params(**qp_kw)
+        st = QPStats()
+        _check(self.lib.aa_weights_update(self.h, ctypes.byref(p), ctypes.byref(st)))
+        return st
+
+    def outer_iterations(self, n_outer, spg_kw, qp_kw):
+        sp, qp = spg_params(**spg_kw), qp_params(**qp_kw)
+        costs = np.zeros(2 * n_outer)
+        _check(self.lib.aa_outer_iterations(self.h, n_outer, ctypes.byref(sp), ctypes.byref(qp),
+                                            _ptr(costs)))
+        return costs
+
+    def reconstruction_cost(self):
+        c = ctypes.c_double(0)
+        _check(self.lib.aa_reconstruction_cost(self.h, ctypes.byref(c)))
+        return c.value
+
+    def archetypes(self):
+        out = np.empty((self.k, self.p))
+        _check(self.lib.aa_get_archetypes(self.h, _ptr(out), self.p))
+        return out
+
+    def distance_column(self, j):
+        d = np.empty(self.n)
+        _check(self.lib.aa_distance_column(self.h, int(j), _ptr(d)))
+        return d
+
+    # -- GPNH
+    def gpnh_set_factors(self, k, W=None, Z=None):
+        """W is the reference's dictionary (p x k); it travels transposed (k x p)."""
+        Wt = None if W is None else _c64(np.asarray(W).T)
+        Zc = None if Z is None else _c64(Z)
+        _check(self.lib.aa_gpnh_set_factors(self.h, k, None if Wt is None else _ptr(Wt), self.p,
+                                            None if Zc is None else _ptr(Zc)))
+        self.k = k
+
+    def gpnh_get_weights(self):
+        Z = np.empty((self.n, self.k))
+        _check(self.lib.aa_gpnh_get_weights(self.h, _ptr(Z)))
+        return Z
+
+    def gpnh_reduce(self, want_ztx=True, want_trace=True):
+        k = self.k
+        ZtX = np.empty((k, self.p)) if want_ztx else None
+        ZtZ = np.empty((k, k))
+        tr = ctypes.c_double(0)
+        _check(self.lib.aa_gpnh_reduce(self.h, None if ZtX is None else _ptr(ZtX), self.p, _ptr(ZtZ),
+                                       ctypes.byref(tr) if want_trace else None))
+        return ZtX, ZtZ, tr.value
+
+    def gpnh_weights_update(self, WtW, **qp_kw):
+        WtW = _c64(WtW)
+        p = qp_params(**qp_kw)
+        st = QPStats()
+        _check(self.lib.aa_gpnh_weights_update(self.h, _ptr(WtW), ctypes.byref(p), ctypes.byref(st)))
+        return st
+
+    def gpnh_residual_cost(self):
+        c = ctypes.c_double(0)
+        _check(self.lib.aa_gpnh_residual_cost(self.h, ctypes.byref(c)))
+        return c.value
+
+    def time_kernel(self, which, reps):
+        ms = ctypes.c_double(0)
+        _check(self.lib.aa_time_kernel(self.h, which, reps, ctypes.byref(ms)))
+        return ms.value
+
+
+def comm_unique_id():
+    buf = ctypes.create_string_buffer(128)
+    _check(load_library().aa_comm_get_unique_id(ctypes.cast(buf, _vp)))
+    return buf.raw

@@ -1,0 +1,206 @@
+// aa_internal.h -- shared declarations of libaa_hip.so (gfx950 only).
+//
+// Data layout in HBM (all device buffers are zero-initialised, padded, and owned
+// by the context):
+//   X        [n_pad][ldx]   T (float|double)  row-major data (or kernel) matrix;
+//                            n_pad = roundup(n,128), ldx = p_pad = roundup(p,128);
+//                            padding rows/columns are ZERO so GEMM kernels need no
+//                            bounds checks and padding never contributes to a sum.
+//   "tall"   [n_pad][KP]    double            per-sample x per-component arrays:
+//                            Ct (dictionary, TRANSPOSED: component on the fast axis),
+//                            Z, D (search direction), G (C XX' or C K, transposed),
+//                            g (gradient), H (XX'Z or KZ), XW ...   KP = 32 or 64.
+//   "wide"   [KP][p_pad]    double (+ a T copy used as MFMA operand)
+//                            P = C X, Q = D X, ZtX = Z'X, Wt.
+//   small    [KP][KP]       double            Gram products.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/aa_hip.h"
+
+namespace aa {
+
+void set_error(const char *fmt, ...);
+
+#define AA_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (expr);                                                        \
+        if (e__ != hipSuccess) {                                                        \
+            aa::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,                 \
+                          hipGetErrorString(e__));                                      \
+            return AA_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+#define AA_CHECK(expr)                                                                  \
+    do {                                                                                \
+        int rc__ = (expr);                                                              \
+        if (rc__ != AA_OK) return rc__;                                                 \
+    } while (0)
+
+#define AA_REQUIRE(cond, code, ...)                                                     \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            aa::set_error(__VA_ARGS__);                                                 \
+            return code;                                                                \
+        }                                                                               \
+    } while (0)
+
+inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t b)
+    {
+        if (b <= bytes && p) return AA_OK;
+        release();
+        if (b == 0) b = 16;
+        AA_CHECK_HIP(hipMalloc(&p, b));
+        bytes = b;
+        AA_CHECK_HIP(hipMemset(p, 0, b));
+        return AA_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ------------------------------------------------------------------ scalars
+// Device-resident scalar state of the dictionary SPG solver and the projection
+// passes.  Written by single-thread "scalar stage" kernels so the host does not
+// have to synchronise inside an SPG iteration.
+enum ScalarSlot {
+    SC_TRACE = 0,   // tr(XX') or tr(K)
+    SC_S1,          // tr(C * HD)            H = XX'Z or KZ
+    SC_A0,          // tr(M * C K C')
+    SC_F_OLD,
+    SC_F_NEW,
+    SC_ALPHA,       // BB step
+    SC_ALPHA_SET,   // 0 => derive alpha from the first projected-gradient step
+    SC_LAMBDA,
+    SC_DELTA,       // <d, g>
+    SC_DD,          // <d, d>
+    SC_S1D,         // tr(D * HD)
+    SC_A1,
+    SC_A2,
+    SC_DGN,         // <d, g_new>
+    SC_RES2,        // ||res||^2
+    SC_RESINF,
+    SC_NFEVAL,
+    SC_FLAGS,
+    SC_PROJ_A,      // multiplier of g inside the current projection: w = x - a*g
+    SC_AINV,        // max |P(x-g)-x|
+    SC_FNORM,       // divisor of f (k in both forms)
+    SC_FMEM0,       // f_mem[0..15]
+    SC_COUNT = SC_FMEM0 + 16
+};
+
+struct ProjState {          // per projection, device memory
+    double t[AA_MAX_K];
+    double cnt[AA_MAX_K];
+    int done;
+    int passes;
+};
+
+// ------------------------------------------------------------------ context
+struct Comm;   // RCCL wrapper (comm.hip)
+
+struct Ctx {
+    int device = 0;
+    int dtype = AA_F64;
+    hipStream_t stream = nullptr;
+    Comm *comm = nullptr;
+    int rank = 0, world = 1;
+
+    // data
+    int form = AA_FORM_DATA;
+    long n = 0, n_pad = 0, p = 0, p_pad = 0, n_global = 0, row_offset = 0;
+    DevBuf X;
+    bool have_data = false;
+    double trace = 0.0;
+    bool have_trace = false;
+
+    // problem
+    int k = 0, KP = 0;
+    bool have_state = false, grams_valid = false, gpnh_valid = false;
+    std::vector<double> alpha;                 // host copy
+    std::vector<double> ZtZ, CKCt, CKZ;        // host copies (k x k, dense k)
+    bool dict_inputs_overridden = false;
+
+    // tall arrays
+    DevBuf Ct, Zt, Dt, Gr, Gn, gk, gn, H, tmpTall;
+    // wide arrays
+    DevBuf P, Q, ZtX, Pw, Qw;                  // Pw/Qw: T-typed MFMA operand copies
+    DevBuf wideScratch;                        // KP x max(p_pad, n_pad) double
+    // reduction scratch
+    DevBuf partial;                            // GEMM split-row partials
+    DevBuf redPartial;                         // tall/wide reduction partials
+    DevBuf gramOut;                            // up to 4 KPxKP results
+    DevBuf redOut;                             // finalized [NV][KP] reduction results
+    DevBuf scalars;                            // SC_COUNT doubles
+    DevBuf proj;                               // ProjState
+    DevBuf Mdev, alphaDev;                     // KP*KP, KP
+    DevBuf qpIters;                            // n ints
+    DevBuf qpStats;                            // 2 long long
+    void *hostPinned = nullptr;                // small pinned staging
+    size_t hostPinnedBytes = 0;
+
+    long nslab = 0, rows_per_slab = 0;         // reduce-over-rows decomposition
+    int tallBlocks = 0;                        // blocks of the tall reductions
+};
+
+// ------------------------------------------------------------------ kernels_gemm.hip
+// out[KP][p_pad] (double) = sum_r A[r][i] * X[r][c];  A tall double, X T.
+// Also refreshes the T-typed operand copy outT (may alias out when T == double).
+int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *outT,
+                       bool main_only = false);
+// out[n_pad][KP] (double) = sum_c X[r][c] * B[i][c];  B wide, T-typed.
+int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall);
+
+// ------------------------------------------------------------------ kernels_tall.hip
+int tall_setup(Ctx *c);
+int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode);
+enum { PROJ_FEAS = 0, PROJ_ALPHA = 1, PROJ_DIR = 2, PROJ_RES = 3 };
+int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, double scale,
+                const double *d_for_dot /*nullable*/, int dot_slot);
+int launch_tall_axpy_lambda(Ctx *c, double *x, const double *d);             // x += lambda * d
+int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const double *alpha_dev,
+                           int slot);   // sum x*H*alpha (alpha_dev nullable => 1)
+int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev); // A'B  (KPxKP)
+int launch_gram_wide(Ctx *c, const double *A, const double *B, double *out_dev); // A B' (KPxKP)
+int launch_wide_axpy_lambda(Ctx *c, double *P, const double *Q, void *PT);   // P += lambda*Q; PT = T(P)
+int launch_wide_to_T(Ctx *c, const double *src, void *dstT);
+int launch_transpose_wide_to_tall(Ctx *c, const double *wide, double *tall); // [KP][p_pad] -> [n_pad][KP] (kernel form)
+int launch_transpose_tall_to_wide(Ctx *c, const double *tall, double *wide, void *wideT);
+int launch_scalar_stage(Ctx *c, int stage, const aa_spg_params *sp, int it);
+enum { ST_INIT_F = 0, ST_ALPHA = 1, ST_LINESEARCH = 2, ST_BB = 3, ST_CONV = 4 };
+int launch_row_sqnorm_sum(Ctx *c, double *trace_out_host);
+int launch_distance_column(Ctx *c, long j_local, int owner_has_row, const double *xj_host, double *d_host);
+int launch_residual_cost(Ctx *c, const double *Ztall, const double *Wwide, const double *alpha_dev,
+                         double *out_host);
+
+// ------------------------------------------------------------------ kernels_qp.hip
+int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, long stride_t,
+              const double *bscale_host /*k or null*/, double *Ztall, int ldz, long n, int k,
+              const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats);
+int launch_simplex_rows_generic(hipStream_t s, const double *in, double *out, long rows, long cols);
+
+// ------------------------------------------------------------------ comm.hip
+int comm_unique_id(void *id128);
+int comm_init(Ctx *c, const void *id128, int rank, int world);
+void comm_destroy(Ctx *c);
+int comm_allreduce(Ctx *c, double *dev, long count, int op);   // in place, on c->stream
+
+}  // namespace aa

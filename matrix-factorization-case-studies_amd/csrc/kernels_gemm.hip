@@ -1,0 +1,307 @@
+// kernels_gemm.hip -- the two skinny-GEMM shapes of the AA/GPNH solver against the
+// resident data matrix X [n_pad][ldx] (gfx950 / CDNA4 only).
+//
+//   reduce-over-rows  out[i][c] = sum_r A[r][i] * X[r][c]      (k x p result)
+//       C X   archetypal_analysis.py:262,297,544,618     (A = C', tall)
+//       D X   (search direction; gives (C + lambda D) X by linearity)
+//       Z'X   archetypal_analysis.py:548,641; gpnh_convex_coding.py:219
+//       C K   archetypal_analysis.py:208,288,409,484     (kernel form)
+//   row-local         out[r][i] = sum_c X[r][c] * B[i][c]      (n x k result)
+//       (CX) X'   archetypal_analysis.py:299,545,619
+//       X (X'Z)   archetypal_analysis.py:549,642
+//       X W       gpnh_convex_coding.py:270,292,352
+//       K Z       archetypal_analysis.py:411,502             (kernel form)
+//
+// float32: v_mfma_f32_32x32x2_f32, operands loaded straight from HBM into the MFMA
+// fragment layout (each X element is read exactly once per pass; the small operand
+// comes from L2).  Algorithmic traffic per pass = n*p*4 bytes; 2*k*n*p flop; at
+// k = 32 the intensity is 16 flop/B (< the 19.7 flop/B ridge) => HBM-bound.
+// float64: same decomposition on the f64 VALU (v_fma_f64 runs at the f64 MFMA rate
+// on gfx950), used by the reference-dtype parity path.
+#include "aa_internal.h"
+
+namespace aa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// reduce over rows, float32 MFMA.
+// grid = (ceil(p_pad/512), nslab); block = 4 waves; wave w owns the 128-column
+// strip c0 = (4*blockIdx.x + w)*128 and rows [slab*rows_per_slab, +rows_per_slab).
+// MFMA 32x32x2: A-operand lane l = A[row r0+2u+(l>>5)][component l&31],
+// B-operand lane l = X[row r0+2u+(l>>5)][c0 + 4*(l&31) + m]  (one dwordx4 load feeds
+// the four MFMAs m = 0..3, whose output columns are c0 + 4*j + m).
+// ---------------------------------------------------------------------------
+template <int NCT>
+__global__ __launch_bounds__(256) void k_reduce_rows_f32(const float *__restrict__ X, long ldx,
+                                                         const double *__restrict__ A,
+                                                         long rows_per_slab, long n_pad, int p_pad,
+                                                         float *__restrict__ partial)
+{
+    constexpr int KP = 32 * NCT;
+    constexpr int U = 8;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = (blockIdx.x * 4 + wave) * 128;
+    if (c0 >= p_pad) return;   // wave-uniform; the kernel has no barriers
+    const int h = lane >> 5, j = lane & 31;
+    const long r_begin = (long)blockIdx.y * rows_per_slab;
+    long r_end = r_begin + rows_per_slab;
+    if (r_end > n_pad) r_end = n_pad;
+
+    f32x16 acc[NCT][4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ct][m][e] = 0.f;
+
+    const float *xp = X + (r_begin + h) * ldx + c0 + 4 * j;
+    const double *ap = A + (r_begin + h) * KP + j;
+    for (long r = r_begin; r < r_end; r += 2 * U) {
+        f32x4 xv[U];
+        float av[U][NCT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xv[u] = *reinterpret_cast<const f32x4 *>(xp + (long)(2 * u) * ldx);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) av[u][ct] = (float)ap[(2 * u) * KP + ct * 32];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[ct][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][ct], xv[u][m],
+                                                                      acc[ct][m], 0, 0, 0);
+        xp += (long)(2 * U) * ldx;
+        ap += (2 * U) * KP;
+    }
+
+    // D layout (32x32): column = lane&31 (-> 4 data columns c0+4j+m), row (component)
+    // = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    float *out = partial + (size_t)blockIdx.y * KP * p_pad;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int comp = ct * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            f32x4 v = {acc[ct][0][reg], acc[ct][1][reg], acc[ct][2][reg], acc[ct][3][reg]};
+            *reinterpret_cast<f32x4 *>(out + (size_t)comp * p_pad + c0 + 4 * j) = v;
+        }
+}
+
+// reduce over rows, float64 VALU: thread = data column, KP accumulators in registers,
+// A[r][*] is wave-uniform (scalar loads).
+template <int KP>
+__global__ __launch_bounds__(256) void k_reduce_rows_f64(const double *__restrict__ X, long ldx,
+                                                         const double *__restrict__ A,
+                                                         long rows_per_slab, long n_pad, int p_pad,
+                                                         double *__restrict__ partial)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p_pad) return;
+    const long r_begin = (long)blockIdx.y * rows_per_slab;
+    long r_end = r_begin + rows_per_slab;
+    if (r_end > n_pad) r_end = n_pad;
+    double acc[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) acc[i] = 0.0;
+    for (long r = r_begin; r < r_end; ++r) {
+        const double x = X[r * ldx + c];
+        const double *a = A + r * KP;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) acc[i] = fma(a[i], x, acc[i]);
+    }
+    double *out = partial + (size_t)blockIdx.y * KP * p_pad;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) out[(size_t)i * p_pad + c] = acc[i];
+}
+
+// second stage of the split-row reduction: fixed summation order => deterministic.
+template <typename TP, typename TO>
+__global__ __launch_bounds__(256) void k_reduce_partials(const TP *__restrict__ partial, long nslab,
+                                                         long elems, double *__restrict__ out,
+                                                         TO *__restrict__ outT)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= elems) return;
+    double s = 0.0;
+    for (long sl = 0; sl < nslab; ++sl) s += (double)partial[sl * elems + idx];
+    out[idx] = s;
+    if (outT) outT[idx] = (TO)s;
+}
+
+// ---------------------------------------------------------------------------
+// row-local, float32 MFMA.  wave owns 32*RT rows; contraction over the columns.
+// A-operand lane l = X[r0 + 32*rt + (l&31)][c + 8u + 4*(l>>5) + m]
+// B-operand lane l = B[32*ct + (l&31)][c + 8u + 4*(l>>5) + m]      (m = 0..3 from one
+// dwordx4 load each); D[row][component]: component = lane&31, row = (reg&3)+8*(reg>>2)+4*(l>>5).
+// ---------------------------------------------------------------------------
+template <int NCT, int RT>
+__global__ __launch_bounds__(256) void k_row_local_f32(const float *__restrict__ X, long ldx,
+                                                       const float *__restrict__ B, int p_pad,
+                                                       double *__restrict__ out, long n_pad)
+{
+    constexpr int KP = 32 * NCT;
+    constexpr int U = 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r0 = ((long)blockIdx.x * 4 + wave) * (32 * RT);
+    if (r0 >= n_pad) return;
+    const int h = lane >> 5, j = lane & 31;
+
+    f32x16 acc[RT][NCT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.f;
+
+    const float *xp = X + (r0 + j) * ldx + 4 * h;
+    const float *bp = B + (long)j * p_pad + 4 * h;
+    for (int c = 0; c < p_pad; c += 8 * U) {
+        f32x4 xv[U][RT], bv[U][NCT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                xv[u][rt] = *reinterpret_cast<const f32x4 *>(xp + (long)(rt * 32) * ldx + c + 8 * u);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                bv[u][ct] = *reinterpret_cast<const f32x4 *>(bp + (long)(ct * 32) * p_pad + c + 8 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            xv[u][rt][m], bv[u][ct][m], acc[rt][ct], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long row = r0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                out[row * KP + ct * 32 + j] = (double)acc[rt][ct][reg];
+            }
+}
+
+// row-local, float64 VALU: block = 64 rows, X tile staged through LDS with coalesced
+// loads; thread (row = t&63, q = t>>6) accumulates the components [q*KP/4, (q+1)*KP/4).
+template <int KP>
+__global__ __launch_bounds__(256) void k_row_local_f64(const double *__restrict__ X, long ldx,
+                                                       const double *__restrict__ B, int p_pad,
+                                                       double *__restrict__ out, long n_pad)
+{
+    constexpr int KQ = KP / 4;
+    __shared__ double tile[64][65];
+    const int t = threadIdx.x, row = t & 63, q = t >> 6;
+    const long r0 = (long)blockIdx.x * 64;
+    if (r0 >= n_pad) return;
+    double acc[KQ];
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) acc[i] = 0.0;
+    for (int c0 = 0; c0 < p_pad; c0 += 64) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int idx = e * 256 + t;
+            tile[idx >> 6][idx & 63] = X[(r0 + (idx >> 6)) * ldx + c0 + (idx & 63)];
+        }
+        __syncthreads();
+        const double *bq = B + (long)(q * KQ) * p_pad + c0;
+        for (int cc = 0; cc < 64; ++cc) {
+            const double x = tile[row][cc];
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) acc[i] = fma(x, bq[(long)i * p_pad + cc], acc[i]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) out[(r0 + row) * KP + q * KQ + i] = acc[i];
+}
+
+// ---------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------
+int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *outT, bool main_only)
+{
+    const long elems = (long)c->KP * c->p_pad;
+    dim3 block(256);
+    if (c->dtype == AA_F32) {
+        dim3 grid((unsigned)((c->p_pad + 511) / 512), (unsigned)c->nslab);
+        float *part = c->partial.as<float>();
+        if (c->KP == 32)
+            hipLaunchKernelGGL(k_reduce_rows_f32<1>, grid, block, 0, c->stream, c->X.as<float>(),
+                               c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
+        else
+            hipLaunchKernelGGL(k_reduce_rows_f32<2>, grid, block, 0, c->stream, c->X.as<float>(),
+                               c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
+        float *oT = (c->world > 1) ? nullptr : reinterpret_cast<float *>(outT);
+        if (!main_only)
+            hipLaunchKernelGGL((k_reduce_partials<float, float>), dim3((unsigned)((elems + 255) / 256)),
+                           block, 0, c->stream, part, c->nslab, elems, out_wide, oT);
+    } else {
+        dim3 grid((unsigned)((c->p_pad + 255) / 256), (unsigned)c->nslab);
+        double *part = c->partial.as<double>();
+        if (c->KP == 32)
+            hipLaunchKernelGGL(k_reduce_rows_f64<32>, grid, block, 0, c->stream, c->X.as<double>(),
+                               c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
+        else
+            hipLaunchKernelGGL(k_reduce_rows_f64<64>, grid, block, 0, c->stream, c->X.as<double>(),
+                               c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
+        double *oT = (c->world > 1 || outT == (void *)out_wide) ? nullptr
+                                                                : reinterpret_cast<double *>(outT);
+        if (!main_only)
+            hipLaunchKernelGGL((k_reduce_partials<double, double>),
+                           dim3((unsigned)((elems + 255) / 256)), block, 0, c->stream, part,
+                           c->nslab, elems, out_wide, oT);
+    }
+    AA_CHECK_HIP(hipGetLastError());
+    if (main_only) return AA_OK;
+    if (c->world > 1) {
+        AA_CHECK(comm_allreduce(c, out_wide, elems, 0));
+        if (outT && outT != (void *)out_wide) AA_CHECK(launch_wide_to_T(c, out_wide, outT));
+    }
+    return AA_OK;
+}
+
+int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
+{
+    dim3 block(256);
+    if (c->dtype == AA_F32) {
+        const float *B = reinterpret_cast<const float *>(B_wideT);
+        if (c->KP == 32) {
+            constexpr int RT = 2;
+            dim3 grid((unsigned)((c->n_pad + 128 * RT - 1) / (128 * RT)));
+            hipLaunchKernelGGL((k_row_local_f32<1, RT>), grid, block, 0, c->stream,
+                               c->X.as<float>(), c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
+        } else {
+            constexpr int RT = 1;
+            dim3 grid((unsigned)((c->n_pad + 128 * RT - 1) / (128 * RT)));
+            hipLaunchKernelGGL((k_row_local_f32<2, RT>), grid, block, 0, c->stream,
+                               c->X.as<float>(), c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
+        }
+    } else {
+        const double *B = reinterpret_cast<const double *>(B_wideT);
+        dim3 grid((unsigned)(c->n_pad / 64));
+        if (c->KP == 32)
+            hipLaunchKernelGGL(k_row_local_f64<32>, grid, block, 0, c->stream, c->X.as<double>(),
+                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
+        else
+            hipLaunchKernelGGL(k_row_local_f64<64>, grid, block, 0, c->stream, c->X.as<double>(),
+                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
+    }
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+}  // namespace aa

@@ -1,0 +1,1000 @@
+// kernels_tall.hip -- the HBM/latency-bound float64 kernels around the GEMMs:
+// column-wise simplex projection of the transposed dictionary (the reference's
+// simplex_project_rows on the k x n dictionary, simplex_projection.py:40-47, called at
+// spg.py:148,184,193,250), gradient assembly (archetypal_analysis.py:284-301), SPG
+// reductions (spg.py:206,237-238,252), small Gram products (archetypal_analysis.py:
+// 543-556,618-621,640-643), and the single-thread "scalar stage" kernels that carry
+// the SPG control arithmetic (spg.py:19-43,153-266) on the device.
+//
+// "tall" arrays are [n_pad][KP] doubles, component on the fast axis: thread t of a
+// 256-thread block handles component t % KP of row (t / KP) + RS*step, so every wave
+// touches whole 256-byte rows (coalesced).  Every reduction is two-stage with a fixed
+// summation order (per-block partials, then one finalize block) => deterministic,
+// and the finalize step is where the multi-GPU all-reduce is spliced in.
+//
+// The simplex projection does not sort: per column it runs Michelot's fixed point
+//   S <- {w > t},  t <- (sum_S w - 1)/|S|,   starting from t = max(w) - 1,
+// which ends at exactly the support the reference's sorted scan finds and the same
+// closed form t = (sum of the m largest - 1)/m (simplex_projection.py:23).
+#include "aa_internal.h"
+
+namespace aa {
+
+// ---------------------------------------------------------------- helpers
+template <int KP, int NV>
+__device__ __forceinline__ void block_col_combine(const double (&v)[NV], unsigned max_mask,
+                                                  double *sm, double *dst)
+{
+    constexpr int RS = 256 / KP;
+    const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
+#pragma unroll
+    for (int a = 0; a < NV; ++a) sm[a * 256 + t] = v[a];
+    __syncthreads();
+    if (rsub == 0) {
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+            double s = sm[a * 256 + comp];
+            if ((max_mask >> a) & 1u) {
+                for (int q = 1; q < RS; ++q) s = fmax(s, sm[a * 256 + q * KP + comp]);
+            } else {
+                for (int q = 1; q < RS; ++q) s += sm[a * 256 + q * KP + comp];
+            }
+            dst[a * KP + comp] = s;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double load_a(double a_const, const double *scal, int a_slot)
+{
+    return a_slot >= 0 ? scal[a_slot] : a_const;
+}
+
+// ---------------------------------------------------------------- projection passes
+// w[r][i] = x[r][i] - a * g[r][i]   (g == nullptr => w = x)
+template <int KP>
+__global__ __launch_bounds__(256) void k_proj_colmax(const double *__restrict__ x,
+                                                     const double *__restrict__ g, double a_const,
+                                                     const double *__restrict__ scal, int a_slot,
+                                                     long n, long rows_pb, int k,
+                                                     double *__restrict__ partial)
+{
+    __shared__ double sm[256];
+    constexpr int RS = 256 / KP;
+    const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
+    const double a = load_a(a_const, scal, a_slot);
+    const long rb = (long)blockIdx.x * rows_pb;
+    long re = rb + rows_pb;
+    if (re > n) re = n;
+    double m[1] = {-INFINITY};
+    if (comp < k)
+        for (long r = rb + rsub; r < re; r += RS) {
+            const double w = g ? x[r * KP + comp] - a * g[r * KP + comp] : x[r * KP + comp];
+            m[0] = fmax(m[0], w);
+        }
+    block_col_combine<KP, 1>(m, 1u, sm, partial + (size_t)blockIdx.x * KP);
+}
+
+template <int KP>
+__global__ __launch_bounds__(256) void k_proj_pass(const double *__restrict__ x,
+                                                   const double *__restrict__ g, double a_const,
+                                                   const double *__restrict__ scal, int a_slot,
+                                                   long n, long rows_pb, int k,
+                                                   const ProjState *__restrict__ ps,
+                                                   double *__restrict__ partial)
+{
+    if (ps->done) return;   // uniform: every thread reads the same word
+    __shared__ double sm[2 * 256];
+    constexpr int RS = 256 / KP;
+    const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
+    const double a = load_a(a_const, scal, a_slot);
+    const long rb = (long)blockIdx.x * rows_pb;
+    long re = rb + rows_pb;
+    if (re > n) re = n;
+    double v[2] = {0.0, 0.0};
+    if (comp < k) {
+        const double th = ps->t[comp];
+        for (long r = rb + rsub; r < re; r += RS) {
+            const double w = g ? x[r * KP + comp] - a * g[r * KP + comp] : x[r * KP + comp];
+            if (w > th) {
+                v[0] += w;
+                v[1] += 1.0;
+            }
+        }
+    }
+    block_col_combine<KP, 2>(v, 0u, sm, partial + (size_t)blockIdx.x * 2 * KP);
+}
+
+// mode: PROJ_FEAS  out = max(w - t, 0)                                   (spg.py:148)
+//       PROJ_ALPHA v3 = max |max(w-t,0) - x|                             (spg.py:184)
+//       PROJ_DIR   out = d = max(w-t,0) - x; v0 = <d,g>, v1 = <d,d>, v2 = <d, H alpha>
+//       PROJ_RES   v0 = sum res^2, v3 = max |res|                        (spg.py:250-263)
+template <int KP>
+__global__ __launch_bounds__(256) void k_proj_finish(int mode, const double *__restrict__ x,
+                                                     const double *__restrict__ g, double a_const,
+                                                     const double *__restrict__ scal, int a_slot,
+                                                     const double *__restrict__ H,
+                                                     const double *__restrict__ alpha, long n,
+                                                     long rows_pb, int k,
+                                                     const ProjState *__restrict__ ps,
+                                                     double *__restrict__ out,
+                                                     double *__restrict__ partial)
+{
+    __shared__ double sm[4 * 256];
+    constexpr int RS = 256 / KP;
+    const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
+    const double a = load_a(a_const, scal, a_slot);
+    const long rb = (long)blockIdx.x * rows_pb;
+    long re = rb + rows_pb;
+    if (re > n) re = n;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (comp < k) {
+        const double th = ps->t[comp];
+        const double al = alpha ? alpha[comp] : 1.0;
+        for (long r = rb + rsub; r < re; r += RS) {
+            const long e = r * KP + comp;
+            const double xe = x[e];
+            const double ge = g ? g[e] : 0.0;
+            const double w = g ? xe - a * ge : xe;
+            const double pr = fmax(w - th, 0.0);
+            if (mode == PROJ_FEAS) {
+                out[e] = pr;
+            } else {
+                const double d = pr - xe;
+                if (mode == PROJ_DIR) {
+                    out[e] = d;
+                    v[0] += d * ge;
+                    v[1] += d * d;
+                    v[2] += d * H[e] * al;
+                } else if (mode == PROJ_RES) {
+                    v[0] += d * d;
+                    v[3] = fmax(v[3], fabs(d));
+                } else {
+                    v[3] = fmax(v[3], fabs(d));
+                }
+            }
+        }
+    }
+    block_col_combine<KP, 4>(v, 8u, sm, partial + (size_t)blockIdx.x * 4 * KP);
+}
+
+// ---------------------------------------------------------------- finalize
+// partial [nb][NV][KP] -> red [NV][KP] (fixed order).  One block of 256 threads.
+__global__ __launch_bounds__(256) void k_finalize_sum(const double *__restrict__ partial, int nb,
+                                                      int NV, int KP, unsigned max_mask,
+                                                      double *__restrict__ red,
+                                                      const ProjState *__restrict__ ps_gate)
+{
+    if (ps_gate && ps_gate->done) return;
+    __shared__ double sm[256];
+    const int RS = 256 / KP;
+    const int t = threadIdx.x, comp = t % KP, part = t / KP;
+    for (int a = 0; a < NV; ++a) {
+        const bool is_max = (max_mask >> a) & 1u;
+        double s = is_max ? -INFINITY : 0.0;
+        for (int b = part; b < nb; b += RS) {
+            const double val = partial[((size_t)b * NV + a) * KP + comp];
+            s = is_max ? fmax(s, val) : s + val;
+        }
+        sm[t] = s;
+        __syncthreads();
+        if (part == 0) {
+            for (int q = 1; q < RS; ++q) {
+                const double val = sm[q * KP + comp];
+                s = is_max ? fmax(s, val) : s + val;
+            }
+            red[a * KP + comp] = s;
+        }
+        __syncthreads();
+    }
+}
+
+enum { POST_COLMAX = 0, POST_MICHELOT, POST_FIN, POST_SCALAR_SUM };
+
+// red [NV][KP] -> projection state / scalars.  One block, >= KP threads.
+__global__ __launch_bounds__(64) void k_post(int kind, int mode, const double *__restrict__ red,
+                                             int KP, int k, ProjState *__restrict__ ps,
+                                             double *__restrict__ scal, int slot)
+{
+    const int i = threadIdx.x;
+    if (kind == POST_COLMAX) {
+        if (i < k) {
+            ps->t[i] = red[i] - 1.0;   // t* >= max - 1
+            ps->cnt[i] = 0.0;
+        }
+        if (i == 0) {
+            ps->done = 0;
+            ps->passes = 0;
+        }
+    } else if (kind == POST_MICHELOT) {
+        if (ps->done) return;
+        __shared__ int all_conv;
+        if (i == 0) all_conv = 1;
+        __syncthreads();
+        if (i < k) {
+            const double s = red[i], cnt = red[KP + i], prev = ps->cnt[i];
+            // converged when the support stops shrinking (>= guards against a
+            // last-bit oscillation of the threshold)
+            const bool conv = (prev > 0.0) && (cnt >= prev);
+            if (cnt > 0.0) ps->t[i] = (s - 1.0) / cnt;
+            ps->cnt[i] = cnt;
+            if (!conv) atomicAnd(&all_conv, 0);
+        }
+        __syncthreads();
+        if (i == 0) {
+            ps->passes += 1;
+            if (all_conv) ps->done = 1;
+        }
+    } else if (kind == POST_FIN) {
+        if (i == 0) {
+            double s0 = 0, s1 = 0, s2 = 0, m3 = 0;
+            for (int c = 0; c < k; ++c) {
+                s0 += red[c];
+                s1 += red[KP + c];
+                s2 += red[2 * KP + c];
+                m3 = fmax(m3, red[3 * KP + c]);
+            }
+            if (mode == PROJ_DIR) {
+                scal[SC_DELTA] = s0;
+                scal[SC_DD] = s1;
+                scal[SC_S1D] = s2;
+            } else if (mode == PROJ_RES) {
+                scal[SC_RES2] = s0;
+                scal[SC_RESINF] = m3;
+            } else if (mode == PROJ_ALPHA) {
+                scal[SC_AINV] = m3;
+            }
+            if (!ps->done)
+                scal[SC_FLAGS] = (double)((int)scal[SC_FLAGS] | AA_SPG_FLAG_PROJ_UNCONV);
+        }
+    } else if (kind == POST_SCALAR_SUM) {
+        if (i == 0) {
+            double s = 0;
+            for (int c = 0; c < k; ++c) s += red[c];
+            scal[slot] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- gradient
+// g[r][i] = (sum_j M[i][j] * Graw[r][j] - H[r][i] * alpha[i]) * scale
+//   data form:   Graw = (C X X')', H = XX'Z, scale = 1/n   (archetypal_analysis.py:293-301)
+//   kernel form: Graw = (C K)',    H = K Z,  scale = 1/k   (archetypal_analysis.py:284-290)
+// optional: v0 = <d, g>.
+template <int KP>
+__global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
+                                              const double *__restrict__ H,
+                                              const double *__restrict__ M,
+                                              const double *__restrict__ alpha, double scale,
+                                              long n, long rows_pb, int k,
+                                              double *__restrict__ gout,
+                                              const double *__restrict__ d,
+                                              double *__restrict__ partial)
+{
+    constexpr int RS = 256 / KP;
+    __shared__ double Ms[KP][KP + 1];
+    __shared__ double row[RS][KP];
+    __shared__ double sm[256];
+    const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
+    for (int e = t; e < KP * KP; e += 256) Ms[e / KP][e % KP] = M[e];
+    const double al = alpha[comp];
+    const long rb = (long)blockIdx.x * rows_pb;
+    long re = rb + rows_pb;
+    if (re > n) re = n;
+    double v[1] = {0.0};
+    __syncthreads();
+    for (long r0 = rb; r0 < re; r0 += RS) {
+        const long r = r0 + rsub;
+        const bool ok = r < re;
+        row[rsub][comp] = ok ? Graw[r * KP + comp] : 0.0;
+        __syncthreads();
+        if (ok && comp < k) {
+            double s = 0.0;
+            for (int j = 0; j < k; ++j) s = fma(Ms[comp][j], row[rsub][j], s);
+            const double ge = (s - H[r * KP + comp] * al) * scale;
+            gout[r * KP + comp] = ge;
+            if (d) v[0] += d[r * KP + comp] * ge;
+        }
+        __syncthreads();
+    }
+    if (partial) block_col_combine<KP, 1>(v, 0u, sm, partial + (size_t)blockIdx.x * KP);
+}
+
+// v0 = sum x * H * alpha   (tr(C * H D), archetypal_analysis.py:267,279)
+template <int KP>
+__global__ __launch_bounds__(256) void k_tall_dot_scaled(const double *__restrict__ x,
+                                                         const double *__restrict__ H,
+                                                         const double *__restrict__ alpha, long n,
+                                                         long rows_pb, int k,
+                                                         double *__restrict__ partial)
+{
+    __shared__ double sm[256];
+    constexpr int RS = 256 / KP;
+    const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
+    const long rb = (long)blockIdx.x * rows_pb;
+    long re = rb + rows_pb;
+    if (re > n) re = n;
+    double v[1] = {0.0};
+    if (comp < k) {
+        const double al = alpha ? alpha[comp] : 1.0;
+        for (long r = rb + rsub; r < re; r += RS) v[0] += x[r * KP + comp] * H[r * KP + comp] * al;
+    }
+    block_col_combine<KP, 1>(v, 0u, sm, partial + (size_t)blockIdx.x * KP);
+}
+
+// x += lambda * d   (rows < n only; padding stays zero)
+__global__ __launch_bounds__(256) void k_tall_axpy(double *__restrict__ x,
+                                                   const double *__restrict__ d,
+                                                   const double *__restrict__ scal, long elems)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < elems) x[i] = x[i] + scal[SC_LAMBDA] * d[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wide_axpy(double *__restrict__ P,
+                                                   const double *__restrict__ Q,
+                                                   const double *__restrict__ scal, long elems,
+                                                   T *__restrict__ PT)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < elems) {
+        const double v = P[i] + scal[SC_LAMBDA] * Q[i];
+        P[i] = v;
+        if (PT) PT[i] = (T)v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wide_to_T(const double *__restrict__ src, long elems,
+                                                   T *__restrict__ dst)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < elems) dst[i] = (T)src[i];
+}
+
+// ---------------------------------------------------------------- Gram products
+// tall:  out[i][j] = sum_r A[r][i] * B[r][j]      (Z'Z, C (XX'Z), (CK) C')
+template <int KP>
+__global__ __launch_bounds__(256) void k_gram_tall(const double *__restrict__ A,
+                                                   const double *__restrict__ B, long n,
+                                                   long rows_pb, double *__restrict__ partial)
+{
+    constexpr int JT = KP * KP / 256;          // outputs per thread (4 or 16)
+    constexpr int TPI = KP / JT;               // threads per i
+    __shared__ double As[32][KP + 1], Bs[32][KP + 1];
+    const int t = threadIdx.x, i = t / TPI, j0 = (t % TPI) * JT;
+    const long rb = (long)blockIdx.x * rows_pb;
+    long re = rb + rows_pb;
+    if (re > n) re = n;
+    double acc[JT];
+#pragma unroll
+    for (int q = 0; q < JT; ++q) acc[q] = 0.0;
+    for (long r0 = rb; r0 < re; r0 += 32) {
+        for (int e = t; e < 32 * KP; e += 256) {
+            const long r = r0 + e / KP;
+            const bool ok = r < re;
+            As[e / KP][e % KP] = ok ? A[r * KP + e % KP] : 0.0;
+            Bs[e / KP][e % KP] = ok ? B[r * KP + e % KP] : 0.0;
+        }
+        __syncthreads();
+        for (int rr = 0; rr < 32; ++rr) {
+            const double a = As[rr][i];
+#pragma unroll
+            for (int q = 0; q < JT; ++q) acc[q] = fma(a, Bs[rr][j0 + q], acc[q]);
+        }
+        __syncthreads();
+    }
+    double *dst = partial + (size_t)blockIdx.x * KP * KP;
+#pragma unroll
+    for (int q = 0; q < JT; ++q) dst[i * KP + j0 + q] = acc[q];
+}
+
+// wide:  out[i][j] = sum_c A[i][c] * B[j][c]      ((CX)(CX)', (CX)(DX)', (DX)(DX)')
+template <int KP>
+__global__ __launch_bounds__(256) void k_gram_wide(const double *__restrict__ A,
+                                                   const double *__restrict__ B, int ld,
+                                                   double *__restrict__ partial)
+{
+    constexpr int JT = KP * KP / 256;
+    constexpr int TPI = KP / JT;
+    constexpr int CW = 32;
+    __shared__ double As[KP][CW + 1], Bs[KP][CW + 1];
+    const int t = threadIdx.x, i = t / TPI, j0 = (t % TPI) * JT;
+    const int c0 = blockIdx.x * 128;
+    double acc[JT];
+#pragma unroll
+    for (int q = 0; q < JT; ++q) acc[q] = 0.0;
+    for (int cc = 0; cc < 128; cc += CW) {
+        for (int e = t; e < KP * CW; e += 256) {
+            As[e / CW][e % CW] = A[(long)(e / CW) * ld + c0 + cc + e % CW];
+            Bs[e / CW][e % CW] = B[(long)(e / CW) * ld + c0 + cc + e % CW];
+        }
+        __syncthreads();
+        for (int c = 0; c < CW; ++c) {
+            const double a = As[i][c];
+#pragma unroll
+            for (int q = 0; q < JT; ++q) acc[q] = fma(a, Bs[j0 + q][c], acc[q]);
+        }
+        __syncthreads();
+    }
+    double *dst = partial + (size_t)blockIdx.x * KP * KP;
+#pragma unroll
+    for (int q = 0; q < JT; ++q) dst[i * KP + j0 + q] = acc[q];
+}
+
+__global__ __launch_bounds__(256) void k_gram_finalize(const double *__restrict__ partial, int nb,
+                                                       int elems, double *__restrict__ out)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * elems + e];
+    out[e] = s;
+}
+
+// ---------------------------------------------------------------- transposes (kernel form)
+// wide [KP][ld] -> tall [n_pad][KP]
+__global__ __launch_bounds__(256) void k_wide_to_tall(const double *__restrict__ wide, int ld,
+                                                      int KP, long n_pad, double *__restrict__ tall)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const long r0 = (long)blockIdx.x * 32;
+    const int i0 = blockIdx.y * 32;
+    for (int q = ty; q < 32; q += 8) tile[q][tx] = wide[(long)(i0 + q) * ld + r0 + tx];
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) tall[(r0 + q) * KP + i0 + tx] = tile[tx][q];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_tall_to_wide(const double *__restrict__ tall, int KP,
+                                                      int ld, double *__restrict__ wide,
+                                                      T *__restrict__ wideT)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long r0 = (long)blockIdx.x * 32;
+    const int i0 = blockIdx.y * 32;
+    for (int q = ty; q < 32; q += 8) tile[q][tx] = tall[(r0 + q) * KP + i0 + tx];
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {
+        const double v = tile[tx][q];
+        if (wide) wide[(long)(i0 + q) * ld + r0 + tx] = v;
+        if (wideT) wideT[(long)(i0 + q) * ld + r0 + tx] = (T)v;
+    }
+}
+
+// ---------------------------------------------------------------- scalar stages
+__device__ double dev_line_search_step(double lam, double delta, double f_old, double f_new,
+                                       double s1, double s2)
+{   // spg.py:19-33
+    const double tmp = -0.5 * lam * lam * delta / (f_new - f_old - lam * delta);
+    if (s1 <= tmp && tmp <= s2 * lam) return tmp;
+    return 0.5 * lam;
+}
+
+__device__ double dev_trace_MG(const double *M, const double *G, int k, int KP)
+{   // tr(M * G)
+    double s = 0.0;
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) s += M[i * KP + j] * G[j * KP + i];
+    return s;
+}
+
+// gram: [0] = C K C' (or (CX)(CX)'), [1] = cross1, [2] = D K D', [3] = cross2
+__global__ void k_scalar_stage(int stage, double *__restrict__ sc, const double *__restrict__ gram,
+                               const double *__restrict__ M, int k, int KP, aa_spg_params sp,
+                               int cross2_is_transpose)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int GS = KP * KP;
+    if (stage == ST_INIT_F) {            // spg.py:153-157
+        const double a0 = dev_trace_MG(M, gram, k, KP);
+        sc[SC_A0] = a0;
+        sc[SC_F_OLD] = 0.5 * (sc[SC_TRACE] - 2.0 * sc[SC_S1] + a0) / sc[SC_FNORM];
+        sc[SC_NFEVAL] = 1.0;
+        sc[SC_FLAGS] = 0.0;
+        for (int i = 0; i < 16; ++i) sc[SC_FMEM0 + i] = 0.0;   // f_mem = zeros (spg.py:153)
+        sc[SC_ALPHA_SET] = (sp.alpha0 >= 0.0) ? 1.0 : 0.0;
+        sc[SC_ALPHA] = sp.alpha0;
+    } else if (stage == ST_ALPHA) {      // spg.py:178-189
+        if (sc[SC_ALPHA_SET] == 0.0) {
+            const double ainv = sc[SC_AINV];
+            sc[SC_ALPHA] = (fabs(ainv) > 1e-12) ? 1.0 / ainv : 1.0;
+            sc[SC_ALPHA_SET] = 1.0;
+        }
+    } else if (stage == ST_LINESEARCH) { // spg.py:196-229, f along x + lambda d in closed form
+        double a1 = dev_trace_MG(M, gram + GS, k, KP);
+        if (cross2_is_transpose) {
+            double s = 0.0;                 // tr(M * cross1')
+            for (int i = 0; i < k; ++i)
+                for (int j = 0; j < k; ++j) s += M[i * KP + j] * gram[GS + i * KP + j];
+            a1 += s;
+        } else {
+            a1 += dev_trace_MG(M, gram + 3 * GS, k, KP);
+        }
+        const double a2 = dev_trace_MG(M, gram + 2 * GS, k, KP);
+        const double tr = sc[SC_TRACE], s1 = sc[SC_S1], s1d = sc[SC_S1D], a0 = sc[SC_A0];
+        const double fn = sc[SC_FNORM], f_old = sc[SC_F_OLD], delta = sc[SC_DELTA];
+        int mem = sp.memory < 1 ? 1 : (sp.memory > 16 ? 16 : sp.memory);
+        for (int i = mem - 1; i > 0; --i) sc[SC_FMEM0 + i] = sc[SC_FMEM0 + i - 1];
+        sc[SC_FMEM0] = f_old;
+        double f_max = sc[SC_FMEM0];
+        for (int i = 1; i < mem; ++i) f_max = (sc[SC_FMEM0 + i] >= f_max) ? sc[SC_FMEM0 + i] : f_max;
+        double lam = 1.0;
+        double nfe = sc[SC_NFEVAL];
+        int flags = (int)sc[SC_FLAGS];
+        double f_new = 0.5 * (tr - 2.0 * (s1 + lam * s1d) + a0 + lam * a1 + lam * lam * a2) / fn;
+        nfe += 1.0;
+        int guard = 0;
+        while (f_new > f_max + sp.gamma * lam * delta && guard < 200) {
+            lam = dev_line_search_step(lam, delta, f_old, f_new, sp.sigma_one, sp.sigma_two);
+            f_new = 0.5 * (tr - 2.0 * (s1 + lam * s1d) + a0 + lam * a1 + lam * lam * a2) / fn;
+            nfe += 1.0;
+            ++guard;
+            if (fabs(lam) < sp.lambda_min) {
+                flags |= AA_SPG_FLAG_LAMBDA_MIN;
+                break;
+            }
+        }
+        sc[SC_LAMBDA] = lam;
+        sc[SC_F_NEW] = f_new;
+        sc[SC_S1] = s1 + lam * s1d;
+        sc[SC_A0] = a0 + lam * a1 + lam * lam * a2;
+        sc[SC_A1] = a1;
+        sc[SC_A2] = a2;
+        sc[SC_NFEVAL] = nfe;
+        sc[SC_FLAGS] = (double)flags;
+    } else if (stage == ST_BB) {         // spg.py:232-244
+        const double lam = sc[SC_LAMBDA];
+        const double sksk = lam * lam * sc[SC_DD];
+        const double beta = lam * (sc[SC_DGN] - sc[SC_DELTA]);
+        double al;
+        if (beta <= 0.0) al = sp.alpha_max;
+        else al = fmin(sp.alpha_max, fmax(sp.alpha_min, sksk / beta));
+        sc[SC_ALPHA] = al;
+        sc[SC_F_OLD] = sc[SC_F_NEW];
+        sc[SC_NFEVAL] += 1.0;
+    } else if (stage == ST_CONV) {       // spg.py:246-276
+        const double rn = sqrt(sc[SC_RES2]);
+        sc[SC_RES2] = rn * rn;
+        bool conv = rn < sp.epsilon_two;
+        if (sp.use_infinity_norm) conv = conv || (sc[SC_RESINF] < sp.epsilon_one);
+        int flags = (int)sc[SC_FLAGS];
+        if (conv) flags |= AA_SPG_FLAG_CONVERGED;
+        else if (sc[SC_NFEVAL] > (double)sp.max_feval) flags |= AA_SPG_FLAG_MAX_FEVAL;
+        sc[SC_FLAGS] = (double)flags;
+    }
+}
+
+// ---------------------------------------------------------------- data-matrix reductions
+template <typename T>
+__global__ __launch_bounds__(256) void k_sqnorm(const T *__restrict__ X, long ldx, long n, int p,
+                                                double *__restrict__ partial)
+{
+    __shared__ double sm[256];
+    double s = 0.0;
+    for (long r = blockIdx.x; r < n; r += gridDim.x)
+        for (int c = threadIdx.x; c < p; c += 256) {
+            const double v = (double)X[r * ldx + c];
+            s = fma(v, v, s);
+        }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_diag_sum(const T *__restrict__ K, long ldx, long n,
+                                                  long col_offset, double *__restrict__ partial)
+{
+    __shared__ double sm[256];
+    double s = 0.0;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < n; r += (long)gridDim.x * 256)
+        s += (double)K[r * ldx + col_offset + r];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// d[i] = sqrt(max(0, <xi,xi> - 2 <xi,xj> + <xj,xj>)), one wave per row; the three dot
+// products use the same lane partition and butterfly so that i == j gives exactly 0
+// (archetypal_analysis.py:95-100 on K = XX' without forming K).
+template <typename T>
+__global__ __launch_bounds__(256) void k_distance_data(const T *__restrict__ X, long ldx, long n,
+                                                       int p_pad, const T *__restrict__ xj,
+                                                       double *__restrict__ d)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + wave;
+    if (r >= n) return;
+    double sii = 0.0, sij = 0.0, sjj = 0.0;
+    for (int c = lane; c < p_pad; c += 64) {
+        const double a = (double)X[r * ldx + c], b = (double)xj[c];
+        sii = fma(a, a, sii);
+        sij = fma(a, b, sij);
+        sjj = fma(b, b, sjj);
+    }
+    sii = wave_sum(sii);
+    sij = wave_sum(sij);
+    sjj = wave_sum(sjj);
+    if (lane == 0) d[r] = sqrt(fmax(sii - 2.0 * sij + sjj, 0.0));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_distance_kernel(const T *__restrict__ K, long ldx, long n,
+                                                         long j, double *__restrict__ d)
+{
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const double kd = (double)K[r * ldx + r], kj = (double)K[r * ldx + j],
+                 jj = (double)K[j * ldx + j];
+    d[r] = sqrt(kd - 2.0 * kj + jj);
+}
+
+// sum_r || x_r - sum_i z[r][i] * alpha[i] * W[i][:] ||^2, one wave per row.
+template <typename T, int KP>
+__global__ __launch_bounds__(256) void k_residual(const T *__restrict__ X, long ldx, long n,
+                                                  int p_pad, const double *__restrict__ Z,
+                                                  const double *__restrict__ W,
+                                                  const double *__restrict__ alpha, int k,
+                                                  double *__restrict__ partial)
+{
+    __shared__ double zs[4][KP];
+    __shared__ double ws[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + wave;
+    double s = 0.0;
+    if (r < n) {
+        if (lane < KP) zs[wave][lane] = (lane < k) ? Z[r * KP + lane] * (alpha ? alpha[lane] : 1.0) : 0.0;
+    }
+    __syncthreads();
+    if (r < n) {
+        for (int c = lane; c < p_pad; c += 64) {
+            double rec = 0.0;
+            for (int i = 0; i < k; ++i) rec = fma(zs[wave][i], W[(long)i * p_pad + c], rec);
+            const double df = (double)X[r * ldx + c] - rec;
+            s = fma(df, df, s);
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) ws[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ partial, long nb,
+                                                      double *__restrict__ out)
+{
+    __shared__ double sm[256];
+    double s = 0.0;
+    for (long b = threadIdx.x; b < nb; b += 256) s += partial[b];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+// ===========================================================================
+// host launchers
+// ===========================================================================
+static inline long tall_rows_pb(const Ctx *c)
+{
+    const int RS = 256 / c->KP;
+    long rpb = (c->n + c->tallBlocks - 1) / c->tallBlocks;
+    return round_up(rpb < RS ? RS : rpb, RS);
+}
+
+int tall_setup(Ctx *c)
+{
+    long nb = (c->n + 127) / 128;
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    c->tallBlocks = (int)nb;
+    // gram partials: tall grams use tallBlocks blocks, wide grams p_pad/128 blocks
+    long gb = nb > c->p_pad / 128 ? nb : c->p_pad / 128;
+    size_t need = (size_t)gb * c->KP * c->KP * sizeof(double);
+    size_t need2 = (size_t)nb * 4 * c->KP * sizeof(double) + 4 * c->KP * sizeof(double);
+    // residual / distance partials: one per 4 rows
+    size_t need3 = (size_t)((c->n + 3) / 4 + 1024) * sizeof(double);
+    if (need2 > need) need = need2;
+    if (need3 > need) need = need3;
+    AA_CHECK(c->redPartial.alloc(need + 4096));
+    AA_CHECK(c->gramOut.alloc((size_t)4 * c->KP * c->KP * sizeof(double)));
+    AA_CHECK(c->redOut.alloc((size_t)8 * c->KP * sizeof(double)));
+    AA_CHECK(c->scalars.alloc(SC_COUNT * sizeof(double)));
+    AA_CHECK(c->proj.alloc(sizeof(ProjState)));
+    AA_CHECK(c->Mdev.alloc((size_t)c->KP * c->KP * sizeof(double)));
+    AA_CHECK(c->alphaDev.alloc((size_t)c->KP * sizeof(double)));
+    return AA_OK;
+}
+
+static inline double *red_buf(Ctx *c) { return c->redOut.as<double>(); }
+
+static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mode, int slot,
+                             bool gated)
+{
+    double *part = c->redPartial.as<double>();
+    double *red = red_buf(c);
+    ProjState *ps = c->proj.as<ProjState>();
+    hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(256), 0, c->stream, part, c->tallBlocks, NV,
+                       c->KP, max_mask, red, gated ? ps : (const ProjState *)nullptr);
+    if (c->world > 1) {
+        // sums and maxima are reduced separately; layout red[a][KP]
+        for (int a = 0; a < NV; ++a) {
+            const int op = (max_mask >> a) & 1u;
+            AA_CHECK(comm_allreduce(c, red + (size_t)a * c->KP, c->KP, op));
+        }
+    }
+    hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, c->stream, kind, mode, red, c->KP, c->k, ps,
+                       c->scalars.as<double>(), slot);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+#define TALL_DISPATCH(KERNEL, ...)                                                          \
+    do {                                                                                    \
+        if (c->KP == 32)                                                                    \
+            hipLaunchKernelGGL(KERNEL<32>, dim3(c->tallBlocks), dim3(256), 0, c->stream,    \
+                               __VA_ARGS__);                                                \
+        else                                                                                \
+            hipLaunchKernelGGL(KERNEL<64>, dim3(c->tallBlocks), dim3(256), 0, c->stream,    \
+                               __VA_ARGS__);                                                \
+    } while (0)
+
+// Maximum Michelot passes enqueued per projection.  Passes after convergence exit
+// at their first instruction (device-side `done` flag), so no host sync is needed.
+static int g_proj_max_passes = 24;
+
+int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode)
+{
+    const long rpb = tall_rows_pb(c);
+    double *part = c->redPartial.as<double>();
+    const double *scal = c->scalars.as<double>();
+    ProjState *ps = c->proj.as<ProjState>();
+    TALL_DISPATCH(k_proj_colmax, x, g, a_const, scal, a_slot, c->n, rpb, c->k, part);
+    AA_CHECK(finalize_and_post(c, 1, 1u, POST_COLMAX, 0, 0, false));
+    for (int it = 0; it < g_proj_max_passes; ++it) {
+        TALL_DISPATCH(k_proj_pass, x, g, a_const, scal, a_slot, c->n, rpb, c->k,
+                      (const ProjState *)ps, part);
+        AA_CHECK(finalize_and_post(c, 2, 0u, POST_MICHELOT, 0, 0, true));
+    }
+    double *out = nullptr;
+    if (mode == PROJ_FEAS) out = const_cast<double *>(x);
+    if (mode == PROJ_DIR) out = c->Dt.as<double>();
+    TALL_DISPATCH(k_proj_finish, mode, x, g, a_const, scal, a_slot, c->H.as<double>(),
+                  c->alphaDev.as<double>(), c->n, rpb, c->k, (const ProjState *)ps, out, part);
+    AA_CHECK(finalize_and_post(c, 4, 8u, POST_FIN, mode, 0, false));
+    return AA_OK;
+}
+
+int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, double scale,
+                const double *d_for_dot, int dot_slot)
+{
+    const long rpb = tall_rows_pb(c);
+    double *part = c->redPartial.as<double>();
+    TALL_DISPATCH(k_grad, Graw, H, c->Mdev.as<double>(), c->alphaDev.as<double>(), scale, c->n,
+                  rpb, c->k, gout, d_for_dot, d_for_dot ? part : (double *)nullptr);
+    AA_CHECK_HIP(hipGetLastError());
+    if (d_for_dot) AA_CHECK(finalize_and_post(c, 1, 0u, POST_SCALAR_SUM, 0, dot_slot, false));
+    return AA_OK;
+}
+
+int launch_tall_axpy_lambda(Ctx *c, double *x, const double *d)
+{
+    const long elems = c->n * c->KP;
+    hipLaunchKernelGGL(k_tall_axpy, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
+                       x, d, c->scalars.as<double>(), elems);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const double *alpha_dev, int slot)
+{
+    const long rpb = tall_rows_pb(c);
+    double *part = c->redPartial.as<double>();
+    TALL_DISPATCH(k_tall_dot_scaled, x, H, alpha_dev, c->n, rpb, c->k, part);
+    AA_CHECK(finalize_and_post(c, 1, 0u, POST_SCALAR_SUM, 0, slot, false));
+    return AA_OK;
+}
+
+int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev)
+{
+    const long rpb = round_up((c->n + c->tallBlocks - 1) / c->tallBlocks, 32);
+    const int nb = (int)((c->n + rpb - 1) / rpb);
+    double *part = c->redPartial.as<double>();
+    const int elems = c->KP * c->KP;
+    if (c->KP == 32)
+        hipLaunchKernelGGL(k_gram_tall<32>, dim3(nb), dim3(256), 0, c->stream, A, B, c->n, rpb, part);
+    else
+        hipLaunchKernelGGL(k_gram_tall<64>, dim3(nb), dim3(256), 0, c->stream, A, B, c->n, rpb, part);
+    hipLaunchKernelGGL(k_gram_finalize, dim3((elems + 255) / 256), dim3(256), 0, c->stream, part,
+                       nb, elems, out_dev);
+    AA_CHECK_HIP(hipGetLastError());
+    if (c->world > 1) AA_CHECK(comm_allreduce(c, out_dev, elems, 0));
+    return AA_OK;
+}
+
+int launch_gram_wide(Ctx *c, const double *A, const double *B, double *out_dev)
+{
+    const int nb = (int)(c->p_pad / 128);
+    double *part = c->redPartial.as<double>();
+    const int elems = c->KP * c->KP;
+    if (c->KP == 32)
+        hipLaunchKernelGGL(k_gram_wide<32>, dim3(nb), dim3(256), 0, c->stream, A, B, (int)c->p_pad, part);
+    else
+        hipLaunchKernelGGL(k_gram_wide<64>, dim3(nb), dim3(256), 0, c->stream, A, B, (int)c->p_pad, part);
+    hipLaunchKernelGGL(k_gram_finalize, dim3((elems + 255) / 256), dim3(256), 0, c->stream, part,
+                       nb, elems, out_dev);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;   // wide operands are already replicated across ranks
+}
+
+int launch_wide_axpy_lambda(Ctx *c, double *P, const double *Q, void *PT)
+{
+    const long elems = (long)c->KP * c->p_pad;
+    dim3 grid((unsigned)((elems + 255) / 256));
+    if (c->dtype == AA_F32)
+        hipLaunchKernelGGL(k_wide_axpy<float>, grid, dim3(256), 0, c->stream, P, Q,
+                           c->scalars.as<double>(), elems, reinterpret_cast<float *>(PT));
+    else
+        hipLaunchKernelGGL(k_wide_axpy<double>, grid, dim3(256), 0, c->stream, P, Q,
+                           c->scalars.as<double>(), elems,
+                           (PT == (void *)P) ? (double *)nullptr : reinterpret_cast<double *>(PT));
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_wide_to_T(Ctx *c, const double *src, void *dstT)
+{
+    const long elems = (long)c->KP * c->p_pad;
+    dim3 grid((unsigned)((elems + 255) / 256));
+    if (c->dtype == AA_F32) {
+        hipLaunchKernelGGL(k_wide_to_T<float>, grid, dim3(256), 0, c->stream, src, elems,
+                           reinterpret_cast<float *>(dstT));
+    } else if (dstT != (const void *)src) {
+        hipLaunchKernelGGL(k_wide_to_T<double>, grid, dim3(256), 0, c->stream, src, elems,
+                           reinterpret_cast<double *>(dstT));
+    }
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_transpose_wide_to_tall(Ctx *c, const double *wide, double *tall)
+{
+    dim3 grid((unsigned)(c->n_pad / 32), (unsigned)(c->KP / 32));
+    hipLaunchKernelGGL(k_wide_to_tall, grid, dim3(256), 0, c->stream, wide, (int)c->p_pad, c->KP,
+                       c->n_pad, tall);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_transpose_tall_to_wide(Ctx *c, const double *tall, double *wide, void *wideT)
+{
+    dim3 grid((unsigned)(c->n_pad / 32), (unsigned)(c->KP / 32));
+    if (c->dtype == AA_F32)
+        hipLaunchKernelGGL(k_tall_to_wide<float>, grid, dim3(256), 0, c->stream, tall, c->KP,
+                           (int)c->p_pad, wide, reinterpret_cast<float *>(wideT));
+    else
+        hipLaunchKernelGGL(k_tall_to_wide<double>, grid, dim3(256), 0, c->stream, tall, c->KP,
+                           (int)c->p_pad, wide,
+                           (wideT == (void *)wide) ? (double *)nullptr
+                                                   : reinterpret_cast<double *>(wideT));
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_scalar_stage(Ctx *c, int stage, const aa_spg_params *sp, int cross2_is_transpose)
+{
+    hipLaunchKernelGGL(k_scalar_stage, dim3(1), dim3(1), 0, c->stream, stage,
+                       c->scalars.as<double>(), c->gramOut.as<double>(), c->Mdev.as<double>(),
+                       c->k, c->KP, *sp, cross2_is_transpose);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_row_sqnorm_sum(Ctx *c, double *trace_out_host)
+{
+    double *part = c->redPartial.as<double>();
+    const int nb = 512;
+    if (c->form == AA_FORM_DATA) {
+        if (c->dtype == AA_F32)
+            hipLaunchKernelGGL(k_sqnorm<float>, dim3(nb), dim3(256), 0, c->stream, c->X.as<float>(),
+                               c->p_pad, c->n, (int)c->p, part);
+        else
+            hipLaunchKernelGGL(k_sqnorm<double>, dim3(nb), dim3(256), 0, c->stream,
+                               c->X.as<double>(), c->p_pad, c->n, (int)c->p, part);
+    } else {
+        if (c->dtype == AA_F32)
+            hipLaunchKernelGGL(k_diag_sum<float>, dim3(nb), dim3(256), 0, c->stream,
+                               c->X.as<float>(), c->p_pad, c->n, c->row_offset, part);
+        else
+            hipLaunchKernelGGL(k_diag_sum<double>, dim3(nb), dim3(256), 0, c->stream,
+                               c->X.as<double>(), c->p_pad, c->n, c->row_offset, part);
+    }
+    double *out = red_buf(c);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, part, (long)nb, out);
+    AA_CHECK_HIP(hipGetLastError());
+    if (c->world > 1) AA_CHECK(comm_allreduce(c, out, 1, 0));
+    AA_CHECK_HIP(hipMemcpyAsync(trace_out_host, out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return AA_OK;
+}
+
+// xj_dev: T-typed copy of global row j (p_pad entries) already resident in wideScratch.
+int launch_distance_column(Ctx *c, long j_local, int owner_has_row, const double *xj_host,
+                           double *d_host)
+{
+    (void)owner_has_row;
+    (void)xj_host;
+    double *dd = c->tmpTall.as<double>();
+    if (c->form == AA_FORM_DATA) {
+        dim3 grid((unsigned)((c->n + 3) / 4));
+        if (c->dtype == AA_F32)
+            hipLaunchKernelGGL(k_distance_data<float>, grid, dim3(256), 0, c->stream,
+                               c->X.as<float>(), c->p_pad, c->n, (int)c->p_pad,
+                               c->wideScratch.as<float>(), dd);
+        else
+            hipLaunchKernelGGL(k_distance_data<double>, grid, dim3(256), 0, c->stream,
+                               c->X.as<double>(), c->p_pad, c->n, (int)c->p_pad,
+                               c->wideScratch.as<double>(), dd);
+    } else {
+        dim3 grid((unsigned)((c->n + 255) / 256));
+        if (c->dtype == AA_F32)
+            hipLaunchKernelGGL(k_distance_kernel<float>, grid, dim3(256), 0, c->stream,
+                               c->X.as<float>(), c->p_pad, c->n, j_local, dd);
+        else
+            hipLaunchKernelGGL(k_distance_kernel<double>, grid, dim3(256), 0, c->stream,
+                               c->X.as<double>(), c->p_pad, c->n, j_local, dd);
+    }
+    AA_CHECK_HIP(hipGetLastError());
+    AA_CHECK_HIP(hipMemcpyAsync(d_host, dd, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost,
+                                c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return AA_OK;
+}
+
+int launch_residual_cost(Ctx *c, const double *Ztall, const double *Wwide, const double *alpha_dev,
+                         double *out_host)
+{
+    double *part = c->redPartial.as<double>();
+    const long nb = (c->n + 3) / 4;
+    dim3 grid((unsigned)nb);
+#define RESID(T, KPV)                                                                        \
+    hipLaunchKernelGGL((k_residual<T, KPV>), grid, dim3(256), 0, c->stream, c->X.as<T>(),    \
+                       c->p_pad, c->n, (int)c->p_pad, Ztall, Wwide, alpha_dev, c->k, part)
+    if (c->dtype == AA_F32) {
+        if (c->KP == 32) RESID(float, 32); else RESID(float, 64);
+    } else {
+        if (c->KP == 32) RESID(double, 32); else RESID(double, 64);
+    }
+#undef RESID
+    double *out = c->gramOut.as<double>();
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, part, nb, out);
+    AA_CHECK_HIP(hipGetLastError());
+    if (c->world > 1) AA_CHECK(comm_allreduce(c, out, 1, 0));
+    AA_CHECK_HIP(hipMemcpyAsync(out_host, out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return AA_OK;
+}
+
+}  // namespace aa

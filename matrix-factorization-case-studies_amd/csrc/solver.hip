@@ -1,0 +1,870 @@
+// solver.hip -- host drivers of the device-resident solver and the extern "C" surface
+// declared in include/aa_hip.h.
+//
+// Dictionary update = the reference's spg() (spg.py:46-283) specialised to the
+// dictionary objective (archetypal_analysis.py:261-341), restated so that one SPG
+// iteration costs TWO passes over X instead of the reference's seven:
+//   * C X is linear in C:       (C + lam D) X = CX + lam DX            (one pass: DX)
+//   * f is quadratic in C:      f(C + lam D) follows from tr(C H D), tr(D H D) and the
+//                               k x k Grams of CX, DX -> every line-search trial is
+//                               scalar arithmetic (stage kernels, kernels_tall.hip)
+//   * the gradient at the accepted point needs (CX + lam DX) X'         (one pass)
+//     and doubles as the C XX' the weights update consumes (archetypal_analysis.py:619)
+//   * the gradient at the top of the next iteration (spg.py:176) is the one just
+//     computed (spg.py:233).
+// The reference's quirks are kept: f divides by k while the data-form gradient divides
+// by n (archetypal_analysis.py:265 vs :297), f_mem starts as zeros (spg.py:153),
+// sigma_one is an absolute bound (spg.py:28).
+#include "aa_internal.h"
+
+namespace aa {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+static inline size_t esize(const Ctx *c) { return c->dtype == AA_F32 ? 4 : 8; }
+
+// T-typed MFMA operand copy of a wide double array (aliases the array itself in f64)
+static inline void *operandT(Ctx *c, DevBuf &dbl, DevBuf &shadow)
+{
+    return c->dtype == AA_F32 ? shadow.p : dbl.p;
+}
+
+static int ensure_problem(Ctx *c, int k)
+{
+    AA_REQUIRE(c->have_data, AA_ERR_STATE, "set_data must precede the factors");
+    AA_REQUIRE(k >= 1 && k <= AA_MAX_K, AA_ERR_ARG,
+               "n_components = %d unsupported by the HIP backend (1..%d)", k, AA_MAX_K);
+    const int KP = k <= 32 ? 32 : 64;
+    if (c->k == k && c->KP == KP && c->Ct.p) return AA_OK;
+    c->k = k;
+    c->KP = KP;
+    const size_t tall = (size_t)c->n_pad * KP * sizeof(double);
+    const size_t wide = (size_t)KP * c->p_pad * sizeof(double);
+    DevBuf *talls[] = {&c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall};
+    for (DevBuf *b : talls) {
+        b->release();
+        AA_CHECK(b->alloc(tall));
+    }
+    DevBuf *wides[] = {&c->P, &c->Q, &c->ZtX, &c->wideScratch};
+    for (DevBuf *b : wides) {
+        b->release();
+        AA_CHECK(b->alloc(wide));
+    }
+    c->Pw.release();
+    c->Qw.release();
+    if (c->dtype == AA_F32) {
+        AA_CHECK(c->Pw.alloc((size_t)KP * c->p_pad * sizeof(float)));
+        AA_CHECK(c->Qw.alloc((size_t)KP * c->p_pad * sizeof(float)));
+    }
+    // split-row decomposition of the reduce-over-rows GEMM
+    const long colgroups = c->dtype == AA_F32 ? (c->p_pad + 511) / 512 : (c->p_pad + 255) / 256;
+    long nslab = (1024 + colgroups - 1) / colgroups;
+    if (nslab > 128) nslab = 128;
+    if (nslab < 1) nslab = 1;
+    long rps = round_up((c->n_pad + nslab - 1) / nslab, 16);
+    nslab = (c->n_pad + rps - 1) / rps;
+    c->nslab = nslab;
+    c->rows_per_slab = rps;
+    c->partial.release();
+    AA_CHECK(c->partial.alloc((size_t)nslab * KP * c->p_pad * esize(c)));
+    AA_CHECK(tall_setup(c));
+    c->alpha.assign(k, 1.0);
+    c->ZtZ.assign((size_t)k * k, 0.0);
+    c->CKCt.assign((size_t)k * k, 0.0);
+    c->CKZ.assign((size_t)k * k, 0.0);
+    c->grams_valid = false;
+    c->gpnh_valid = false;
+    c->have_state = false;
+    c->dict_inputs_overridden = false;
+    return AA_OK;
+}
+
+static int upload_alpha(Ctx *c)
+{
+    std::vector<double> a(c->KP, 0.0);
+    for (int i = 0; i < c->k; ++i) a[i] = c->alpha[i];
+    AA_CHECK_HIP(hipMemcpy(c->alphaDev.p, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice));
+    return AA_OK;
+}
+
+// host k x k (dense) <- device KP x KP
+static int fetch_gram(Ctx *c, const double *dev, std::vector<double> &out)
+{
+    std::vector<double> tmp((size_t)c->KP * c->KP);
+    AA_CHECK_HIP(hipMemcpyAsync(tmp.data(), dev, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    out.resize((size_t)c->k * c->k);
+    for (int i = 0; i < c->k; ++i)
+        for (int j = 0; j < c->k; ++j) out[(size_t)i * c->k + j] = tmp[(size_t)i * c->KP + j];
+    return AA_OK;
+}
+
+static int upload_tall(Ctx *c, DevBuf &dst, const double *src, long ld_row, long ld_col, long rows, int cols)
+{
+    // dst[r][i] = src[r*ld_row + i*ld_col], zero padded to [n_pad][KP]
+    std::vector<double> tmp((size_t)c->n_pad * c->KP, 0.0);
+    for (long r = 0; r < rows; ++r)
+        for (int i = 0; i < cols; ++i) tmp[(size_t)r * c->KP + i] = src[r * ld_row + i * ld_col];
+    AA_CHECK_HIP(hipMemcpy(dst.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    return AA_OK;
+}
+
+static int download_tall(Ctx *c, const DevBuf &src, double *dst, long ld_row, long ld_col, long rows, int cols)
+{
+    std::vector<double> tmp((size_t)c->n_pad * c->KP);
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    AA_CHECK_HIP(hipMemcpy(tmp.data(), src.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (long r = 0; r < rows; ++r)
+        for (int i = 0; i < cols; ++i) dst[r * ld_row + i * ld_col] = tmp[(size_t)r * c->KP + i];
+    return AA_OK;
+}
+
+static double host_cost(const Ctx *c)
+{   // archetypal_analysis.py:553-556
+    const int k = c->k;
+    double t1 = 0.0, t2 = 0.0;
+    for (int i = 0; i < k; ++i) t1 += c->alpha[i] * c->CKZ[(size_t)i * k + i];
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j)
+            t2 += c->alpha[i] * c->ZtZ[(size_t)i * k + j] * c->alpha[j] * c->CKCt[(size_t)j * k + i];
+    return 0.5 * (c->trace - 2.0 * t1 + t2) / (double)c->n_global;
+}
+
+static int ensure_trace(Ctx *c)
+{
+    if (c->have_trace) return AA_OK;
+    AA_CHECK(launch_row_sqnorm_sum(c, &c->trace));
+    c->have_trace = true;
+    return AA_OK;
+}
+
+// ----------------------------------------------------------------- Gram refresh
+static int refresh_after_dictionary(Ctx *c, bool recompute_products)
+{
+    double *gram = c->gramOut.as<double>();
+    if (c->form == AA_FORM_DATA) {
+        if (recompute_products) {
+            AA_CHECK(launch_reduce_rows(c, c->Ct.as<double>(), c->P.as<double>(), operandT(c, c->P, c->Pw)));
+            AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));
+        }
+        AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), gram));
+    } else {
+        if (recompute_products) {
+            AA_CHECK(launch_reduce_rows(c, c->Ct.as<double>(), c->wideScratch.as<double>(), nullptr));
+            AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gr.as<double>()));
+        }
+        AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), c->Ct.as<double>(), gram));
+    }
+    AA_CHECK(fetch_gram(c, gram, c->CKCt));
+    AA_CHECK(launch_gram_tall(c, c->Ct.as<double>(), c->H.as<double>(), gram));
+    AA_CHECK(fetch_gram(c, gram, c->CKZ));
+    return AA_OK;
+}
+
+static int refresh_after_weights(Ctx *c)
+{
+    double *gram = c->gramOut.as<double>();
+    AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), gram));
+    AA_CHECK(fetch_gram(c, gram, c->ZtZ));
+    if (c->form == AA_FORM_DATA) {
+        AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), operandT(c, c->ZtX, c->Qw)));
+        AA_CHECK(launch_row_local(c, operandT(c, c->ZtX, c->Qw), c->H.as<double>()));
+    } else {
+        AA_CHECK(launch_transpose_tall_to_wide(c, c->Zt.as<double>(), c->ZtX.as<double>(),
+                                               operandT(c, c->ZtX, c->Qw)));
+        AA_CHECK(launch_row_local(c, operandT(c, c->ZtX, c->Qw), c->H.as<double>()));
+    }
+    AA_CHECK(launch_gram_tall(c, c->Ct.as<double>(), c->H.as<double>(), gram));
+    AA_CHECK(fetch_gram(c, gram, c->CKZ));
+    c->dict_inputs_overridden = false;
+    return AA_OK;
+}
+
+static int prepare(Ctx *c, double *cost)
+{
+    AA_REQUIRE(c->have_state, AA_ERR_STATE, "set_state must precede prepare");
+    AA_CHECK(ensure_trace(c));
+    AA_CHECK(upload_alpha(c));
+    AA_CHECK(refresh_after_weights(c));          // ZtZ, H = XX'Z (or KZ), CKZ (overwritten below)
+    AA_CHECK(refresh_after_dictionary(c, true)); // CX, C XX', C XX' C', C XX' Z
+    c->grams_valid = true;
+    if (cost) *cost = host_cost(c);
+    return AA_OK;
+}
+
+// ----------------------------------------------------------------- dictionary SPG
+static int set_scalar(Ctx *c, int slot, double v)
+{
+    AA_CHECK_HIP(hipMemcpyAsync(c->scalars.as<double>() + slot, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return AA_OK;
+}
+
+static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, bool refresh)
+{
+    AA_REQUIRE(c->have_state && (c->grams_valid || c->dict_inputs_overridden), AA_ERR_STATE,
+               "dictionary_update needs prepare() or set_dictionary_inputs() first");
+    AA_REQUIRE(sp->max_iterations >= 1, AA_ERR_ARG, "spg max_iterations must be >= 1");
+    const int k = c->k, KP = c->KP;
+    const bool data = c->form == AA_FORM_DATA;
+    // M = D Z'Z D  (archetypal_analysis.py:310,330)
+    std::vector<double> M((size_t)KP * KP, 0.0);
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j)
+            M[(size_t)i * KP + j] = c->alpha[i] * c->ZtZ[(size_t)i * k + j] * c->alpha[j];
+    AA_CHECK_HIP(hipMemcpy(c->Mdev.p, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice));
+    AA_CHECK(upload_alpha(c));
+    AA_CHECK(set_scalar(c, SC_TRACE, c->trace));
+    AA_CHECK(set_scalar(c, SC_FNORM, (double)k));     // archetypal_analysis.py:265,277
+
+    double *x = c->Ct.as<double>();
+    double *gram = c->gramOut.as<double>();
+    const size_t GS = (size_t)KP * KP;
+    const double gscale = data ? 1.0 / (double)c->n_global : 1.0 / (double)k;   // :297 vs :288
+
+    AA_CHECK(launch_proj(c, x, nullptr, 0.0, -1, PROJ_FEAS));                   // spg.py:148
+    if (data) {
+        AA_CHECK(launch_reduce_rows(c, x, c->P.as<double>(), operandT(c, c->P, c->Pw)));
+        AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), gram));
+    } else {
+        AA_CHECK(launch_reduce_rows(c, x, c->wideScratch.as<double>(), nullptr));
+        AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gr.as<double>()));
+        AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), x, gram));
+    }
+    AA_CHECK(launch_tall_dot_scaled(c, x, c->H.as<double>(), c->alphaDev.as<double>(), SC_S1));
+    AA_CHECK(launch_scalar_stage(c, ST_INIT_F, sp, 0));                         // spg.py:156
+    if (data) AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));
+    AA_CHECK(launch_grad(c, c->Gr.as<double>(), c->H.as<double>(), c->gk.as<double>(), gscale, nullptr, 0));
+
+    std::vector<double> sc(SC_COUNT, 0.0);
+    int n_iter = -1, flags = 0;
+    for (int it = 0; it < sp->max_iterations; ++it) {
+        n_iter = it;
+        if (it == 0 && sp->alpha0 < 0.0) {                                      // spg.py:178-189
+            AA_CHECK(launch_proj(c, x, c->gk.as<double>(), 1.0, -1, PROJ_ALPHA));
+            AA_CHECK(launch_scalar_stage(c, ST_ALPHA, sp, 0));
+        }
+        AA_CHECK(launch_proj(c, x, c->gk.as<double>(), 0.0, SC_ALPHA, PROJ_DIR)); // spg.py:191-194,206
+        if (data) {
+            AA_CHECK(launch_reduce_rows(c, c->Dt.as<double>(), c->Q.as<double>(), nullptr));
+            AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->Q.as<double>(), gram + GS));
+            AA_CHECK(launch_gram_wide(c, c->Q.as<double>(), c->Q.as<double>(), gram + 2 * GS));
+            AA_CHECK(launch_scalar_stage(c, ST_LINESEARCH, sp, 1));
+        } else {
+            AA_CHECK(launch_reduce_rows(c, c->Dt.as<double>(), c->wideScratch.as<double>(), nullptr));
+            AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gn.as<double>()));
+            AA_CHECK(launch_gram_tall(c, c->Gn.as<double>(), x, gram + GS));
+            AA_CHECK(launch_gram_tall(c, c->Gn.as<double>(), c->Dt.as<double>(), gram + 2 * GS));
+            AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), c->Dt.as<double>(), gram + 3 * GS));
+            AA_CHECK(launch_scalar_stage(c, ST_LINESEARCH, sp, 0));
+        }
+        AA_CHECK(launch_tall_axpy_lambda(c, x, c->Dt.as<double>()));            // x = x_old + lam d
+        if (data) {
+            AA_CHECK(launch_wide_axpy_lambda(c, c->P.as<double>(), c->Q.as<double>(), operandT(c, c->P, c->Pw)));
+            AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gn.as<double>()));
+            AA_CHECK(launch_grad(c, c->Gn.as<double>(), c->H.as<double>(), c->gn.as<double>(), gscale,
+                                 c->Dt.as<double>(), SC_DGN));
+        } else {
+            AA_CHECK(launch_tall_axpy_lambda(c, c->Gr.as<double>(), c->Gn.as<double>()));
+            AA_CHECK(launch_grad(c, c->Gr.as<double>(), c->H.as<double>(), c->gn.as<double>(), gscale,
+                                 c->Dt.as<double>(), SC_DGN));
+        }
+        AA_CHECK(launch_scalar_stage(c, ST_BB, sp, 0));                         // spg.py:232-244
+        AA_CHECK(launch_proj(c, x, c->gn.as<double>(), 1.0, -1, PROJ_RES));     // spg.py:250
+        AA_CHECK(launch_scalar_stage(c, ST_CONV, sp, 0));
+        AA_CHECK_HIP(hipMemcpyAsync(sc.data(), c->scalars.p, SC_COUNT * sizeof(double),
+                                    hipMemcpyDeviceToHost, c->stream));
+        AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+        flags = (int)sc[SC_FLAGS];
+        if (data) std::swap(c->Gr, c->Gn);
+        std::swap(c->gk, c->gn);
+        if (flags & (AA_SPG_FLAG_CONVERGED | AA_SPG_FLAG_MAX_FEVAL)) break;
+    }
+    if (n_iter == sp->max_iterations - 1 && !(flags & AA_SPG_FLAG_CONVERGED))
+        flags |= AA_SPG_FLAG_MAX_ITER;                                          // spg.py:278-281
+    if (st) {
+        st->f = sc[SC_F_OLD];
+        st->n_iter = n_iter;
+        st->n_feval = (int)sc[SC_NFEVAL];
+        st->flags = flags;
+        st->res_norm = sqrt(sc[SC_RES2]);
+    }
+    if (refresh) AA_CHECK(refresh_after_dictionary(c, false));
+    return AA_OK;
+}
+
+static int weights_update(Ctx *c, const aa_qp_params *qp, aa_qp_stats *stats)
+{
+    AA_REQUIRE(c->have_state && c->grams_valid, AA_ERR_STATE, "weights_update needs prepare() first");
+    const int k = c->k;
+    std::vector<double> A((size_t)k * k);
+    for (int i = 0; i < k; ++i)                                    // archetypal_analysis.py:387
+        for (int j = 0; j < k; ++j) A[(size_t)i * k + j] = c->alpha[i] * c->CKCt[(size_t)i * k + j] * c->alpha[j];
+    AA_CHECK(launch_qp(c, A.data(), c->Gr.as<double>(), 1, c->KP, c->alpha.data(), c->Zt.as<double>(),
+                       c->KP, c->n, k, qp, nullptr, stats));
+    AA_CHECK(refresh_after_weights(c));
+    return AA_OK;
+}
+
+}  // namespace aa
+
+// ===========================================================================
+// extern "C"
+// ===========================================================================
+using namespace aa;
+
+struct aa_ctx {
+    Ctx c;
+};
+
+extern "C" {
+
+const char *aa_last_error(void) { return g_err.c_str(); }
+int aa_version(void) { return 100; }
+
+int aa_device_count(int *count)
+{
+    int n = 0;
+    AA_CHECK_HIP(hipGetDeviceCount(&n));
+    *count = n;
+    return AA_OK;
+}
+
+int aa_ctx_create(aa_ctx **out, int device, int dtype)
+{
+    AA_REQUIRE(out != nullptr, AA_ERR_ARG, "null ctx pointer");
+    AA_REQUIRE(dtype == AA_F32 || dtype == AA_F64, AA_ERR_ARG, "bad dtype %d", dtype);
+    int n = 0;
+    AA_CHECK_HIP(hipGetDeviceCount(&n));
+    AA_REQUIRE(n > 0, AA_ERR_HIP, "no HIP device visible");
+    AA_REQUIRE(device >= 0 && device < n, AA_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    AA_CHECK_HIP(hipSetDevice(device));
+    aa_ctx *h = new aa_ctx();
+    h->c.device = device;
+    h->c.dtype = dtype;
+    hipError_t e = hipStreamCreate(&h->c.stream);
+    if (e != hipSuccess) {
+        set_error("hipStreamCreate: %s", hipGetErrorString(e));
+        delete h;
+        return AA_ERR_HIP;
+    }
+    *out = h;
+    return AA_OK;
+}
+
+int aa_ctx_destroy(aa_ctx *h)
+{
+    if (!h) return AA_OK;
+    Ctx *c = &h->c;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_destroy(c);
+    DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
+                     &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->redPartial,
+                     &c->gramOut, &c->redOut, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters,
+                     &c->qpStats};
+    for (DevBuf *b : all) b->release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete h;
+    return AA_OK;
+}
+
+int aa_comm_get_unique_id(void *id128) { return comm_unique_id(id128); }
+
+int aa_ctx_comm_init(aa_ctx *h, const void *id128, int rank, int world)
+{
+    AA_REQUIRE(h, AA_ERR_ARG, "null ctx");
+    return comm_init(&h->c, id128, rank, world);
+}
+
+int aa_ctx_allreduce_host(aa_ctx *h, double *buf, int count, int op)
+{
+    AA_REQUIRE(h && buf && count >= 0, AA_ERR_ARG, "bad arguments");
+    Ctx *c = &h->c;
+    if (c->world <= 1 || count == 0) return AA_OK;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    DevBuf tmp;
+    AA_CHECK(tmp.alloc((size_t)count * sizeof(double)));
+    AA_CHECK_HIP(hipMemcpyAsync(tmp.p, buf, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int rc = comm_allreduce(c, tmp.as<double>(), count, op);
+    if (rc == AA_OK) {
+        hipError_t e = hipMemcpyAsync(buf, tmp.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            set_error("allreduce_host copy back: %s", hipGetErrorString(e));
+            rc = AA_ERR_HIP;
+        }
+    }
+    tmp.release();
+    return rc;
+}
+
+int aa_set_data(aa_ctx *h, const void *X, int host_dtype, long n, long p, long ld, int form,
+                long n_global, long row_offset)
+{
+    AA_REQUIRE(h && X, AA_ERR_ARG, "null argument");
+    AA_REQUIRE(n >= 1 && p >= 1 && ld >= p, AA_ERR_ARG, "bad shape n=%ld p=%ld ld=%ld", n, p, ld);
+    AA_REQUIRE(host_dtype == AA_F32 || host_dtype == AA_F64, AA_ERR_ARG, "bad host dtype");
+    AA_REQUIRE(form == AA_FORM_DATA || form == AA_FORM_KERNEL, AA_ERR_ARG, "bad form");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    if (form == AA_FORM_KERNEL)
+        AA_REQUIRE(c->world == 1 && n == p && n_global == n && row_offset == 0, AA_ERR_ARG,
+                   "kernel form needs a square matrix on a single rank");
+    AA_REQUIRE(n_global >= n && row_offset >= 0 && row_offset + n <= n_global, AA_ERR_ARG, "bad shard");
+    c->form = form;
+    c->n = n;
+    c->p = p;
+    c->n_pad = round_up(n, 128);
+    c->p_pad = round_up(p, 128);
+    if (form == AA_FORM_KERNEL) c->p_pad = c->n_pad;
+    c->n_global = n_global;
+    c->row_offset = row_offset;
+    const size_t es = esize(c);
+    c->X.release();
+    AA_CHECK(c->X.alloc((size_t)c->n_pad * c->p_pad * es));
+    const size_t hes = host_dtype == AA_F32 ? 4 : 8;
+    if (host_dtype == c->dtype) {
+        AA_CHECK_HIP(hipMemcpy2D(c->X.p, (size_t)c->p_pad * es, X, (size_t)ld * hes, (size_t)p * es,
+                                 (size_t)n, hipMemcpyHostToDevice));
+    } else {
+        const long chunk = 2048;
+        std::vector<unsigned char> tmp((size_t)chunk * p * es);
+        for (long r0 = 0; r0 < n; r0 += chunk) {
+            const long rows = (n - r0 < chunk) ? n - r0 : chunk;
+            if (c->dtype == AA_F32) {
+                const double *src = reinterpret_cast<const double *>(X);
+                float *dst = reinterpret_cast<float *>(tmp.data());
+                for (long r = 0; r < rows; ++r)
+                    for (long q = 0; q < p; ++q) dst[r * p + q] = (float)src[(r0 + r) * ld + q];
+            } else {
+                const float *src = reinterpret_cast<const float *>(X);
+                double *dst = reinterpret_cast<double *>(tmp.data());
+                for (long r = 0; r < rows; ++r)
+                    for (long q = 0; q < p; ++q) dst[r * p + q] = (double)src[(r0 + r) * ld + q];
+            }
+            AA_CHECK_HIP(hipMemcpy2D(reinterpret_cast<unsigned char *>(c->X.p) + (size_t)r0 * c->p_pad * es,
+                                     (size_t)c->p_pad * es, tmp.data(), (size_t)p * es, (size_t)p * es,
+                                     (size_t)rows, hipMemcpyHostToDevice));
+        }
+    }
+    c->have_data = true;
+    c->have_trace = false;
+    c->k = 0;   // forces (re)allocation of the factor buffers
+    c->KP = 0;
+    c->have_state = false;
+    c->grams_valid = false;
+    return AA_OK;
+}
+
+int aa_data_trace(aa_ctx *h, double *trace)
+{
+    AA_REQUIRE(h && trace, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->have_data, AA_ERR_STATE, "no data");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    if (!c->redPartial.p) {   // trace asked before any factors: set up minimal scratch
+        AA_CHECK(c->redPartial.alloc(8192 * sizeof(double)));
+        AA_CHECK(c->redOut.alloc(512 * sizeof(double)));
+    }
+    AA_CHECK(ensure_trace(c));
+    *trace = c->trace;
+    return AA_OK;
+}
+
+int aa_set_state(aa_ctx *h, int k, const double *C, long ldc, const double *Z, const double *alpha)
+{
+    AA_REQUIRE(h && C && Z, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_CHECK(ensure_problem(c, k));
+    AA_REQUIRE(ldc >= c->n, AA_ERR_ARG, "ldc < n");
+    AA_CHECK(upload_tall(c, c->Ct, C, 1, ldc, c->n, k));     // Ct[r][i] = C[i][r]
+    AA_CHECK(upload_tall(c, c->Zt, Z, k, 1, c->n, k));
+    for (int i = 0; i < k; ++i) c->alpha[i] = alpha ? alpha[i] : 1.0;
+    AA_CHECK(upload_alpha(c));
+    c->have_state = true;
+    c->grams_valid = false;
+    c->dict_inputs_overridden = false;
+    return AA_OK;
+}
+
+int aa_get_state(aa_ctx *h, double *C, long ldc, double *Z, double *alpha)
+{
+    AA_REQUIRE(h, AA_ERR_ARG, "null ctx");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->have_state, AA_ERR_STATE, "no state");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    if (C) AA_CHECK(download_tall(c, c->Ct, C, 1, ldc, c->n, c->k));
+    if (Z) AA_CHECK(download_tall(c, c->Zt, Z, c->k, 1, c->n, c->k));
+    if (alpha)
+        for (int i = 0; i < c->k; ++i) alpha[i] = c->alpha[i];
+    return AA_OK;
+}
+
+int aa_set_alpha(aa_ctx *h, const double *alpha)
+{
+    AA_REQUIRE(h && alpha, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->k > 0, AA_ERR_STATE, "no problem");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    for (int i = 0; i < c->k; ++i) c->alpha[i] = alpha[i];
+    return upload_alpha(c);
+}
+
+int aa_prepare(aa_ctx *h, double *cost)
+{
+    AA_REQUIRE(h, AA_ERR_ARG, "null ctx");
+    AA_CHECK_HIP(hipSetDevice(h->c.device));
+    return prepare(&h->c, cost);
+}
+
+int aa_cost(aa_ctx *h, double *cost)
+{
+    AA_REQUIRE(h && cost, AA_ERR_ARG, "null argument");
+    AA_REQUIRE(h->c.grams_valid, AA_ERR_STATE, "Gram products not valid");
+    *cost = host_cost(&h->c);
+    return AA_OK;
+}
+
+int aa_get_grams(aa_ctx *h, double *ZtZ, double *CKCt, double *CKZ, double *trace)
+{
+    AA_REQUIRE(h, AA_ERR_ARG, "null ctx");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->grams_valid, AA_ERR_STATE, "Gram products not valid");
+    const size_t kk = (size_t)c->k * c->k;
+    if (ZtZ) memcpy(ZtZ, c->ZtZ.data(), kk * sizeof(double));
+    if (CKCt) memcpy(CKCt, c->CKCt.data(), kk * sizeof(double));
+    if (CKZ) memcpy(CKZ, c->CKZ.data(), kk * sizeof(double));
+    if (trace) *trace = c->trace;
+    return AA_OK;
+}
+
+int aa_set_dictionary_inputs(aa_ctx *h, const double *KZ, const double *ZtZ, double trace)
+{
+    AA_REQUIRE(h && KZ && ZtZ, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->have_state, AA_ERR_STATE, "set_state first");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_CHECK(upload_tall(c, c->H, KZ, c->k, 1, c->n, c->k));
+    c->ZtZ.assign(ZtZ, ZtZ + (size_t)c->k * c->k);
+    c->trace = trace;
+    c->have_trace = true;
+    c->dict_inputs_overridden = true;
+    return AA_OK;
+}
+
+int aa_dictionary_update(aa_ctx *h, const aa_spg_params *params, aa_spg_stats *stats)
+{
+    AA_REQUIRE(h && params, AA_ERR_ARG, "null argument");
+    AA_CHECK_HIP(hipSetDevice(h->c.device));
+    return dictionary_update(&h->c, params, stats, true);
+}
+
+int aa_weights_update(aa_ctx *h, const aa_qp_params *params, aa_qp_stats *stats)
+{
+    AA_REQUIRE(h && params, AA_ERR_ARG, "null argument");
+    AA_CHECK_HIP(hipSetDevice(h->c.device));
+    return weights_update(&h->c, params, stats);
+}
+
+int aa_outer_iterations(aa_ctx *h, int n_outer, const aa_spg_params *spg, const aa_qp_params *qp,
+                        double *costs)
+{
+    AA_REQUIRE(h && spg && qp, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    for (int i = 0; i < n_outer; ++i) {
+        AA_CHECK(dictionary_update(c, spg, nullptr, true));
+        if (costs) costs[2 * i] = host_cost(c);
+        AA_CHECK(weights_update(c, qp, nullptr));
+        if (costs) costs[2 * i + 1] = host_cost(c);
+    }
+    return AA_OK;
+}
+
+int aa_reconstruction_cost(aa_ctx *h, double *cost)
+{
+    AA_REQUIRE(h && cost, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->have_state && c->grams_valid && c->form == AA_FORM_DATA, AA_ERR_STATE,
+               "reconstruction cost needs prepared data-form state");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    double s = 0.0;
+    AA_CHECK(launch_residual_cost(c, c->Zt.as<double>(), c->P.as<double>(), c->alphaDev.as<double>(), &s));
+    *cost = 0.5 * s / (double)c->n_global;
+    return AA_OK;
+}
+
+int aa_get_archetypes(aa_ctx *h, double *CX, long ld)
+{
+    AA_REQUIRE(h && CX, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->grams_valid && c->form == AA_FORM_DATA, AA_ERR_STATE, "no C X available");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    AA_CHECK_HIP(hipMemcpy2D(CX, (size_t)ld * sizeof(double), c->P.p, (size_t)c->p_pad * sizeof(double),
+                             (size_t)c->p * sizeof(double), (size_t)c->k, hipMemcpyDeviceToHost));
+    return AA_OK;
+}
+
+int aa_distance_column(aa_ctx *h, long j, double *d)
+{
+    AA_REQUIRE(h && d, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->have_data, AA_ERR_STATE, "no data");
+    AA_REQUIRE(j >= 0 && j < c->n_global, AA_ERR_ARG, "row %ld out of range", j);
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    const size_t es = esize(c);
+    if (!c->tmpTall.p || c->tmpTall.bytes < (size_t)c->n * sizeof(double))
+        AA_CHECK(c->tmpTall.alloc((size_t)c->n_pad * 32 * sizeof(double)));
+    if (c->form == AA_FORM_DATA) {
+        if (!c->wideScratch.p || c->wideScratch.bytes < (size_t)c->p_pad * sizeof(double))
+            AA_CHECK(c->wideScratch.alloc((size_t)32 * c->p_pad * sizeof(double)));
+        const long jl = j - c->row_offset;
+        const bool own = jl >= 0 && jl < c->n;
+        if (c->world == 1) {
+            AA_CHECK_HIP(hipMemcpyAsync(c->wideScratch.p,
+                                        reinterpret_cast<unsigned char *>(c->X.p) + (size_t)jl * c->p_pad * es,
+                                        (size_t)c->p_pad * es, hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            // owner publishes the row through a sum all-reduce of a zero-filled buffer
+            std::vector<double> row(c->p_pad, 0.0);
+            if (own) {
+                std::vector<unsigned char> raw((size_t)c->p_pad * es);
+                AA_CHECK_HIP(hipMemcpy(raw.data(),
+                                       reinterpret_cast<unsigned char *>(c->X.p) + (size_t)jl * c->p_pad * es,
+                                       raw.size(), hipMemcpyDeviceToHost));
+                for (long q = 0; q < c->p_pad; ++q)
+                    row[q] = c->dtype == AA_F32 ? (double)reinterpret_cast<float *>(raw.data())[q]
+                                                : reinterpret_cast<double *>(raw.data())[q];
+            }
+            DevBuf tmp;
+            AA_CHECK(tmp.alloc(row.size() * sizeof(double)));
+            AA_CHECK_HIP(hipMemcpy(tmp.p, row.data(), row.size() * sizeof(double), hipMemcpyHostToDevice));
+            AA_CHECK(comm_allreduce(c, tmp.as<double>(), (long)row.size(), 0));
+            AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+            AA_CHECK_HIP(hipMemcpy(row.data(), tmp.p, row.size() * sizeof(double), hipMemcpyDeviceToHost));
+            tmp.release();
+            if (c->dtype == AA_F32) {
+                std::vector<float> rf(row.begin(), row.end());
+                AA_CHECK_HIP(hipMemcpy(c->wideScratch.p, rf.data(), rf.size() * sizeof(float), hipMemcpyHostToDevice));
+            } else {
+                AA_CHECK_HIP(hipMemcpy(c->wideScratch.p, row.data(), row.size() * sizeof(double), hipMemcpyHostToDevice));
+            }
+        }
+        return launch_distance_column(c, jl, own ? 1 : 0, nullptr, d);
+    }
+    return launch_distance_column(c, j, 1, nullptr, d);
+}
+
+// ------------------------------------------------------------------ GPNH
+int aa_gpnh_set_factors(aa_ctx *h, int k, const double *Wt, long ld, const double *Z)
+{
+    AA_REQUIRE(h, AA_ERR_ARG, "null ctx");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->form == AA_FORM_DATA, AA_ERR_STATE, "GPNH needs a data matrix");
+    AA_CHECK(ensure_problem(c, k));
+    if (Wt) {
+        AA_REQUIRE(ld >= c->p, AA_ERR_ARG, "ld < p");
+        std::vector<double> tmp((size_t)c->KP * c->p_pad, 0.0);
+        for (int i = 0; i < k; ++i)
+            for (long q = 0; q < c->p; ++q) tmp[(size_t)i * c->p_pad + q] = Wt[(size_t)i * ld + q];
+        AA_CHECK_HIP(hipMemcpy(c->P.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+        AA_CHECK(launch_wide_to_T(c, c->P.as<double>(), operandT(c, c->P, c->Pw)));
+        AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));   // XW
+        c->gpnh_valid = true;
+    }
+    if (Z) {
+        AA_CHECK(upload_tall(c, c->Zt, Z, k, 1, c->n, k));
+        c->have_state = true;
+    }
+    return AA_OK;
+}
+
+int aa_gpnh_get_weights(aa_ctx *h, double *Z)
+{
+    AA_REQUIRE(h && Z, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->have_state, AA_ERR_STATE, "no weights");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    return download_tall(c, c->Zt, Z, c->k, 1, c->n, c->k);
+}
+
+int aa_gpnh_reduce(aa_ctx *h, double *ZtX, long ld, double *ZtZ, double *trace_WtXtZ)
+{
+    AA_REQUIRE(h, AA_ERR_ARG, "null ctx");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->have_state, AA_ERR_STATE, "no weights");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    if (ZtX) {
+        AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), nullptr));
+        AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+        AA_CHECK_HIP(hipMemcpy2D(ZtX, (size_t)ld * sizeof(double), c->ZtX.p, (size_t)c->p_pad * sizeof(double),
+                                 (size_t)c->p * sizeof(double), (size_t)c->k, hipMemcpyDeviceToHost));
+    }
+    if (ZtZ) {
+        AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), c->gramOut.as<double>()));
+        std::vector<double> g;
+        AA_CHECK(fetch_gram(c, c->gramOut.as<double>(), g));
+        memcpy(ZtZ, g.data(), g.size() * sizeof(double));
+    }
+    if (trace_WtXtZ) {
+        AA_REQUIRE(c->gpnh_valid, AA_ERR_STATE, "no dictionary");
+        AA_CHECK(launch_tall_dot_scaled(c, c->Gr.as<double>(), c->Zt.as<double>(), nullptr, SC_S1));
+        AA_CHECK_HIP(hipMemcpyAsync(trace_WtXtZ, c->scalars.as<double>() + SC_S1, sizeof(double),
+                                    hipMemcpyDeviceToHost, c->stream));
+        AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    }
+    return AA_OK;
+}
+
+int aa_gpnh_weights_update(aa_ctx *h, const double *WtW, const aa_qp_params *params, aa_qp_stats *stats)
+{
+    AA_REQUIRE(h && WtW && params, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->have_state && c->gpnh_valid, AA_ERR_STATE, "set_factors first");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    return launch_qp(c, WtW, c->Gr.as<double>(), 1, c->KP, nullptr, c->Zt.as<double>(), c->KP, c->n, c->k,
+                     params, nullptr, stats);
+}
+
+int aa_gpnh_residual_cost(aa_ctx *h, double *cost)
+{
+    AA_REQUIRE(h && cost, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->have_state && c->gpnh_valid, AA_ERR_STATE, "set_factors first");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    double s = 0.0;
+    AA_CHECK(launch_residual_cost(c, c->Zt.as<double>(), c->P.as<double>(), nullptr, &s));
+    *cost = 0.5 * s / (double)c->n_global;
+    return AA_OK;
+}
+
+// ------------------------------------------------------------------ stateless ops
+int aa_simplex_project_rows(int device, const double *in, double *out, long rows, long cols)
+{
+    AA_REQUIRE(in && out && rows >= 0 && cols >= 0, AA_ERR_ARG, "bad arguments");
+    if (rows == 0 || cols == 0) return AA_OK;
+    int n = 0;
+    AA_CHECK_HIP(hipGetDeviceCount(&n));
+    AA_REQUIRE(n > 0 && device >= 0 && device < n, AA_ERR_HIP, "no usable HIP device");
+    AA_CHECK_HIP(hipSetDevice(device));
+    DevBuf a, b;
+    const size_t bytes = (size_t)rows * cols * sizeof(double);
+    AA_CHECK(a.alloc(bytes));
+    int rc = b.alloc(bytes);
+    if (rc == AA_OK) {
+        hipError_t e = hipMemcpy(a.p, in, bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            rc = launch_simplex_rows_generic(nullptr, a.as<double>(), b.as<double>(), rows, cols);
+            if (rc == AA_OK) e = hipDeviceSynchronize();
+            if (rc == AA_OK && e == hipSuccess) e = hipMemcpy(out, b.p, bytes, hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) {
+            set_error("simplex_project_rows: %s", hipGetErrorString(e));
+            rc = AA_ERR_HIP;
+        }
+    }
+    a.release();
+    b.release();
+    return rc;
+}
+
+int aa_quad_simplex_spg_batch(int device, const double *A, const double *B, long stride_j, long stride_t,
+                              const double *Z0, double *Zout, long n, int k, const aa_qp_params *params,
+                              int *iters)
+{
+    AA_REQUIRE(A && B && Z0 && Zout && params, AA_ERR_ARG, "null argument");
+    AA_REQUIRE(n >= 0 && k >= 1 && k <= AA_MAX_K, AA_ERR_ARG, "bad n=%ld k=%d", n, k);
+    AA_REQUIRE(stride_j >= 1 && stride_t >= 1, AA_ERR_ARG, "bad strides");
+    if (n == 0) return AA_OK;
+    aa_ctx *h = nullptr;
+    AA_CHECK(aa_ctx_create(&h, device, AA_F64));
+    Ctx *c = &h->c;
+    DevBuf dB, dZ, dI;
+    const size_t extent = (size_t)((k - 1) * stride_j + (n - 1) * stride_t + 1);
+    int rc = dB.alloc(extent * sizeof(double));
+    if (rc == AA_OK) rc = dZ.alloc((size_t)n * k * sizeof(double));
+    if (rc == AA_OK) rc = dI.alloc((size_t)n * sizeof(int));
+    if (rc == AA_OK) {
+        hipError_t e = hipMemcpy(dB.p, B, extent * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dZ.p, Z0, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("qp batch upload: %s", hipGetErrorString(e));
+            rc = AA_ERR_HIP;
+        }
+    }
+    if (rc == AA_OK)
+        rc = launch_qp(c, A, dB.as<double>(), stride_j, stride_t, nullptr, dZ.as<double>(), k, n, k, params,
+                       dI.as<int>(), nullptr);
+    if (rc == AA_OK) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(Zout, dZ.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && iters) e = hipMemcpy(iters, dI.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_error("qp batch: %s", hipGetErrorString(e));
+            rc = AA_ERR_HIP;
+        }
+    }
+    dB.release();
+    dZ.release();
+    dI.release();
+    aa_ctx_destroy(h);
+    return rc;
+}
+
+// ------------------------------------------------------------------ measurement
+int aa_time_kernel(aa_ctx *h, int which, int reps, double *ms_avg)
+{
+    AA_REQUIRE(h && ms_avg && reps >= 1, AA_ERR_ARG, "bad arguments");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->have_state && c->form == AA_FORM_DATA, AA_ERR_STATE, "needs data-form state");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    hipEvent_t e0, e1;
+    AA_CHECK_HIP(hipEventCreate(&e0));
+    AA_CHECK_HIP(hipEventCreate(&e1));
+    int rc = AA_OK;
+    // one untimed launch first
+    for (int phase = 0; phase < 2 && rc == AA_OK; ++phase) {
+        const int nrep = phase == 0 ? 1 : reps;
+        if (phase == 1) (void)hipEventRecord(e0, c->stream);
+        for (int r = 0; r < nrep && rc == AA_OK; ++r) {
+            if (which == 0)
+                rc = launch_reduce_rows(c, c->Ct.as<double>(), c->Q.as<double>(), nullptr, true);
+            else if (which == 1)
+                rc = launch_row_local(c, operandT(c, c->P, c->Pw), c->Gn.as<double>());
+            else {
+                set_error("aa_time_kernel: unknown kernel %d", which);
+                rc = AA_ERR_ARG;
+            }
+        }
+        if (phase == 1) (void)hipEventRecord(e1, c->stream);
+    }
+    if (rc == AA_OK) {
+        hipError_t e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) {
+            set_error("aa_time_kernel: %s", hipGetErrorString(e));
+            rc = AA_ERR_HIP;
+        }
+        *ms_avg = (double)ms / reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+}  // extern "C"

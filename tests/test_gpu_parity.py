@@ -1,0 +1,376 @@
+"""Parity of the HIP path (through the C ABI, via the product package) against the
+reference-generated golden vectors and the CPU oracle.  Needs an MI355X.
+
+Bars: support patterns / argmax indices / constraint satisfaction exact; values of
+fixed-iteration runs to rounding (<= 1e-9, stated per test); runs to convergence to
+the solver's own stopping tolerance; float32-MFMA mode to the stated fp32 tolerance."""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cdr():
+    import convex_dim_red
+    from convex_dim_red import _backend
+    _backend.require_gpu()
+    return convex_dim_red
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import aa_oracle
+    return aa_oracle
+
+
+def _keys(g, prefix):
+    return sorted(k[len(prefix):] for k in g.files if k.startswith(prefix))
+
+
+def _assert_simplex(M, atol=1e-13):
+    assert np.all(M >= 0)
+    assert np.allclose(M.sum(axis=1), 1, rtol=0, atol=atol)
+
+
+# ---------------------------------------------------------------- simplex projection
+def test_simplex_rows_golden(cdr):
+    g = load_golden("simplex_rows")
+    for key in _keys(g, "in_"):
+        A, want = g["in_" + key], g["out_" + key]
+        got = cdr.simplex_project_rows(A)
+        scale = max(1.0, np.abs(A).max())
+        assert np.allclose(got, want, rtol=0, atol=8e-16 * scale * max(1, A.shape[1]) ** 0.5), key
+        if key not in ("ties", "large"):
+            assert np.array_equal(got > 0, want > 0), key       # support pattern exact
+        cols = cdr.simplex_project_columns(np.ascontiguousarray(A.T))
+        assert np.array_equal(cols, got.T), key
+
+
+def test_simplex_exact_small_cases(cdr):
+    # reference tests/test_simplex_projection.py:13-57,166-176 known answers
+    assert np.array_equal(cdr.simplex_project_rows(np.array([[-0.5]])), [[1.0]])
+    got = cdr.simplex_project_rows(np.array([[0.8, 0.8], [0.0, 2.0], [0.5, -0.5]]))
+    assert np.array_equal(got, [[0.5, 0.5], [0.0, 1.0], [1.0, 0.0]])
+    got = cdr.simplex_project_rows(np.array([[0.5, 0.5], [0.5, 1.0], [0.0, -0.5]]))
+    assert np.array_equal(got, [[0.5, 0.5], [0.25, 0.75], [0.75, 0.25]])
+
+
+@pytest.mark.parametrize("shape", [(57, 5), (341, 317), (7, 3000), (2, 20000), (3, 1)])
+def test_simplex_rows_vs_oracle(cdr, orc, shape):
+    rng = np.random.RandomState(shape[0] * 7 + shape[1])
+    A = rng.standard_normal(shape) * rng.choice([0.01, 1.0, 50.0])
+    got, want = cdr.simplex_project_rows(A), orc.simplex_project_rows(A)
+    assert np.abs(got - want).max() < 1e-13 * max(1.0, np.abs(A).max())
+    assert np.array_equal(got > 0, want > 0)
+    _assert_simplex(got, 1e-12)
+    inside = orc.right_stochastic_matrix(shape, rng)            # already feasible: invariant
+    assert np.abs(cdr.simplex_project_rows(inside) - inside).max() < 1e-15
+
+
+# ---------------------------------------------------------------- per-sample QP
+@pytest.mark.parametrize("k", [3, 8, 10, 32])
+@pytest.mark.parametrize("tag,kw", [("default", {}), ("one", dict(max_iterations=1)),
+                                    ("alpha0", dict(alpha0=0.5, max_iterations=5))])
+def test_qp_golden(cdr, k, tag, kw):
+    from convex_dim_red import _backend
+    g = load_golden("quad_simplex_spg")
+    A, B, Z0 = g["in_A_k%d" % k], g["in_B_k%d" % k], g["in_Z0_k%d" % k]
+    want = g["out_Z_k%d_%s" % (k, tag)]
+    got = _backend.qp_batch(A, B, Z0, "kn", **kw)
+    scale = np.abs(A).max()
+    tol = 1e-6 if tag == "default" else 1e-11 * scale
+    assert np.abs(got - want).max() < tol
+    _assert_simplex(got)
+    if tag != "default":
+        assert np.array_equal(got > 0, want > 0)
+    # objective value agrees much more tightly than the minimiser
+    f = lambda Z: 0.5 * np.einsum("ti,ij,tj->t", Z, A, Z) - np.einsum("ti,it->t", Z, B)
+    assert np.abs(f(got) - f(want)).max() < 1e-9 * scale
+
+
+def test_qp_layouts_and_iters(cdr, orc):
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(5)
+    n, k, p = 500, 10, 30
+    W = rng.standard_normal((p, k))
+    X = orc.right_stochastic_matrix((n, k), rng).dot(W.T) + 0.1 * rng.standard_normal((n, p))
+    A, XW = W.T.dot(W), X.dot(W)
+    Z0 = orc.right_stochastic_matrix((n, k), rng)
+    got_nk, it = _backend.qp_batch(A, XW, Z0, "nk", return_iters=True)
+    got_kn = _backend.qp_batch(A, np.ascontiguousarray(XW.T), Z0, "kn")
+    want, it_o = orc.qp_batch(A, XW, Z0, "nk", return_iters=True)
+    assert np.array_equal(got_nk, got_kn)
+    assert np.abs(got_nk - want).max() < 1e-6
+    assert abs(it.mean() - it_o.mean()) < 0.05 * it_o.mean() + 1
+    from convex_dim_red.spg import quad_simplex_spg
+    single = quad_simplex_spg(A, -XW[3], Z0[3])
+    assert np.abs(single - want[3]).max() < 1e-6
+
+
+# ---------------------------------------------------------------- dictionary SPG
+def test_dictionary_spg_golden(cdr):
+    from convex_dim_red import archetypal_analysis as aa
+    g = load_golden("aa_dictionary_spg")
+    X, C0, Z0 = g["in_X"], g["in_C0"], g["in_Z0"]
+    alpha = np.ones(C0.shape[0])
+    trX = np.trace(X.dot(X.T))
+    XXtZ = X.dot(X.T.dot(Z0))
+    ZtZ = Z0.T.dot(Z0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, kw, tol in (("one", dict(max_iterations=1), 1e-11),
+                             ("five", dict(max_iterations=5), 1e-9)):
+            C = aa._update_aa_dictionary(X, C0, alpha, trX, XXtZ, ZtZ, **kw)
+            assert np.abs(C - g["out_C_" + tag]).max() < tol, tag
+            assert np.array_equal(C > 0, g["out_C_" + tag] > 0), tag
+            _assert_simplex(C)
+        K = X.dot(X.T)
+        C = aa._update_kernel_aa_dictionary(K, C0, alpha, np.trace(K), K.dot(Z0), ZtZ,
+                                            max_iterations=1)
+        assert np.abs(C - g["out_kernel_C_one"]).max() < 1e-11
+        CK = C0.dot(K)
+        Z = aa._update_kernel_aa_weights(Z0, alpha, CK, CK.dot(C0.T))
+        assert np.abs(Z - g["out_kernel_Z"]).max() < 1e-6
+        assert abs(aa._kernel_aa_cost(K, Z0, C0, alpha) - g["out_kernel_cost"]) < 1e-12
+
+
+def test_dictionary_spg_flags_and_stats(cdr):
+    from convex_dim_red import _backend
+    g = load_golden("aa_dictionary_spg")
+    X, C0, Z0 = g["in_X"], g["in_C0"], g["in_Z0"]
+    for tag, kw in (("one", dict(max_iterations=1)), ("five", dict(max_iterations=5))):
+        want_f, want_it, want_fe = g["out_stats_" + tag]
+        with _backend.Context(dtype="float64") as ctx:
+            ctx.set_data(X)
+            ctx.set_state(C0, Z0, np.ones(C0.shape[0]))
+            ctx.prepare()
+            st = ctx.dictionary_update(**kw)
+        assert abs(st.f - want_f) < 1e-11 * abs(want_f)
+        assert (st.n_iter, st.n_feval) == (int(want_it), int(want_fe))
+        assert st.flags & _backend.SPG_FLAG_MAX_ITER
+
+
+# ---------------------------------------------------------------- outer loops
+def test_iterate_aa_steps_golden(cdr):
+    from convex_dim_red import archetypal_analysis as aa
+    g = load_golden("iterate_aa")
+    X, C0, Z0 = g["in_X"], g["in_C0"], g["in_Z0"]
+    k = C0.shape[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Z, C = Z0.copy(), C0.copy()
+        for step in range(3):
+            Z, C, _, cost, n_iter, _, deltas = aa._iterate_aa(
+                X, Z, C, np.ones(k), tolerance=0, max_iterations=1,
+                dictionary_solver_kwargs=dict(max_iterations=1),
+                require_monotonic_cost_decrease=False)
+            assert np.abs(C - g["out_step%d_C" % step]).max() < 1e-8, step
+            assert np.abs(Z - g["out_step%d_Z" % step]).max() < 5e-6, step
+            assert abs(cost - g["out_step%d_cost" % step]) < 1e-9, step
+            assert n_iter == 0 and len(deltas) == 1
+            _assert_simplex(C)
+            _assert_simplex(Z)
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 2e-6), ("float32", 2e-5)])
+def test_iterate_aa_traces_golden(cdr, dtype, tol):
+    from convex_dim_red import archetypal_analysis as aa
+    g = load_golden("iterate_aa")
+    X, C0, Z0 = g["in_X"], g["in_C0"], g["in_Z0"]
+    k = C0.shape[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, kw in (("prod", dict(dictionary_solver_kwargs=dict(max_iterations=1))),
+                        ("default", {})):
+            Z, C, al, cost, n_iter, _, deltas = aa._iterate_aa(
+                X, Z0.copy(), C0.copy(), np.ones(k), tolerance=1e-6, max_iterations=60,
+                dtype=dtype, **kw)
+            want_cost, want_it = g["out_cost_" + tag]
+            assert abs(cost - want_cost) < tol, tag
+            assert abs(n_iter - int(want_it)) <= 3, tag
+            assert np.array_equal(C.argmax(axis=1), g["out_C_" + tag].argmax(axis=1)), tag
+            assert len(deltas) == n_iter + 1
+        Z, C, al, cost, n_iter, _, deltas = aa._iterate_aa(
+            X, Z0.copy(), C0.copy(), g["in_alpha0"].copy(), delta=0.1, tolerance=1e-6,
+            max_iterations=40, dtype=dtype, dictionary_solver_kwargs=dict(max_iterations=1))
+        want_cost, want_it = g["out_cost_delta"]
+        assert abs(cost - want_cost) < 10 * tol
+        assert np.abs(al - g["out_alpha_delta"]).max() < 1e-3
+
+
+def test_iterate_kernel_aa_golden(cdr):
+    from convex_dim_red import archetypal_analysis as aa
+    g = load_golden("iterate_kernel_aa")
+    K, C0, Z0 = g["in_K"], g["in_C0"], g["in_Z0"]
+    k = C0.shape[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, kw in (("prod", dict(dictionary_solver_kwargs=dict(max_iterations=1))),
+                        ("default", {})):
+            Z, C, al, cost, n_iter, _, deltas = aa._iterate_kernel_aa(
+                K, Z0.copy(), C0.copy(), np.ones(k), tolerance=1e-6, max_iterations=40, **kw)
+            want_cost, want_it = g["out_cost_" + tag]
+            assert abs(cost - want_cost) < 2e-6, tag
+            assert abs(n_iter - int(want_it)) <= 3, tag
+            _assert_simplex(C, 1e-12)
+            _assert_simplex(Z, 1e-12)
+
+
+# ---------------------------------------------------------------- estimators
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-6), ("float32", 1e-5)])
+def test_aa_estimator_known_answers(cdr, dtype, tol):
+    g = load_golden("aa_estimator")
+    X = g["in_X"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for init in ("furthest_sum", "random"):
+            for tag, dkw in (("one", dict(max_iterations=1)), ("full", {})):
+                key = "%s_%s" % (init, tag)
+                m = cdr.ArchetypalAnalysis(3, init=init, random_state=0, tolerance=1e-6,
+                                           max_iterations=1000, dictionary_solver_kwargs=dkw,
+                                           dtype=dtype)
+                W = m.fit_transform(X)
+                want_cost, want_it = g["out_cost_" + key]
+                assert abs(m.cost - want_cost) < tol, key
+                assert sorted(m.dictionary.argmax(axis=1)) == sorted(g["out_argmax_" + key]), key
+                assert abs(m.n_iter - int(want_it)) <= 3, key
+                assert np.abs(m.archetypes - m.dictionary.dot(X)).max() < 1e-4 if dtype == "float32" \
+                    else np.abs(m.archetypes - m.dictionary.dot(X)).max() < 1e-12
+                _assert_simplex(W, 1e-12)
+                if key == "furthest_sum_one" and dtype == "float64":
+                    Wn, cn = m.transform(X[:25] + 0.0)
+                    # transform draws fresh random starting weights; compare the optimum
+                    assert abs(cn - g["out_transform_cost"]) < 1e-8
+                    assert np.abs(m.inverse_transform(Wn) - g["out_inverse"]).max() < 1e-4
+
+
+def test_kernel_aa_estimator_hull(cdr):
+    g = load_golden("kernel_aa_estimator")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = cdr.KernelAA(3, delta=0, init="custom", tolerance=1e-10, max_iterations=500)
+        W = m.fit_transform(g["in_K"], dictionary=g["in_C0"], weights=g["in_Z0"], alpha=np.ones(3))
+    assert sorted(m.dictionary.argmax(axis=1)) == [5, 27, 32]
+    assert abs(m.cost - g["out_cost"][0]) < 1e-8
+    _assert_simplex(W, 1e-12)
+
+
+def test_deepcopy_and_shared_random_state(cdr):
+    import copy
+    rng = np.random.RandomState(3)
+    X = rng.uniform(size=(80, 12))
+    shared = np.random.RandomState(0)
+    best = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(2):                        # drivers' n_init loop, bin/run_hadisst_aa.py:158-172
+            m = cdr.ArchetypalAnalysis(3, init="random", random_state=shared, max_iterations=20,
+                                       dictionary_solver_kwargs=dict(max_iterations=1))
+            m.fit_transform(X)
+            if best is None or m.cost < best.cost:
+                best = copy.deepcopy(m)
+    assert best.weights.shape == (80, 3) and best.archetypes.shape == (3, 12)
+
+
+# ---------------------------------------------------------------- GPNH
+def test_gpnh_golden(cdr):
+    from convex_dim_red import gpnh_convex_coding as gp
+    g = load_golden("gpnh")
+    X, W0, Z0 = g["in_X"], g["in_W0"], g["in_Z0"]
+    p, k = W0.shape
+    for lam in (0.0, 1.0):
+        tag = "lam%d" % int(lam)
+        assert abs(gp._gpnh_cost(X, Z0, W0, lam) - g["out_cost0_" + tag]) < 1e-12
+        GW = (4.0 / (p * k * (k - 1))) * (k * np.eye(k) - 1)
+        Wn = gp._update_gpnh_dictionary(X, Z0, Z0.T.dot(Z0), GW, lam)
+        assert np.abs(Wn - g["out_Wupd_" + tag]).max() < 1e-10
+        for wtag, wkw in (("one", dict(max_iterations=1)), ("full", {})):
+            Z, W, cost, n_iter, _, deltas = gp._iterate_gpnh_convex_coding(
+                X, Z0.copy(), W0.copy(), lambda_W=lam, tolerance=1e-6, max_iterations=200,
+                stopping_criterion="rel_delta_f", weights_solver_kwargs=wkw)
+            want_cost, want_it = g["out_cost_%s_%s" % (tag, wtag)]
+            assert abs(cost - want_cost) < 1e-5 * want_cost, (tag, wtag)
+            assert abs(n_iter - int(want_it)) <= 3, (tag, wtag)
+            _assert_simplex(Z, 1e-12)
+    assert np.abs(gp._update_gpnh_weights(X, Z0, W0) - g["out_Zupd"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-5), ("float32", 1e-4)])
+def test_gpnh_estimator_known_answers(cdr, dtype, tol):
+    g = load_golden("gpnh_estimator")
+    X = g["in_X"]
+    for lam in (0.0, 1.0):
+        for init in ("random", "furthest_sum"):
+            key = "lam%d_%s" % (int(lam), init)
+            m = cdr.GPNHConvexCoding(5, lambda_W=lam, init=init, tolerance=1e-6,
+                                     max_iterations=3000, stopping_criterion="rel_delta_f",
+                                     random_state=0, dtype=dtype,
+                                     weights_solver_kwargs=dict(max_iterations=1))
+            Z = m.fit_transform(X)
+            want_cost, want_it = g["out_cost_" + key]
+            assert abs(m.cost - want_cost) < tol * want_cost, key
+            assert m.dictionary.shape == (30, 5) and Z.shape == (300, 5)
+
+
+# ---------------------------------------------------------------- bigger problems vs oracle
+@pytest.mark.parametrize("dtype,k,rtol", [("float64", 32, 1e-9), ("float32", 32, 2e-5),
+                                          ("float64", 40, 1e-9), ("float32", 5, 2e-5)])
+def test_medium_problem_vs_oracle(cdr, orc, dtype, k, rtol):
+    """n = 3000, p = 700 (not a multiple of any tile): three production outer iterations
+    from the same start; factors, costs, support and argmax against the oracle."""
+    from convex_dim_red import archetypal_analysis as aa
+    rng = np.random.RandomState(k)
+    n, p = 3000, 700
+    B = rng.standard_normal((k, p))
+    Zt = orc.right_stochastic_matrix((n, k), rng) ** 4
+    Zt /= Zt.sum(axis=1, keepdims=True)
+    X = Zt.dot(B) + 0.05 * rng.standard_normal((n, p))
+    if dtype == "float32":
+        X = X.astype(np.float32)
+    rs = np.random.RandomState(1)
+    C0 = orc.right_stochastic_matrix((k, n), rs)
+    Z0 = orc.right_stochastic_matrix((n, k), rs)
+    kw = dict(tolerance=0, max_iterations=3, dictionary_solver_kwargs=dict(max_iterations=1),
+              require_monotonic_cost_decrease=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Xd = X.astype(np.float64)
+        wZ, wC, _, wcost, _, _, wdeltas = orc.iterate_aa(
+            Xd, Z0.copy(), C0.copy(), np.ones(k), trace_XXt=(Xd * Xd).sum(), **kw)
+        Z, C, _, cost, n_iter, _, deltas = aa._iterate_aa(
+            X, Z0.copy(), C0.copy(), np.ones(k), dtype=dtype, **kw)
+    assert abs(cost - wcost) < rtol * wcost
+    assert np.abs(np.asarray(deltas) - np.asarray(wdeltas)).max() < 10 * rtol * wcost
+    assert np.array_equal(C.argmax(axis=1), wC.argmax(axis=1))
+    _assert_simplex(C, 1e-12)
+    _assert_simplex(Z, 1e-12)
+    if dtype == "float64":
+        assert np.abs(C - wC).max() < 1e-7
+        assert np.abs(Z - wZ).max() < 1e-4
+        assert np.array_equal(C > 0, wC > 0)
+
+
+def test_reconstruction_cost_matches_trace_form(cdr, orc):
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(9)
+    n, p, k = 1000, 300, 6
+    X = rng.standard_normal((n, p)).astype(np.float32)
+    C = orc.right_stochastic_matrix((k, n), rng)
+    Z = orc.right_stochastic_matrix((n, k), rng)
+    Xd = X.astype(np.float64)
+    want = 0.5 * np.linalg.norm(Xd - Z.dot(C.dot(Xd))) ** 2 / n
+    for dtype in ("float32", "float64"):
+        with _backend.Context(dtype=dtype) as ctx:
+            ctx.set_data(X)
+            ctx.set_state(C, Z, np.ones(k))
+            cost = ctx.prepare()
+            rec = ctx.reconstruction_cost()
+            tr = ctx.data_trace()
+        assert abs(tr - (Xd * Xd).sum()) < 1e-10 * tr
+        assert abs(rec - want) < (1e-6 if dtype == "float32" else 1e-12) * want
+        assert abs(cost - want) < (1e-4 if dtype == "float32" else 1e-10) * want
