@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""Headline benchmark: archetypal-analysis outer iterations per second on the synthetic
+fp32 100000 x 4096, k = 32 problem (BASELINE.json configs[3]/[4]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE outer iteration of the alternating solver on data already resident in
+HBM: dictionary SPG update (reference archetypal_analysis.py:324-341 with the
+production setting dictionary_solver_kwargs={max_iterations: 1}) + Gram refresh
+(:618-627) + per-sample simplex-QP weights update (:369-396, default solver settings)
++ Gram refresh (:640-648).  N > 1 (launched by torch.distributed.run, one rank per
+GPU): X is row-sharded, the total problem is fixed (strong scaling), RCCL all-reduces
+only the k x p / k x k Gram products and packed scalars.
+
+No PyTorch here: ranks read RANK/LOCAL_RANK/WORLD_SIZE/MASTER_PORT from the
+environment, exchange the RCCL unique id through a file in /tmp, and do the barrier and
+the max-over-ranks through the library's own communicator.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "matrix-factorization-case-studies_amd"))
+sys.path.insert(0, ROOT)
+
+N_SAMPLES, N_FEATURES, N_COMPONENTS = 100000, 4096, 32
+BLOCK_ROWS = 500                      # synthetic data is generated in seeded row blocks
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def synthetic_rows(lo, hi, n=N_SAMPLES, p=N_FEATURES, k=N_COMPONENTS):
+    """Rows [lo, hi) of the benchmark matrix X = Zt B + 0.05 noise (float32).  Archetypes
+    B from RandomState(0); every BLOCK_ROWS-row block of (Zt, noise) from its own
+    RandomState(1000 + block), so the matrix does not depend on how it is sharded."""
+    B = np.random.RandomState(0).standard_normal((k, p))
+    out = np.empty((hi - lo, p), dtype=np.float32)
+    b0, b1 = lo // BLOCK_ROWS, (hi + BLOCK_ROWS - 1) // BLOCK_ROWS
+    for blk in range(b0, b1):
+        r0, r1 = blk * BLOCK_ROWS, min((blk + 1) * BLOCK_ROWS, n)
+        rng = np.random.RandomState(1000 + blk)
+        Zt = rng.uniform(size=(r1 - r0, k))
+        Zt /= Zt.sum(axis=1, keepdims=True)
+        Zt = Zt ** 4                                      # peaky weights: identifiable hull
+        Zt /= Zt.sum(axis=1, keepdims=True)
+        rows = Zt.dot(B) + 0.05 * rng.standard_normal((r1 - r0, p))
+        s0, s1 = max(lo, r0), min(hi, r1)
+        out[s0 - lo:s1 - lo] = rows[s0 - r0:s1 - r0]
+    return out
+
+
+def start_factors(n=N_SAMPLES, k=N_COMPONENTS):
+    """init='random' start (reference archetypal_analysis.py:51-70) from RandomState(1)."""
+    rs = np.random.RandomState(1)
+    C = rs.uniform(size=(k, n))
+    C /= C.sum(axis=1, keepdims=True)
+    Z = rs.uniform(size=(n, k))
+    Z /= Z.sum(axis=1, keepdims=True)
+    return C, Z
+
+
+def exchange_unique_id(rank, world, backend):
+    port = os.environ.get("MASTER_PORT", "0")
+    run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    path = "/tmp/aa_bench_uid_%s_%s_%d" % (port, run, world)
+    if rank == 0:
+        uid = backend.comm_unique_id()
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as fh:
+            fh.write(uid)
+        os.replace(tmp, path)
+        return uid, path
+    deadline = time.time() + 300
+    while time.time() < deadline:
+        if os.path.exists(path) and os.path.getsize(path) == 128:
+            with open(path, "rb") as fh:
+                return fh.read(), path
+        time.sleep(0.05)
+    raise RuntimeError("rank %d: timed out waiting for the RCCL unique id" % rank)
+
+
+def cpu_baseline(k, p, spg_kw, n_sample, steps):
+    """The reference's op sequence (oracle.iterate_aa: 11 GEMM passes over X, sort-based
+    projections, serial per-sample QPs) in float64 on the host, on the first n_sample
+    rows of the workload from the same kind of start; returns (it/s scaled to the full n,
+    description, final cost on the sample, GPU-comparable inputs)."""
+    from oracle import aa_oracle as orc
+    X = synthetic_rows(0, n_sample).astype(np.float64)
+    C, Z = start_factors(n_sample, k)
+    trace = float((X * X).sum())
+    kw = dict(tolerance=0, dictionary_solver_kwargs=spg_kw, require_monotonic_cost_decrease=False,
+              trace_XXt=trace)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Z1, C1, _, _, _, _, _ = orc.iterate_aa(X, Z, C, np.ones(k), max_iterations=1, **kw)   # warm-up
+        t0 = time.perf_counter()
+        timings = {}
+        Z2, C2, _, cost, _, _, deltas = orc.iterate_aa(X, Z1, C1, np.ones(k), max_iterations=steps,
+                                                       timings=timings, **kw)
+        dt = time.perf_counter() - t0
+    its = steps / dt
+    return dict(its_sample=its, seconds=dt, cost=cost, timings=timings, X=X, C=C, Z=Z,
+                used_c=orc.clib() is not None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=N_SAMPLES)
+    ap.add_argument("--p", type=int, default=N_FEATURES)
+    ap.add_argument("--k", type=int, default=N_COMPONENTS)
+    ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8000)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one rank per GPU: launch with "
+                             "python -m torch.distributed.run --nproc-per-node %d bench.py ..."
+                             % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    from convex_dim_red import _backend
+    _backend.require_gpu()                                 # no CPU fallback
+
+    n, p, k = args.n, args.p, args.k
+    bounds = np.linspace(0, n, world + 1).astype(np.int64)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    t_gen = time.perf_counter()
+    X = synthetic_rows(lo, hi, n, p, k)
+    C0, Z0 = start_factors(n, k)
+    t_gen = time.perf_counter() - t_gen
+
+    spg_kw = dict(max_iterations=1)                        # production setting (run_hadisst_aa.py:165)
+    qp_kw = {}                                             # defaults (archetypal_analysis.py:372-383)
+
+    ctx = _backend.Context(dtype=args.dtype, device=local_rank)
+    uid_path = None
+    if world > 1:
+        uid, uid_path = exchange_unique_id(rank, world, _backend)
+        ctx.comm_init(uid, rank, world)
+    ctx.set_data(X, n_global=n, row_offset=lo)
+    ctx.set_state(np.ascontiguousarray(C0[:, lo:hi]), Z0[lo:hi], np.ones(k))
+    cost0 = ctx.prepare()
+
+    if args.warmup > 0:
+        ctx.outer_iterations(args.warmup, spg_kw, qp_kw)
+    ctx.allreduce_host([0.0])                              # barrier (outer_iterations ends synchronised)
+    t0 = time.perf_counter()
+    costs = ctx.outer_iterations(args.steps, spg_kw, qp_kw)
+    elapsed = time.perf_counter() - t0                     # host has read the last cost: device idle
+    elapsed = float(ctx.allreduce_host([elapsed], "max")[0])
+
+    # dominant kernels, timed live with HIP events on the solver's stream
+    reps = 10
+    ms_reduce = ctx.time_kernel(0, reps)                   # C X / D X / Z'X   (k x p out)
+    ms_local = ctx.time_kernel(1, reps)                    # (CX) X' / X (X'Z) (n x k out)
+    qp_stats = ctx.weights_update(**qp_kw)                 # one more QP pass for its statistics
+    recon = ctx.reconstruction_cost()
+    trace_cost = ctx.cost()
+    ms_reduce = float(ctx.allreduce_host([ms_reduce], "max")[0])
+    ms_local = float(ctx.allreduce_host([ms_local], "max")[0])
+    ctx.close()
+    if uid_path and rank == 0:
+        try:
+            os.remove(uid_path)
+        except OSError:
+            pass
+    if rank != 0:
+        return
+
+    es = 4 if args.dtype == "float32" else 8
+    n_loc = hi - lo
+    bytes_pass = float(n_loc) * p * es                     # algorithmic bytes of one pass over X
+    flops_pass = 2.0 * k * n_loc * p
+    ms_dom = 0.5 * (ms_reduce + ms_local)                  # 3 + 3 launches per outer iteration
+    achieved_gbs = bytes_pass / (ms_dom * 1e-3) / 1e9
+    its = args.steps / elapsed
+    flops_alg = 12.0 * k * n * p                           # 6 passes x 2knp
+    result = {
+        "metric": "AA SPG outer iterations/sec (synthetic %dx%d, k=%d)" % (n, p, k),
+        "value": its,
+        "unit": "it/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32" if args.dtype == "float32" else "f64",
+        "data": "synthetic",
+        "config": {"workload": "AA n=%d p=%d k=%d, X row-sharded over %d GPU(s), init=random, "
+                               "delta=0, dictionary spg max_iterations=1, default weights QP"
+                               % (n, p, k, world),
+                   "parallelism": "rows/%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_reduce_rows_f32 / k_row_local_f32 (mean of the two pass kernels)",
+                     "ms_reduce_rows": ms_reduce, "ms_row_local": ms_local,
+                     "bytes_per_launch": bytes_pass, "flops_per_launch": flops_pass,
+                     "mfma_frac_of_kernel": flops_pass / (ms_dom * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12)},
+        "mfma_frac_outer_iteration": flops_alg / world / (elapsed / args.steps) / (MFMA_F32_PEAK_TFLOPS * 1e12),
+        "cost": {"initial": cost0, "final_trace_form": trace_cost, "final_residual_form": recon,
+                 "after_each_update_last": [float(costs[-2]), float(costs[-1])]},
+        "qp": {"mean_passes_per_sample": qp_stats.total_passes / float(n_loc),
+               "max_passes": qp_stats.max_passes},
+        "datagen_s": t_gen,
+    }
+
+    if not args.no_cpu_baseline and world == 1:
+        base = cpu_baseline(k, p, spg_kw, min(args.cpu_sample, n), args.cpu_steps)
+        ns = min(args.cpu_sample, n)
+        # the same sample through the HIP path for a like-for-like cost comparison
+        with _backend.Context(dtype=args.dtype, device=local_rank) as c2:
+            c2.set_data(base["X"].astype(np.float32) if args.dtype == "float32" else base["X"])
+            c2.set_state(base["C"], base["Z"], np.ones(k))
+            c2.prepare()
+            gcosts = c2.outer_iterations(1 + args.cpu_steps, spg_kw, qp_kw)
+        result["cpu_baseline"] = {
+            "value": base["its_sample"] * ns / float(n),
+            "unit": "it/s",
+            "cores": len(os.sched_getaffinity(0)),
+            "kind": "port",
+            "sample": "oracle.iterate_aa (reference op sequence, float64, NumPy/BLAS GEMMs on all "
+                      "host cores + %s projection/QP loops) on the first %d rows of the workload, "
+                      "%d outer iterations in %.1f s = %.3f it/s at n=%d; value = that rate x %d/%d"
+                      % ("serial C" if base["used_c"] else "NumPy", ns, args.cpu_steps,
+                         base["seconds"], base["its_sample"], ns, ns, n),
+            "phase_seconds": base["timings"],
+        }
+        result["parity_on_sample"] = {
+            "oracle_cost": base["cost"], "hip_cost": float(gcosts[-1]),
+            "rel_diff": abs(float(gcosts[-1]) - base["cost"]) / base["cost"],
+        }
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()
