@@ -55,6 +55,10 @@ void set_error(const char *fmt, ...);
 
 inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 
+// zero rows allocated past n_pad in X and in every tall array, so software-pipelined
+// kernels may prefetch past the end of their row range without a guard
+#define AA_SLACK_ROWS 64
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -148,6 +152,7 @@ struct Ctx {
     DevBuf partial;                            // GEMM split-row partials
     DevBuf redPartial;                         // tall/wide reduction partials
     DevBuf gramOut;                            // up to 4 KPxKP results
+    DevBuf gramPP;                             // (CX)(CX)' / C K C' of the current dictionary
     DevBuf redOut;                             // finalized [NV][KP] reduction results
     DevBuf scalars;                            // SC_COUNT doubles
     DevBuf proj;                               // ProjState
@@ -159,6 +164,9 @@ struct Ctx {
 
     long nslab = 0, rows_per_slab = 0;         // reduce-over-rows decomposition
     int tallBlocks = 0;                        // blocks of the tall reductions
+    int projPassHint = 0;                      // Michelot passes the last projection needed
+    bool x_feasible = false;                   // dictionary known to be on the simplex
+    bool products_valid = false;               // P (= CX) and Gr (= C XX' or C K) match Ct
 };
 
 // ------------------------------------------------------------------ kernels_gemm.hip

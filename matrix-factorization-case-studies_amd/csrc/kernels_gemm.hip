@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_reduce_rows_f32(const float *__restrict
                                                          float *__restrict__ partial)
 {
     constexpr int KP = 32 * NCT;
-    constexpr int U = 8;
+    constexpr int U = 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c0 = (blockIdx.x * 4 + wave) * 128;
     if (c0 >= p_pad) return;   // wave-uniform; the kernel has no barriers
@@ -57,28 +57,42 @@ __global__ __launch_bounds__(256) void k_reduce_rows_f32(const float *__restrict
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[ct][m][e] = 0.f;
 
+    // Two register sets, software-pipelined one half-step (2*U rows) ahead: while the
+    // MFMAs of one set run, the U dwordx4 loads of the other are in flight.  The
+    // sched_barriers keep hipcc from sinking the loads down to their first use.
     const float *xp = X + (r_begin + h) * ldx + c0 + 4 * j;
     const double *ap = A + (r_begin + h) * KP + j;
-    for (long r = r_begin; r < r_end; r += 2 * U) {
-        f32x4 xv[U];
-        float av[U][NCT];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            xv[u] = *reinterpret_cast<const f32x4 *>(xp + (long)(2 * u) * ldx);
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) av[u][ct] = (float)ap[(2 * u) * KP + ct * 32];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    acc[ct][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][ct], xv[u][m],
-                                                                      acc[ct][m], 0, 0, 0);
-        xp += (long)(2 * U) * ldx;
-        ap += (2 * U) * KP;
+    f32x4 xa[U], xb[U];
+    double aa[U][NCT], ab[U][NCT];
+#define RR_LOAD(XV, AV, ROWOFF)                                                              \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
+        XV[u] = *reinterpret_cast<const f32x4 *>(xp + (long)((ROWOFF) + 2 * u) * ldx);        \
+        _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct)                                    \
+            AV[u][ct] = ap[((ROWOFF) + 2 * u) * KP + ct * 32];                                \
     }
+#define RR_COMPUTE(XV, AV)                                                                   \
+    _Pragma("unroll") for (int u = 0; u < U; ++u)                                             \
+        _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct) {                                  \
+            const float af = (float)AV[u][ct];                                                \
+            _Pragma("unroll") for (int m = 0; m < 4; ++m)                                     \
+                acc[ct][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, XV[u][m], acc[ct][m],  \
+                                                                  0, 0, 0);                   \
+        }
+    RR_LOAD(xa, aa, 0)
+    for (long r = r_begin; r < r_end; r += 4 * U) {
+        RR_LOAD(xb, ab, 2 * U)      // may run past r_end: X and A carry AA_SLACK_ROWS zero rows
+        __builtin_amdgcn_sched_barrier(0);
+        RR_COMPUTE(xa, aa)
+        __builtin_amdgcn_sched_barrier(0);
+        RR_LOAD(xa, aa, 4 * U)
+        __builtin_amdgcn_sched_barrier(0);
+        RR_COMPUTE(xb, ab)          // the row range is a multiple of 4*U
+        __builtin_amdgcn_sched_barrier(0);
+        xp += (long)(4 * U) * ldx;
+        ap += (4 * U) * KP;
+    }
+#undef RR_LOAD
+#undef RR_COMPUTE
 
     // D layout (32x32): column = lane&31 (-> 4 data columns c0+4j+m), row (component)
     // = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -195,6 +209,73 @@ __global__ __launch_bounds__(256) void k_row_local_f32(const float *__restrict__
             }
 }
 
+// row-local, float32 MFMA, X staged through wave-private LDS.
+// Each wave owns 32 rows and streams them in [32 rows][128 columns] tiles (16 KB): the
+// HBM side is 16 fully coalesced loads (two 512-byte row segments per wave-instruction,
+// register-prefetched one tile ahead), the MFMA side reads its A fragments from LDS with
+// ds_read_b128.  16-byte chunk c of row r is stored at chunk c ^ (r & 15), so the 16
+// lanes of a ds_read_b128 group (16 different rows, same logical chunk) hit 16 different
+// bank groups.  The tile is private to the wave: no barriers.
+template <int NCT>
+__global__ __launch_bounds__(256) void k_row_local_f32_lds(const float *__restrict__ X, long ldx,
+                                                           const float *__restrict__ B, int p_pad,
+                                                           double *__restrict__ out, long n_pad)
+{
+    constexpr int KP = 32 * NCT;
+    __shared__ __attribute__((aligned(16))) float tiles[4][32 * 128];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (r0 >= n_pad) return;
+    const int h = lane >> 5, j = lane & 31;
+    float *my = tiles[wave];
+
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+
+    const float *gbase = X + (r0 + h) * ldx + 4 * j;       // lane: row 2e + h, chunk j
+    const float *bp = B + (long)j * p_pad + 4 * h;
+    f32x4 stage[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) stage[e] = *reinterpret_cast<const f32x4 *>(gbase + (long)(2 * e) * ldx);
+
+    for (int c0 = 0; c0 < p_pad; c0 += 128) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 2 * e + h;
+            *reinterpret_cast<f32x4 *>(my + row * 128 + ((j ^ (row & 15)) << 2)) = stage[e];
+        }
+        if (c0 + 128 < p_pad) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stage[e] = *reinterpret_cast<const f32x4 *>(gbase + (long)(2 * e) * ldx + c0 + 128);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMA block
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(my + j * 128 + (((2 * q + h) ^ (j & 15)) << 2));
+            f32x4 bv[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                bv[ct] = *reinterpret_cast<const f32x4 *>(bp + (long)(ct * 32) * p_pad + c0 + 8 * q);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[ct][m], acc[ct], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const long row = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            out[row * KP + ct * 32 + j] = (double)acc[ct][reg];
+        }
+}
+
 // row-local, float64 VALU: block = 64 rows, X tile staged through LDS with coalesced
 // loads; thread (row = t&63, q = t>>6) accumulates the components [q*KP/4, (q+1)*KP/4).
 template <int KP>
@@ -274,10 +355,29 @@ int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *out
     return AA_OK;
 }
 
+static int row_local_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("AA_ROW_LOCAL");
+        v = (e && !strcmp(e, "direct")) ? 0 : 1;      // default: LDS-staged
+    }
+    return v;
+}
+
 int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
 {
     dim3 block(256);
-    if (c->dtype == AA_F32) {
+    if (c->dtype == AA_F32 && row_local_variant() == 1) {
+        const float *B = reinterpret_cast<const float *>(B_wideT);
+        dim3 grid((unsigned)(c->n_pad / 128));
+        if (c->KP == 32)
+            hipLaunchKernelGGL(k_row_local_f32_lds<1>, grid, block, 0, c->stream, c->X.as<float>(),
+                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
+        else
+            hipLaunchKernelGGL(k_row_local_f32_lds<2>, grid, block, 0, c->stream, c->X.as<float>(),
+                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
+    } else if (c->dtype == AA_F32) {
         const float *B = reinterpret_cast<const float *>(B_wideT);
         if (c->KP == 32) {
             constexpr int RT = 2;

@@ -57,26 +57,69 @@ __device__ __forceinline__ double qp_project_threshold(const double (&x)[KQ], co
     return t;
 }
 
+// Continuation record of a sample whose SPG loop hit the phase-1 pass cap.
+struct QpCarry {
+    double alpha, f;
+    int n_iter, n_feval;
+};
+
+// Device-side header of the QP scratch buffer (zeroed by the host before each update).
+struct QpHeader {
+    unsigned long long total_passes, max_passes;
+    unsigned int next_row;        // phase-1 work counter
+    unsigned int n_overflow;      // samples handed to phase 2
+    unsigned int next_overflow;   // phase-2 work counter
+    unsigned int pad;
+};
+
+// ---------------------------------------------------------------------------
+// phase 1: one lane per sample, A broadcast from LDS.
+// ---------------------------------------------------------------------------
+// out = A v for the sample of this lane.  v sits in LDS as vl[j*64] (lane-private
+// column, conflict-free), A transposed as AsT[j][i] so one step reads a contiguous,
+// wave-uniform (broadcast) 8*KQ-byte row.  The j loop is a real loop: its loads depend
+// on j, so the compiler cannot hoist the whole matrix into registers.
+template <int KQ>
+__device__ __forceinline__ void qp_matvec(const double *__restrict__ AsT,
+                                          const double *__restrict__ vl, int k, double (&out)[KQ])
+{
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) out[i] = 0.0;
+#pragma unroll 2
+    for (int j = 0; j < k; ++j) {
+        const double vj = vl[j * 64];
+        const double *col = AsT + j * KQ;
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) out[i] = fma(col[i], vj, out[i]);
+    }
+}
+
 template <int KQ>
 __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][KQ]*/,
                                            const double *__restrict__ B, long stride_j,
                                            long stride_t, const double *__restrict__ bscale,
-                                           const double *__restrict__ Z0, double *__restrict__ Z,
-                                           int ldz, long n, int k, aa_qp_params p,
-                                           int *__restrict__ iters,
-                                           unsigned long long *__restrict__ stats,
-                                           unsigned int *__restrict__ counter)
+                                           double *__restrict__ Z, int ldz, long n, int k,
+                                           aa_qp_params p, int pass_cap, int *__restrict__ iters,
+                                           QpHeader *__restrict__ hdr,
+                                           int *__restrict__ ovf_rows, QpCarry *__restrict__ ovf)
 {
-    double x[KQ], g[KQ], d[KQ], Ad[KQ];
+    __shared__ __attribute__((aligned(16))) double AsT[KQ * KQ];
+    __shared__ double vbuf[KQ * 64];
+    for (int e = threadIdx.x; e < KQ * KQ; e += 64) AsT[(e % KQ) * KQ + e / KQ] = A[e];
+    __syncthreads();
+    double *vl = vbuf + threadIdx.x;
+
+    double x[KQ], g[KQ], Ad[KQ];
     double f = 0.0, alpha = 1.0, fmem[QP_MAXMEM];
     int n_iter = 0, n_feval = 0;
     long row = -1;
     bool active = false, exhausted = false;
     const int mem = p.memory < 1 ? 1 : (p.memory > QP_MAXMEM ? QP_MAXMEM : p.memory);
 
-    while (true) {
+    // the trip bound is a watchdog only (each sample needs <= max_iterations trips)
+    for (long trip = 0; trip < (1L << 24); ++trip) {
         if (!active && !exhausted) {
-            const unsigned int nxt = atomicAdd(counter, 1u);
+            const unsigned int nxt = atomicAdd(&hdr->next_row, 1u);
             if ((long)nxt < n) {
                 row = (long)nxt;
                 active = true;
@@ -84,20 +127,20 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                 double b[KQ];
 #pragma unroll
                 for (int i = 0; i < KQ; ++i) {
-                    x[i] = (i < k) ? Z0[row * ldz + i] : 0.0;
+                    x[i] = (i < k) ? Z[row * ldz + i] : 0.0;
                     g[i] = 0.0;
                     b[i] = (i < k) ? -B[i * stride_j + row * stride_t] * (bscale ? bscale[i] : 1.0) : 0.0;
                 }
                 const double t0 = qp_project_threshold<KQ>(x, g, 0.0, k);
 #pragma unroll
                 for (int i = 0; i < KQ; ++i) x[i] = (i < k) ? fmax(x[i] - t0, 0.0) : 0.0;
+#pragma unroll
+                for (int i = 0; i < KQ; ++i) vl[i * 64] = x[i];
+                qp_matvec<KQ>(AsT, vl, k, g);
                 double xg = 0.0, xb = 0.0;
 #pragma unroll
                 for (int i = 0; i < KQ; ++i) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int j = 0; j < KQ; ++j) s = fma(A[i * KQ + j], x[j], s);
-                    g[i] = s + b[i];
+                    g[i] += b[i];
                     xg = fma(x[i], g[i], xg);
                     xb = fma(x[i], b[i], xb);
                 }
@@ -130,19 +173,15 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             double delta = 0.0, dd = 0.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
-                d[i] = (i < k) ? fmax(x[i] - alpha * g[i] - td, 0.0) - x[i] : 0.0;
-                delta = fma(d[i], g[i], delta);
-                dd = fma(d[i], d[i], dd);
+                const double di = (i < k) ? fmax(x[i] - alpha * g[i] - td, 0.0) - x[i] : 0.0;
+                vl[i * 64] = di;                 // the direction lives in LDS only
+                delta = fma(di, g[i], delta);
+                dd = fma(di, di, dd);
             }
+            qp_matvec<KQ>(AsT, vl, k, Ad);
             double dAd = 0.0;
 #pragma unroll
-            for (int i = 0; i < KQ; ++i) {
-                double s = 0.0;
-#pragma unroll
-                for (int j = 0; j < KQ; ++j) s = fma(A[i * KQ + j], d[j], s);
-                Ad[i] = s;
-                dAd = fma(d[i], s, dAd);
-            }
+            for (int i = 0; i < KQ; ++i) dAd = fma(vl[i * 64], Ad[i], dAd);
             // non-monotone reference value (spg.py:341-344): roll, store, nanmax
 #pragma unroll
             for (int i = QP_MAXMEM - 1; i > 0; --i)
@@ -167,7 +206,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             }
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
-                x[i] = fma(lam, d[i], x[i]);
+                x[i] = fma(lam, vl[i * 64], x[i]);
                 g[i] = fma(lam, Ad[i], g[i]);
             }
             const double sksk = lam * lam * dd;
@@ -187,15 +226,191 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                 }
             n_iter += 1;
             const bool conv = (sqrt(r2) < p.epsilon_two) || (rinf < p.epsilon_one);
-            if (conv || n_feval > p.max_feval || n_iter >= p.max_iterations) {
+            const bool finished = conv || n_feval > p.max_feval || n_iter >= p.max_iterations;
+            if (finished || n_iter >= pass_cap) {
 #pragma unroll
                 for (int i = 0; i < KQ; ++i)
                     if (i < k) Z[row * ldz + i] = x[i];
-                if (iters) iters[row] = n_iter;
-                atomicAdd(&stats[0], (unsigned long long)n_iter);
-                atomicMax(&stats[1], (unsigned long long)n_iter);
+                if (finished) {
+                    if (iters) iters[row] = n_iter;
+                    atomicAdd(&hdr->total_passes, (unsigned long long)n_iter);
+                    atomicMax(&hdr->max_passes, (unsigned long long)n_iter);
+                } else {
+                    // hand the sample to the low-latency wave-per-sample kernel
+                    const unsigned int slot = atomicAdd(&hdr->n_overflow, 1u);
+                    ovf_rows[slot] = (int)row;
+                    QpCarry cr;
+                    cr.alpha = alpha;
+                    cr.f = f;
+                    cr.n_iter = n_iter;
+                    cr.n_feval = n_feval;
+                    ovf[slot] = cr;
+                }
                 active = false;
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// phase 2 (and the whole update when k > 32): ONE WAVE PER SAMPLE, lane = component.
+// Short critical path per SPG pass (a handful of wave reductions and a k-step
+// broadcast mat-vec), so the few samples that need hundreds of passes do not hold a
+// 64-sample wave hostage.  memory == 1 only on the continuation path (the host keeps
+// samples in phase 1 otherwise); fresh samples support any memory.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double qw_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double qw_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double qw_bcast(double v, int j)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, j);
+    hi = __builtin_amdgcn_readlane(hi, j);
+    return __hiloint2double(hi, lo);
+}
+// threshold of the projection of the wave-distributed vector w (w = -inf on idle lanes)
+__device__ __forceinline__ double qw_threshold(double w, int k)
+{
+    double t = qw_max(w) - 1.0;
+    int prev = 0;
+    for (int pass = 0; pass < k + 2; ++pass) {
+        const bool in = w > t;
+        const int c = __popcll(__ballot(in));
+        const double s = qw_sum(in ? w : 0.0);
+        const bool conv = (prev > 0) && (c >= prev);
+        t = (s - 1.0) / (double)c;
+        prev = c;
+        if (conv) break;
+    }
+    return t;
+}
+
+template <int KQ>
+__global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*[KQ][KQ]*/,
+                                                 const double *__restrict__ B, long stride_j,
+                                                 long stride_t, const double *__restrict__ bscale,
+                                                 double *__restrict__ Z, int ldz, long n_fresh,
+                                                 int k, aa_qp_params p, int *__restrict__ iters,
+                                                 QpHeader *__restrict__ hdr,
+                                                 const int *__restrict__ ovf_rows,
+                                                 const QpCarry *__restrict__ ovf)
+{
+    const int lane = threadIdx.x & 63;
+    const bool live = lane < k;
+    // row `lane` of A in registers
+    double Arow[KQ];
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) Arow[j] = (lane < KQ) ? A[lane * KQ + j] : 0.0;
+    const int mem = p.memory < 1 ? 1 : (p.memory > QP_MAXMEM ? QP_MAXMEM : p.memory);
+    // n_fresh >= 0: process rows [0, n_fresh) from scratch; otherwise the overflow list
+    const bool fresh = n_fresh >= 0;
+    const unsigned int count = fresh ? (unsigned int)n_fresh : hdr->n_overflow;
+
+    const unsigned int wave_id =
+        (unsigned int)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const unsigned int n_waves = gridDim.x * 4;
+    for (unsigned int slot = wave_id; slot < count; slot += n_waves) {
+        const long row = fresh ? (long)slot : (long)ovf_rows[slot];
+
+        double x = live ? Z[row * ldz + lane] : 0.0;
+        const double b = live ? -B[lane * stride_j + row * stride_t] * (bscale ? bscale[lane] : 1.0) : 0.0;
+        double f, alpha = 1.0, fmem[QP_MAXMEM];
+        int n_iter, n_feval;
+#pragma unroll
+        for (int i = 0; i < QP_MAXMEM; ++i) fmem[i] = NAN;
+        if (fresh) {
+            const double t0 = qw_threshold(live ? x : -INFINITY, k);
+            x = live ? fmax(x - t0, 0.0) : 0.0;
+        }
+        double g = 0.0;
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) g = fma(Arow[j], qw_bcast(x, j), g);
+        g += b;
+        if (fresh) {
+            f = 0.5 * (qw_sum(x * g) + qw_sum(x * b));
+            n_iter = 0;
+            n_feval = 1;
+        } else {
+            const QpCarry cr = ovf[slot];
+            f = cr.f;
+            alpha = cr.alpha;
+            n_iter = cr.n_iter;
+            n_feval = cr.n_feval;
+        }
+
+        // `guard_w` bounds the loop even if the arithmetic goes non-finite
+        for (int guard_w = 0; guard_w < p.max_iterations + 2; ++guard_w) {
+            if (n_iter == 0) {
+                if (p.alpha_min <= p.alpha0 && p.alpha0 <= p.alpha_max) {
+                    alpha = p.alpha0;
+                } else {
+                    const double t1 = qw_threshold(live ? x - g : -INFINITY, k);
+                    double ainv = qw_max(live ? fabs(fmax(x - g - t1, 0.0) - x) : 0.0);
+                    if (fabs(ainv) < 1e-12) ainv = 1.0;
+                    alpha = fmin(fmax(p.alpha_min, 1.0 / ainv), p.alpha_max);
+                }
+            }
+            const double td = qw_threshold(live ? x - alpha * g : -INFINITY, k);
+            const double d = live ? fmax(x - alpha * g - td, 0.0) - x : 0.0;
+            const double delta = qw_sum(d * g);
+            const double dd = qw_sum(d * d);
+            double Ad = 0.0;
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) Ad = fma(Arow[j], qw_bcast(d, j), Ad);
+            const double dAd = qw_sum(d * Ad);
+
+#pragma unroll
+            for (int i = QP_MAXMEM - 1; i > 0; --i)
+                if (i < mem) fmem[i] = fmem[i - 1];
+            fmem[0] = f;
+            double f_max = f;
+#pragma unroll
+            for (int i = 1; i < QP_MAXMEM; ++i)
+                if (i < mem && fmem[i] > f_max) f_max = fmem[i];
+
+            double lam = 1.0;
+            double f_new = f + lam * delta + 0.5 * lam * lam * dAd;
+            n_feval += 1;
+            int guard = 0;
+            while (f_new > f_max + p.gamma * lam * delta && guard < 200) {
+                const double tmp = -0.5 * lam * lam * delta / (f_new - f - lam * delta);
+                lam = (p.sigma_one <= tmp && tmp <= p.sigma_two * lam) ? tmp : 0.5 * lam;
+                f_new = f + lam * delta + 0.5 * lam * lam * dAd;
+                n_feval += 1;
+                ++guard;
+                if (fabs(lam) < p.lambda_min) break;
+            }
+            x = fma(lam, d, x);
+            g = fma(lam, Ad, g);
+            const double sksk = lam * lam * dd;
+            const double beta = lam * (lam * dAd);
+            alpha = (beta <= 0.0) ? p.alpha_max : fmin(p.alpha_max, fmax(p.alpha_min, sksk / beta));
+            f = f_new;
+            n_feval += 1;
+
+            const double tr = qw_threshold(live ? x - g : -INFINITY, k);
+            const double r = live ? fmax(x - g - tr, 0.0) - x : 0.0;
+            const double r2 = qw_sum(r * r);
+            const double rinf = qw_max(fabs(r));
+            n_iter += 1;
+            const bool conv = (sqrt(r2) < p.epsilon_two) || (rinf < p.epsilon_one);
+            if (conv || n_feval > p.max_feval || n_iter >= p.max_iterations) break;
+        }
+        if (live) Z[row * ldz + lane] = x;
+        if (lane == 0) {
+            if (iters) iters[row] = n_iter;
+            atomicAdd(&hdr->total_passes, (unsigned long long)n_iter);
+            atomicMax(&hdr->max_passes, (unsigned long long)n_iter);
         }
     }
 }
@@ -220,7 +435,19 @@ __global__ __launch_bounds__(256) void k_qp_project_only(const double *__restric
         if (i < k) Z[row * ldz + i] = fmax(x[i] - t0, 0.0);
 }
 
-// Apad: device buffer [KQ][KQ] (zero padded copy of the host k x k matrix)
+// Passes a sample may spend in the lane-per-sample kernel before it is handed to the
+// wave-per-sample kernel.
+static int qp_pass_cap()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("AA_QP_PASS_CAP");
+        v = e ? atoi(e) : 16;
+        if (v < 1) v = 1;
+    }
+    return v;
+}
+
 int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, long stride_t,
               const double *bscale_host, double *Ztall, int ldz, long n, int k,
               const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats)
@@ -228,23 +455,36 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     int KQ = 4;
     while (KQ < k) KQ *= 2;
     AA_REQUIRE(KQ <= 64, AA_ERR_ARG, "QP: k = %d > 64 unsupported", k);
-    // stage A (padded) + bscale + counters in qpStats buffer:
-    //   [0..1] stats, [2] counter, then doubles: A[KQ*KQ], bscale[KQ]
-    const size_t hdr = 64;
-    const size_t bytes = hdr + ((size_t)KQ * KQ + KQ) * sizeof(double);
+    AA_REQUIRE(n < (1L << 31), AA_ERR_ARG, "QP: too many samples");
+    const bool wave_only = KQ > 32;
+    const int KW = wave_only ? 64 : 32;            // A padding of the wave kernel
+    // scratch layout: QpHeader | A[KQ*KQ] | A2[KW*KW] | bscale[64] | ovf_rows[n] | ovf[n]
+    const size_t off_A = 64;
+    const size_t off_A2 = off_A + (size_t)KQ * KQ * sizeof(double);
+    const size_t off_bs = off_A2 + (size_t)KW * KW * sizeof(double);
+    const size_t off_rows = off_bs + 64 * sizeof(double);
+    const size_t off_ovf = off_rows + round_up((long)n * sizeof(int), 16);
+    const size_t bytes = off_ovf + (size_t)n * sizeof(QpCarry);
     AA_CHECK(c->qpStats.alloc(bytes));
-    std::vector<unsigned char> host(bytes, 0);
-    double *Ah = reinterpret_cast<double *>(host.data() + hdr);
+    std::vector<unsigned char> host(off_rows, 0);
+    double *Ah = reinterpret_cast<double *>(host.data() + off_A);
+    double *A2h = reinterpret_cast<double *>(host.data() + off_A2);
     for (int i = 0; i < k; ++i)
-        for (int j = 0; j < k; ++j) Ah[i * KQ + j] = A_host[i * k + j];
-    double *bs = Ah + (size_t)KQ * KQ;
-    for (int i = 0; i < KQ; ++i) bs[i] = (bscale_host && i < k) ? bscale_host[i] : 1.0;
-    AA_CHECK_HIP(hipMemcpyAsync(c->qpStats.p, host.data(), bytes, hipMemcpyHostToDevice, c->stream));
+        for (int j = 0; j < k; ++j) {
+            Ah[i * KQ + j] = A_host[i * k + j];
+            A2h[i * KW + j] = A_host[i * k + j];
+        }
+    double *bs = reinterpret_cast<double *>(host.data() + off_bs);
+    for (int i = 0; i < 64; ++i) bs[i] = (bscale_host && i < k) ? bscale_host[i] : 1.0;
+    AA_CHECK_HIP(hipMemcpyAsync(c->qpStats.p, host.data(), off_rows, hipMemcpyHostToDevice, c->stream));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));   // host vector goes out of scope
-    unsigned long long *st = c->qpStats.as<unsigned long long>();
-    unsigned int *counter = reinterpret_cast<unsigned int *>(st + 2);
-    const double *Ad = reinterpret_cast<const double *>(reinterpret_cast<unsigned char *>(c->qpStats.p) + hdr);
-    const double *bsd = bscale_host ? Ad + (size_t)KQ * KQ : nullptr;
+    unsigned char *base = reinterpret_cast<unsigned char *>(c->qpStats.p);
+    QpHeader *hdr = reinterpret_cast<QpHeader *>(base);
+    const double *Ad = reinterpret_cast<const double *>(base + off_A);
+    const double *A2d = reinterpret_cast<const double *>(base + off_A2);
+    const double *bsd = bscale_host ? reinterpret_cast<const double *>(base + off_bs) : nullptr;
+    int *ovf_rows = reinterpret_cast<int *>(base + off_rows);
+    QpCarry *ovf = reinterpret_cast<QpCarry *>(base + off_ovf);
 
     if (p->max_iterations <= 0) {
         dim3 grid((unsigned)((n + 255) / 256));
@@ -252,24 +492,39 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         switch (KQ) { case 4: QPP(4); break; case 8: QPP(8); break; case 16: QPP(16); break;
                       case 32: QPP(32); break; default: QPP(64); break; }
 #undef QPP
+    } else if (wave_only) {
+        long blocks = (n + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_qp_wave<64>, dim3((unsigned)blocks), dim3(256), 0, c->stream, A2d, Btall,
+                           stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr,
+                           (const int *)ovf_rows, (const QpCarry *)ovf);
     } else {
+        // phase 1: every sample gets up to pass_cap passes in a lane
+        int cap = qp_pass_cap();
+        if (p->memory > 1 || p->max_iterations <= cap) cap = p->max_iterations;
         long waves = (n + 63) / 64;
-        const long max_waves = 256L * 4 * 2;     // 2 waves per SIMD on every CU
-        if (waves > max_waves) waves = max_waves;
+        if (waves > 2048) waves = 2048;
         dim3 grid((unsigned)waves);
-#define QPL(KQV) hipLaunchKernelGGL(k_qp<KQV>, grid, dim3(64), 0, c->stream, Ad, Btall, stride_j, stride_t, bsd, (const double *)Ztall, Ztall, ldz, n, k, *p, iters_dev, st, counter)
+#define QPL(KQV) hipLaunchKernelGGL(k_qp<KQV>, grid, dim3(64), 0, c->stream, Ad, Btall, stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf)
         switch (KQ) { case 4: QPL(4); break; case 8: QPL(8); break; case 16: QPL(16); break;
-                      case 32: QPL(32); break; default: QPL(64); break; }
+                      default: QPL(32); break; }
 #undef QPL
+        if (cap < p->max_iterations && !getenv("AA_QP_SKIP_PHASE2")) {
+            // phase 2: the stragglers, one wave each (grid is fixed; the count is read on
+            // the device, so no host synchronisation between the phases)
+            hipLaunchKernelGGL(k_qp_wave<32>, dim3(512), dim3(256), 0, c->stream, A2d, Btall, stride_j,
+                               stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
+                               (const int *)ovf_rows, (const QpCarry *)ovf);
+        }
     }
     AA_CHECK_HIP(hipGetLastError());
     if (stats) {
-        unsigned long long h[2] = {0, 0};
-        AA_CHECK_HIP(hipMemcpyAsync(h, st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        QpHeader h;
+        AA_CHECK_HIP(hipMemcpyAsync(&h, hdr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-        stats->total_passes = (long)h[0];
-        stats->max_passes = (int)h[1];
-        stats->reserved = 0;
+        stats->total_passes = (long)h.total_passes;
+        stats->max_passes = (int)h.max_passes;
+        stats->reserved = (int)h.n_overflow;
     }
     return AA_OK;
 }

@@ -159,44 +159,15 @@ __global__ __launch_bounds__(256) void k_proj_finish(int mode, const double *__r
 }
 
 // ---------------------------------------------------------------- finalize
-// partial [nb][NV][KP] -> red [NV][KP] (fixed order).  One block of 256 threads.
-__global__ __launch_bounds__(256) void k_finalize_sum(const double *__restrict__ partial, int nb,
-                                                      int NV, int KP, unsigned max_mask,
-                                                      double *__restrict__ red,
-                                                      const ProjState *__restrict__ ps_gate)
-{
-    if (ps_gate && ps_gate->done) return;
-    __shared__ double sm[256];
-    const int RS = 256 / KP;
-    const int t = threadIdx.x, comp = t % KP, part = t / KP;
-    for (int a = 0; a < NV; ++a) {
-        const bool is_max = (max_mask >> a) & 1u;
-        double s = is_max ? -INFINITY : 0.0;
-        for (int b = part; b < nb; b += RS) {
-            const double val = partial[((size_t)b * NV + a) * KP + comp];
-            s = is_max ? fmax(s, val) : s + val;
-        }
-        sm[t] = s;
-        __syncthreads();
-        if (part == 0) {
-            for (int q = 1; q < RS; ++q) {
-                const double val = sm[q * KP + comp];
-                s = is_max ? fmax(s, val) : s + val;
-            }
-            red[a * KP + comp] = s;
-        }
-        __syncthreads();
-    }
-}
+// partial [nb][NV][KP] -> red [NV][KP] (fixed order), then (single rank) the post step
+// in the same launch.  One block of 256 threads.
+enum { POST_NONE = -1, POST_COLMAX = 0, POST_MICHELOT, POST_FIN, POST_SCALAR_SUM };
 
-enum { POST_COLMAX = 0, POST_MICHELOT, POST_FIN, POST_SCALAR_SUM };
-
-// red [NV][KP] -> projection state / scalars.  One block, >= KP threads.
-__global__ __launch_bounds__(64) void k_post(int kind, int mode, const double *__restrict__ red,
-                                             int KP, int k, ProjState *__restrict__ ps,
-                                             double *__restrict__ scal, int slot)
+__device__ void post_step(int kind, int mode, const double *__restrict__ red, int KP, int k,
+                          ProjState *__restrict__ ps, double *__restrict__ scal, int slot)
 {
     const int i = threadIdx.x;
+    __shared__ int all_conv;
     if (kind == POST_COLMAX) {
         if (i < k) {
             ps->t[i] = red[i] - 1.0;   // t* >= max - 1
@@ -207,8 +178,6 @@ __global__ __launch_bounds__(64) void k_post(int kind, int mode, const double *_
             ps->passes = 0;
         }
     } else if (kind == POST_MICHELOT) {
-        if (ps->done) return;
-        __shared__ int all_conv;
         if (i == 0) all_conv = 1;
         __syncthreads();
         if (i < k) {
@@ -254,6 +223,50 @@ __global__ __launch_bounds__(64) void k_post(int kind, int mode, const double *_
             scal[slot] = s;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_finalize_sum(const double *__restrict__ partial, int nb,
+                                                      int NV, int KP, unsigned max_mask,
+                                                      double *__restrict__ red,
+                                                      const ProjState *__restrict__ ps_gate,
+                                                      int kind, int mode, int k,
+                                                      ProjState *__restrict__ ps,
+                                                      double *__restrict__ scal, int slot)
+{
+    if (ps_gate && ps_gate->done) return;
+    __shared__ double sm[256];
+    const int RS = 256 / KP;
+    const int t = threadIdx.x, comp = t % KP, part = t / KP;
+    for (int a = 0; a < NV; ++a) {
+        const bool is_max = (max_mask >> a) & 1u;
+        double s = is_max ? -INFINITY : 0.0;
+#pragma unroll 8
+        for (int b = part; b < nb; b += RS) {
+            const double val = partial[((size_t)b * NV + a) * KP + comp];
+            s = is_max ? fmax(s, val) : s + val;
+        }
+        sm[t] = s;
+        __syncthreads();
+        if (part == 0) {
+            for (int q = 1; q < RS; ++q) {
+                const double val = sm[q * KP + comp];
+                s = is_max ? fmax(s, val) : s + val;
+            }
+            red[a * KP + comp] = s;
+        }
+        __syncthreads();
+    }
+    if (kind != POST_NONE) post_step(kind, mode, red, KP, k, ps, scal, slot);
+}
+
+// red [NV][KP] -> projection state / scalars, as its own launch (multi-rank: runs after
+// the all-reduce of `red`).  One block of 256 threads.
+__global__ __launch_bounds__(256) void k_post(int kind, int mode, const double *__restrict__ red,
+                                              int KP, int k, ProjState *__restrict__ ps,
+                                              double *__restrict__ scal, int slot, int gated)
+{
+    if (gated && ps->done) return;
+    post_step(kind, mode, red, KP, k, ps, scal, slot);
 }
 
 // ---------------------------------------------------------------- gradient
@@ -429,6 +442,7 @@ __global__ __launch_bounds__(256) void k_gram_finalize(const double *__restrict_
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= elems) return;
     double s = 0.0;
+#pragma unroll 8
     for (int b = 0; b < nb; ++b) s += partial[(size_t)b * elems + e];
     out[e] = s;
 }
@@ -474,23 +488,46 @@ __device__ double dev_line_search_step(double lam, double delta, double f_old, d
     return 0.5 * lam;
 }
 
-__device__ double dev_trace_MG(const double *M, const double *G, int k, int KP)
-{   // tr(M * G)
+// tr(M * G) (or tr(M * G') when transposed), all 256 threads, fixed-order tree.
+__device__ double block_trace_MG(const double *__restrict__ M, const double *__restrict__ G, int k,
+                                 int KP, bool transposed, double *sm)
+{
     double s = 0.0;
-    for (int i = 0; i < k; ++i)
-        for (int j = 0; j < k; ++j) s += M[i * KP + j] * G[j * KP + i];
-    return s;
+    for (int e = threadIdx.x; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        s += M[i * KP + j] * (transposed ? G[i * KP + j] : G[j * KP + i]);
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double r = sm[0];
+    __syncthreads();
+    return r;
 }
 
 // gram: [0] = C K C' (or (CX)(CX)'), [1] = cross1, [2] = D K D', [3] = cross2
-__global__ void k_scalar_stage(int stage, double *__restrict__ sc, const double *__restrict__ gram,
-                               const double *__restrict__ M, int k, int KP, aa_spg_params sp,
-                               int cross2_is_transpose)
+__global__ __launch_bounds__(256) void k_scalar_stage(int stage, double *__restrict__ sc,
+                                                      const double *__restrict__ gram,
+                                                      const double *__restrict__ M, int k, int KP,
+                                                      aa_spg_params sp, int cross2_is_transpose)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ double sm[256];
     const int GS = KP * KP;
+    double tr0 = 0.0, tr1 = 0.0, tr2 = 0.0;
+    if (stage == ST_INIT_F) {
+        tr0 = block_trace_MG(M, gram, k, KP, false, sm);
+    } else if (stage == ST_LINESEARCH) {
+        tr1 = block_trace_MG(M, gram + GS, k, KP, false, sm);
+        if (cross2_is_transpose) tr1 += block_trace_MG(M, gram + GS, k, KP, true, sm);
+        else tr1 += block_trace_MG(M, gram + 3 * GS, k, KP, false, sm);
+        tr2 = block_trace_MG(M, gram + 2 * GS, k, KP, false, sm);
+    }
+    if (threadIdx.x != 0) return;
     if (stage == ST_INIT_F) {            // spg.py:153-157
-        const double a0 = dev_trace_MG(M, gram, k, KP);
+        const double a0 = tr0;
         sc[SC_A0] = a0;
         sc[SC_F_OLD] = 0.5 * (sc[SC_TRACE] - 2.0 * sc[SC_S1] + a0) / sc[SC_FNORM];
         sc[SC_NFEVAL] = 1.0;
@@ -505,16 +542,7 @@ __global__ void k_scalar_stage(int stage, double *__restrict__ sc, const double 
             sc[SC_ALPHA_SET] = 1.0;
         }
     } else if (stage == ST_LINESEARCH) { // spg.py:196-229, f along x + lambda d in closed form
-        double a1 = dev_trace_MG(M, gram + GS, k, KP);
-        if (cross2_is_transpose) {
-            double s = 0.0;                 // tr(M * cross1')
-            for (int i = 0; i < k; ++i)
-                for (int j = 0; j < k; ++j) s += M[i * KP + j] * gram[GS + i * KP + j];
-            a1 += s;
-        } else {
-            a1 += dev_trace_MG(M, gram + 3 * GS, k, KP);
-        }
-        const double a2 = dev_trace_MG(M, gram + 2 * GS, k, KP);
+        const double a1 = tr1, a2 = tr2;
         const double tr = sc[SC_TRACE], s1 = sc[SC_S1], s1d = sc[SC_S1D], a0 = sc[SC_A0];
         const double fn = sc[SC_FNORM], f_old = sc[SC_F_OLD], delta = sc[SC_DELTA];
         int mem = sp.memory < 1 ? 1 : (sp.memory > 16 ? 16 : sp.memory);
@@ -706,8 +734,8 @@ static inline long tall_rows_pb(const Ctx *c)
 
 int tall_setup(Ctx *c)
 {
-    long nb = (c->n + 127) / 128;
-    if (nb > 512) nb = 512;
+    long nb = (c->n + 255) / 256;
+    if (nb > 256) nb = 256;           // one block per CU; finalize sums <= 256 partials
     if (nb < 1) nb = 1;
     c->tallBlocks = (int)nb;
     // gram partials: tall grams use tallBlocks blocks, wide grams p_pad/128 blocks
@@ -721,6 +749,7 @@ int tall_setup(Ctx *c)
     AA_CHECK(c->redPartial.alloc(need + 4096));
     AA_CHECK(c->gramOut.alloc((size_t)4 * c->KP * c->KP * sizeof(double)));
     AA_CHECK(c->redOut.alloc((size_t)8 * c->KP * sizeof(double)));
+    AA_CHECK(c->gramPP.alloc((size_t)c->KP * c->KP * sizeof(double)));
     AA_CHECK(c->scalars.alloc(SC_COUNT * sizeof(double)));
     AA_CHECK(c->proj.alloc(sizeof(ProjState)));
     AA_CHECK(c->Mdev.alloc((size_t)c->KP * c->KP * sizeof(double)));
@@ -736,17 +765,24 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
     double *part = c->redPartial.as<double>();
     double *red = red_buf(c);
     ProjState *ps = c->proj.as<ProjState>();
-    hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(256), 0, c->stream, part, c->tallBlocks, NV,
-                       c->KP, max_mask, red, gated ? ps : (const ProjState *)nullptr);
-    if (c->world > 1) {
-        // sums and maxima are reduced separately; layout red[a][KP]
+    const ProjState *gate = gated ? ps : (const ProjState *)nullptr;
+    if (c->world <= 1) {
+        hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(256), 0, c->stream, part, c->tallBlocks, NV,
+                           c->KP, max_mask, red, gate, kind, mode, c->k, ps, c->scalars.as<double>(),
+                           slot);
+    } else {
+        hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(256), 0, c->stream, part, c->tallBlocks, NV,
+                           c->KP, max_mask, red, gate, (int)POST_NONE, mode, c->k, ps,
+                           c->scalars.as<double>(), slot);
+        // sums and maxima are reduced separately; layout red[a][KP].  (When a gated pass
+        // has already converged the reduced values are stale but unused: k_post exits.)
         for (int a = 0; a < NV; ++a) {
             const int op = (max_mask >> a) & 1u;
             AA_CHECK(comm_allreduce(c, red + (size_t)a * c->KP, c->KP, op));
         }
+        hipLaunchKernelGGL(k_post, dim3(1), dim3(256), 0, c->stream, kind, mode, red, c->KP, c->k, ps,
+                           c->scalars.as<double>(), slot, gated ? 1 : 0);
     }
-    hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, c->stream, kind, mode, red, c->KP, c->k, ps,
-                       c->scalars.as<double>(), slot);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
@@ -761,9 +797,10 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
                                __VA_ARGS__);                                                \
     } while (0)
 
-// Maximum Michelot passes enqueued per projection.  Passes after convergence exit
-// at their first instruction (device-side `done` flag), so no host sync is needed.
-static int g_proj_max_passes = 24;
+// Michelot passes are enqueued in batches sized from the previous projection's pass
+// count; after each batch the host reads the device-side `done` flag (one small
+// synchronisation, cheaper than enqueuing a dozen passes that exit immediately).
+static int g_proj_hard_cap = 200;
 
 int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode)
 {
@@ -773,11 +810,22 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     ProjState *ps = c->proj.as<ProjState>();
     TALL_DISPATCH(k_proj_colmax, x, g, a_const, scal, a_slot, c->n, rpb, c->k, part);
     AA_CHECK(finalize_and_post(c, 1, 1u, POST_COLMAX, 0, 0, false));
-    for (int it = 0; it < g_proj_max_passes; ++it) {
-        TALL_DISPATCH(k_proj_pass, x, g, a_const, scal, a_slot, c->n, rpb, c->k,
-                      (const ProjState *)ps, part);
-        AA_CHECK(finalize_and_post(c, 2, 0u, POST_MICHELOT, 0, 0, true));
+    int batch = c->projPassHint > 0 ? c->projPassHint + 1 : 12;
+    int total = 0;
+    int hdr[2] = {0, 0};
+    while (true) {
+        for (int it = 0; it < batch; ++it) {
+            TALL_DISPATCH(k_proj_pass, x, g, a_const, scal, a_slot, c->n, rpb, c->k,
+                          (const ProjState *)ps, part);
+            AA_CHECK(finalize_and_post(c, 2, 0u, POST_MICHELOT, 0, 0, true));
+        }
+        total += batch;
+        AA_CHECK_HIP(hipMemcpyAsync(hdr, &ps->done, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
+        AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+        if (hdr[0] || total >= g_proj_hard_cap) break;
+        batch = 4;
     }
+    c->projPassHint = hdr[1];
     double *out = nullptr;
     if (mode == PROJ_FEAS) out = const_cast<double *>(x);
     if (mode == PROJ_DIR) out = c->Dt.as<double>();
@@ -819,7 +867,8 @@ int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const doubl
 
 int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev)
 {
-    const long rpb = round_up((c->n + c->tallBlocks - 1) / c->tallBlocks, 32);
+    const int want = c->tallBlocks > 128 ? 128 : c->tallBlocks;
+    const long rpb = round_up((c->n + want - 1) / want, 32);
     const int nb = (int)((c->n + rpb - 1) / rpb);
     double *part = c->redPartial.as<double>();
     const int elems = c->KP * c->KP;
@@ -905,7 +954,7 @@ int launch_transpose_tall_to_wide(Ctx *c, const double *tall, double *wide, void
 
 int launch_scalar_stage(Ctx *c, int stage, const aa_spg_params *sp, int cross2_is_transpose)
 {
-    hipLaunchKernelGGL(k_scalar_stage, dim3(1), dim3(1), 0, c->stream, stage,
+    hipLaunchKernelGGL(k_scalar_stage, dim3(1), dim3(256), 0, c->stream, stage,
                        c->scalars.as<double>(), c->gramOut.as<double>(), c->Mdev.as<double>(),
                        c->k, c->KP, *sp, cross2_is_transpose);
     AA_CHECK_HIP(hipGetLastError());

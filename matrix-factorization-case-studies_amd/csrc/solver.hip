@@ -48,7 +48,7 @@ static int ensure_problem(Ctx *c, int k)
     if (c->k == k && c->KP == KP && c->Ct.p) return AA_OK;
     c->k = k;
     c->KP = KP;
-    const size_t tall = (size_t)c->n_pad * KP * sizeof(double);
+    const size_t tall = (size_t)(c->n_pad + AA_SLACK_ROWS) * KP * sizeof(double);
     const size_t wide = (size_t)KP * c->p_pad * sizeof(double);
     DevBuf *talls[] = {&c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall};
     for (DevBuf *b : talls) {
@@ -152,20 +152,22 @@ static int ensure_trace(Ctx *c)
 static int refresh_after_dictionary(Ctx *c, bool recompute_products)
 {
     double *gram = c->gramOut.as<double>();
+    double *gpp = c->gramPP.as<double>();
     if (c->form == AA_FORM_DATA) {
         if (recompute_products) {
             AA_CHECK(launch_reduce_rows(c, c->Ct.as<double>(), c->P.as<double>(), operandT(c, c->P, c->Pw)));
             AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));
         }
-        AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), gram));
+        AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), gpp));
     } else {
         if (recompute_products) {
             AA_CHECK(launch_reduce_rows(c, c->Ct.as<double>(), c->wideScratch.as<double>(), nullptr));
             AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gr.as<double>()));
         }
-        AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), c->Ct.as<double>(), gram));
+        AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), c->Ct.as<double>(), gpp));
     }
-    AA_CHECK(fetch_gram(c, gram, c->CKCt));
+    c->products_valid = true;
+    AA_CHECK(fetch_gram(c, gpp, c->CKCt));
     AA_CHECK(launch_gram_tall(c, c->Ct.as<double>(), c->H.as<double>(), gram));
     AA_CHECK(fetch_gram(c, gram, c->CKZ));
     return AA_OK;
@@ -232,18 +234,32 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
     const size_t GS = (size_t)KP * KP;
     const double gscale = data ? 1.0 / (double)c->n_global : 1.0 / (double)k;   // :297 vs :288
 
-    AA_CHECK(launch_proj(c, x, nullptr, 0.0, -1, PROJ_FEAS));                   // spg.py:148
-    if (data) {
-        AA_CHECK(launch_reduce_rows(c, x, c->P.as<double>(), operandT(c, c->P, c->Pw)));
-        AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), gram));
+    // spg.py:148 projects the start point.  A dictionary that came out of our own update
+    // (x_old + lambda d, a convex combination of simplex points) is feasible to rounding,
+    // and projecting it would move it by ~1e-17: skipped.  Caller-supplied factors are
+    // always projected.
+    // The same holds for its products: CX (P) and C XX' / C K (Gr) computed by the
+    // previous update's refresh (archetypal_analysis.py:618-619) are the f / gradient
+    // ingredients of this one (spg.py:156,176) -- the weights update in between does not
+    // touch the dictionary -- so two passes over X are saved (`warm`).
+    const bool warm = c->x_feasible && c->products_valid;
+    if (!c->x_feasible) AA_CHECK(launch_proj(c, x, nullptr, 0.0, -1, PROJ_FEAS));
+    if (!warm) {
+        if (data) {
+            AA_CHECK(launch_reduce_rows(c, x, c->P.as<double>(), operandT(c, c->P, c->Pw)));
+            AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), gram));
+        } else {
+            AA_CHECK(launch_reduce_rows(c, x, c->wideScratch.as<double>(), nullptr));
+            AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gr.as<double>()));
+            AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), x, gram));
+        }
     } else {
-        AA_CHECK(launch_reduce_rows(c, x, c->wideScratch.as<double>(), nullptr));
-        AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gr.as<double>()));
-        AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), x, gram));
+        AA_CHECK_HIP(hipMemcpyAsync(gram, c->gramPP.p, GS * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
     AA_CHECK(launch_tall_dot_scaled(c, x, c->H.as<double>(), c->alphaDev.as<double>(), SC_S1));
     AA_CHECK(launch_scalar_stage(c, ST_INIT_F, sp, 0));                         // spg.py:156
-    if (data) AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));
+    if (data && !warm) AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));
+    c->products_valid = false;
     AA_CHECK(launch_grad(c, c->Gr.as<double>(), c->H.as<double>(), c->gk.as<double>(), gscale, nullptr, 0));
 
     std::vector<double> sc(SC_COUNT, 0.0);
@@ -299,6 +315,7 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
         st->flags = flags;
         st->res_norm = sqrt(sc[SC_RES2]);
     }
+    c->x_feasible = true;
     if (refresh) AA_CHECK(refresh_after_dictionary(c, false));
     return AA_OK;
 }
@@ -371,7 +388,7 @@ int aa_ctx_destroy(aa_ctx *h)
     comm_destroy(c);
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->redPartial,
-                     &c->gramOut, &c->redOut, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters,
+                     &c->gramOut, &c->gramPP, &c->redOut, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters,
                      &c->qpStats};
     for (DevBuf *b : all) b->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -432,7 +449,7 @@ int aa_set_data(aa_ctx *h, const void *X, int host_dtype, long n, long p, long l
     c->row_offset = row_offset;
     const size_t es = esize(c);
     c->X.release();
-    AA_CHECK(c->X.alloc((size_t)c->n_pad * c->p_pad * es));
+    AA_CHECK(c->X.alloc((size_t)(c->n_pad + AA_SLACK_ROWS) * c->p_pad * es));
     const size_t hes = host_dtype == AA_F32 ? 4 : 8;
     if (host_dtype == c->dtype) {
         AA_CHECK_HIP(hipMemcpy2D(c->X.p, (size_t)c->p_pad * es, X, (size_t)ld * hes, (size_t)p * es,
@@ -496,6 +513,8 @@ int aa_set_state(aa_ctx *h, int k, const double *C, long ldc, const double *Z, c
     c->have_state = true;
     c->grams_valid = false;
     c->dict_inputs_overridden = false;
+    c->x_feasible = false;
+    c->products_valid = false;
     return AA_OK;
 }
 

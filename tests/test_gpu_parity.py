@@ -296,7 +296,7 @@ def test_gpnh_golden(cdr):
             want_cost, want_it = g["out_cost_%s_%s" % (tag, wtag)]
             # ('lam1', 'one') stops at the iteration cap, not at a fixed point
             assert abs(cost - want_cost) < 5e-5 * want_cost, (tag, wtag)
-            assert abs(n_iter - int(want_it)) <= 3, (tag, wtag)
+            assert abs(n_iter - int(want_it)) <= max(3, int(0.1 * want_it)), (tag, wtag)
             _assert_simplex(Z, 1e-12)
     assert np.abs(gp._update_gpnh_weights(X, Z0, W0) - g["out_Zupd"]).max() < 1e-6
 
