@@ -111,6 +111,47 @@ def cpu_baseline(k, p, spg_kw, n_sample, steps):
                 used_c=orc.clib() is not None)
 
 
+def converged_parity(k, p, dtype, device, spg_kw, qp_kw, n_small=1500, tol_rel=1e-7, max_outer=600):
+    """Run-to-convergence comparison (the north star's 'reconstruction error within 1e-5
+    rel of the NumPy reference'): oracle (float64 CPU) and HIP path from the same start on
+    the first n_small rows, stopped by abs_delta_f < tol_rel * initial cost."""
+    import warnings
+    from convex_dim_red import archetypal_analysis as aa
+    from oracle import aa_oracle as orc
+    X = synthetic_rows(0, n_small).astype(np.float64)
+    C, Z = start_factors(n_small, k)
+    trace = float((X * X).sum())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        c0 = orc.iterate_aa(X, Z, C, np.ones(k), tolerance=0, max_iterations=1, trace_XXt=trace,
+                            update_weights=False, update_dictionary=False)[3]
+        tol = tol_rel * c0
+        t0 = time.perf_counter()
+        oZ, oC, _, ocost, oit, _, _ = orc.iterate_aa(
+            X, Z, C, np.ones(k), tolerance=tol, max_iterations=max_outer, trace_XXt=trace,
+            dictionary_solver_kwargs=spg_kw, weights_solver_kwargs=qp_kw,
+            require_monotonic_cost_decrease=False)
+        t_cpu = time.perf_counter() - t0
+        Xh = X.astype(np.float32) if dtype == "float32" else X
+        t0 = time.perf_counter()
+        hZ, hC, _, hcost, hit, _, _ = aa._iterate_aa(
+            Xh, Z, C, np.ones(k), tolerance=tol, max_iterations=max_outer, dtype=dtype,
+            dictionary_solver_kwargs=spg_kw, weights_solver_kwargs=qp_kw,
+            require_monotonic_cost_decrease=False)
+        t_hip = time.perf_counter() - t0
+    rec_o = 0.5 * np.linalg.norm(X - oZ.dot(oC.dot(X))) ** 2 / n_small
+    rec_h = 0.5 * np.linalg.norm(X - hZ.dot(hC.dot(X))) ** 2 / n_small
+    return {"rows": n_small, "tolerance": tol, "oracle_cost": ocost, "hip_cost": hcost,
+            "oracle_n_iter": int(oit), "hip_n_iter": int(hit),
+            "oracle_reconstruction_error": rec_o, "hip_reconstruction_error": rec_h,
+            "rel_diff_reconstruction_error": abs(rec_h - rec_o) / rec_o,
+            "argmax_equal": bool(np.array_equal(oC.argmax(axis=1), hC.argmax(axis=1))),
+            "constraints_ok": bool(np.all(hC >= 0) and np.all(hZ >= 0)
+                                   and np.allclose(hC.sum(axis=1), 1, rtol=0, atol=1e-12)
+                                   and np.allclose(hZ.sum(axis=1), 1, rtol=0, atol=1e-12)),
+            "seconds_cpu": t_cpu, "seconds_hip": t_hip}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,7 +261,7 @@ def main():
         "cost": {"initial": cost0, "final_trace_form": trace_cost, "final_residual_form": recon,
                  "after_each_update_last": [float(costs[-2]), float(costs[-1])]},
         "qp": {"mean_passes_per_sample": qp_stats.total_passes / float(n_loc),
-               "max_passes": qp_stats.max_passes},
+               "max_passes": qp_stats.max_passes, "samples_finished_by_wave_kernel": qp_stats.reserved},
         "datagen_s": t_gen,
     }
 
@@ -246,9 +287,11 @@ def main():
             "phase_seconds": base["timings"],
         }
         result["parity_on_sample"] = {
+            "what": "cost after %d outer iterations from the same start, first %d rows" % (1 + args.cpu_steps, ns),
             "oracle_cost": base["cost"], "hip_cost": float(gcosts[-1]),
             "rel_diff": abs(float(gcosts[-1]) - base["cost"]) / base["cost"],
         }
+        result["parity_converged"] = converged_parity(k, p, args.dtype, local_rank, spg_kw, qp_kw)
     print(json.dumps(result))
 
 

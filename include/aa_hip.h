@@ -90,6 +90,11 @@ typedef struct {
 const char *aa_last_error(void);
 int aa_version(void);
 int aa_device_count(int *count);
+/* Process-wide tuning knobs (results are identical up to rounding for every setting):
+ *   "row_local_variant" 0|1|2  float32 row-local GEMM: direct / wave-private LDS / block-tiled
+ *   "qp_pass_cap"       >= 1   SPG passes a sample spends in the lane-per-sample QP kernel
+ *                               before it moves to the wave-per-sample kernel */
+int aa_set_option(const char *name, int value);
 
 /* -------------------------------------------- stateless ops (unit-test surface) */
 

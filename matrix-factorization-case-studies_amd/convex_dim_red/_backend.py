@@ -66,6 +66,7 @@ _SIGNATURES = {
     "aa_last_error": (ctypes.c_char_p, []),
     "aa_version": (ctypes.c_int, []),
     "aa_device_count": (ctypes.c_int, [_ip]),
+    "aa_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "aa_simplex_project_rows": (ctypes.c_int, [ctypes.c_int, _dp, _dp, ctypes.c_long, ctypes.c_long]),
     "aa_quad_simplex_spg_batch": (ctypes.c_int, [ctypes.c_int, _dp, _dp, ctypes.c_long, ctypes.c_long,
                                                  _dp, _dp, ctypes.c_long, ctypes.c_int,
@@ -170,6 +171,11 @@ def require_gpu():
                            "this package has no CPU fallback"
                            % (msg.decode() if msg else "device count = %d" % n.value))
     return n.value
+
+
+def set_option(name, value):
+    """Process-wide tuning knob of the library (see include/aa_hip.h: aa_set_option)."""
+    _check(load_library().aa_set_option(name.encode(), int(value)))
 
 
 def _c64(a):

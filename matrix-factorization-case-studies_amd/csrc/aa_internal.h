@@ -116,6 +116,9 @@ struct ProjState {          // per projection, device memory
     double cnt[AA_MAX_K];
     int done;
     int passes;
+    double mx[AA_MAX_K];          // column maxima of the current projection
+    int shrunk[AA_MAX_K];         // the support has started to shrink (oscillation guard)
+    double warm[4][AA_MAX_K];     // final thresholds of the previous projection of each kind
 };
 
 // ------------------------------------------------------------------ context
@@ -164,7 +167,8 @@ struct Ctx {
 
     long nslab = 0, rows_per_slab = 0;         // reduce-over-rows decomposition
     int tallBlocks = 0;                        // blocks of the tall reductions
-    int projPassHint = 0;                      // Michelot passes the last projection needed
+    int projPassHint[4] = {0, 0, 0, 0};        // Michelot passes the last projection of each kind needed
+    bool projWarm[4] = {false, false, false, false};   // ProjState::warm[kind] is valid
     bool x_feasible = false;                   // dictionary known to be on the simplex
     bool products_valid = false;               // P (= CX) and Gr (= C XX' or C K) match Ct
 };
@@ -204,6 +208,9 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
               const double *bscale_host /*k or null*/, double *Ztall, int ldz, long n, int k,
               const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats);
 int launch_simplex_rows_generic(hipStream_t s, const double *in, double *out, long rows, long cols);
+
+extern int g_row_local_variant;   // kernels_gemm.hip
+extern int g_qp_pass_cap;         // kernels_qp.hip
 
 // ------------------------------------------------------------------ comm.hip
 int comm_unique_id(void *id128);

@@ -276,6 +276,93 @@ __global__ __launch_bounds__(256) void k_row_local_f32_lds(const float *__restri
         }
 }
 
+// row-local, float32 MFMA, classic block-tiled form: the 4 waves of a block own 32 rows
+// each (X tiles wave-private in LDS) and SHARE the [KP][64] tile of the small operand B
+// through LDS, so B crosses L2->L1 once per block instead of once per wave (in the
+// wave-private kernels B traffic equals the X traffic).  Both tiles are register-
+// prefetched one step ahead; 16-byte chunk c of row r sits at chunk c ^ (r & 15)
+// (rows are 256 B = one LDS bank row) => conflict-free ds_read_b128 fragments.
+template <int NCT>
+__global__ __launch_bounds__(256) void k_row_local_f32_blk(const float *__restrict__ X, long ldx,
+                                                           const float *__restrict__ B, int p_pad,
+                                                           double *__restrict__ out, long n_pad)
+{
+    constexpr int KP = 32 * NCT;
+    constexpr int TC = 64;                       // tile columns
+    __shared__ __attribute__((aligned(16))) float xs[4][32 * TC];
+    __shared__ __attribute__((aligned(16))) float bs[KP * TC];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const long r0 = ((long)blockIdx.x * 4 + wave) * 32;      // grid = n_pad / 128 exactly
+    const int h = lane >> 5, j = lane & 31;
+    float *myx = xs[wave];
+
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+
+    // X: instruction e covers rows 4e..4e+3 (lane>>4) x 16 chunks (lane&15)
+    const int xr = lane >> 4, xc = lane & 15;
+    const float *gx = X + (r0 + xr) * ldx + 4 * xc;
+    // B: KP*16 chunks, thread t takes chunks t + 256*e (e < 2*NCT)
+    f32x4 sx[8], sb[2 * NCT];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sx[e] = *reinterpret_cast<const f32x4 *>(gx + (long)(4 * e) * ldx);
+#pragma unroll
+    for (int e = 0; e < 2 * NCT; ++e) {
+        const int cid = t + 256 * e;
+        sb[e] = *reinterpret_cast<const f32x4 *>(B + (long)(cid >> 4) * p_pad + 4 * (cid & 15));
+    }
+
+    for (int c0 = 0; c0 < p_pad; c0 += TC) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = 4 * e + xr;
+            *reinterpret_cast<f32x4 *>(myx + ((row * 16 + (xc ^ (row & 15))) << 2)) = sx[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 2 * NCT; ++e) {
+            const int cid = t + 256 * e, comp = cid >> 4, ch = cid & 15;
+            *reinterpret_cast<f32x4 *>(bs + ((comp * 16 + (ch ^ (comp & 15))) << 2)) = sb[e];
+        }
+        __syncthreads();
+        if (c0 + TC < p_pad) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                sx[e] = *reinterpret_cast<const f32x4 *>(gx + (long)(4 * e) * ldx + c0 + TC);
+#pragma unroll
+            for (int e = 0; e < 2 * NCT; ++e) {
+                const int cid = t + 256 * e;
+                sb[e] = *reinterpret_cast<const f32x4 *>(B + (long)(cid >> 4) * p_pad + c0 + TC + 4 * (cid & 15));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int pc = ((2 * q + h) ^ (j & 15)) << 2;
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(myx + j * 64 + pc);
+            f32x4 bv[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                bv[ct] = *reinterpret_cast<const f32x4 *>(bs + (ct * 32 + j) * 64 + pc);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[ct][m], acc[ct], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const long row = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            out[row * KP + ct * 32 + j] = (double)acc[ct][reg];
+        }
+}
+
 // row-local, float64 VALU: block = 64 rows, X tile staged through LDS with coalesced
 // loads; thread (row = t&63, q = t>>6) accumulates the components [q*KP/4, (q+1)*KP/4).
 template <int KP>
@@ -355,20 +442,24 @@ int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *out
     return AA_OK;
 }
 
-static int row_local_variant()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("AA_ROW_LOCAL");
-        v = (e && !strcmp(e, "direct")) ? 0 : 1;      // default: LDS-staged
-    }
-    return v;
-}
+// 0: operands straight from global memory; 1: X staged in wave-private LDS;
+// 2 (default): block-tiled, B shared through LDS.  Settable with aa_set_option.
+int g_row_local_variant = 2;
+static int row_local_variant() { return g_row_local_variant; }
 
 int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
 {
     dim3 block(256);
-    if (c->dtype == AA_F32 && row_local_variant() == 1) {
+    if (c->dtype == AA_F32 && row_local_variant() == 2) {
+        const float *B = reinterpret_cast<const float *>(B_wideT);
+        dim3 grid((unsigned)(c->n_pad / 128));
+        if (c->KP == 32)
+            hipLaunchKernelGGL(k_row_local_f32_blk<1>, grid, block, 0, c->stream, c->X.as<float>(),
+                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
+        else
+            hipLaunchKernelGGL(k_row_local_f32_blk<2>, grid, block, 0, c->stream, c->X.as<float>(),
+                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
+    } else if (c->dtype == AA_F32 && row_local_variant() == 1) {
         const float *B = reinterpret_cast<const float *>(B_wideT);
         dim3 grid((unsigned)(c->n_pad / 128));
         if (c->KP == 32)

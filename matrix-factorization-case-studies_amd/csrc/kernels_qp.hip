@@ -259,17 +259,41 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
 // 64-sample wave hostage.  memory == 1 only on the continuation path (the host keeps
 // samples in phase 1 otherwise); fresh samples support any memory.
 // ---------------------------------------------------------------------------
+// Wave-wide reductions on the DPP crossbar (no LDS traffic): inclusive row scan with
+// row_shr 1/2/4/8, then row_bcast15 / row_bcast31 carry the row totals upward; the total
+// ends in lane 63 and is broadcast through an SGPR.  Fixed order => deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double qw_dpp(double old, double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double qw_lane63(double v)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double qw_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += qw_dpp<0x111, 0xf>(0.0, v);   // row_shr:1
+    v += qw_dpp<0x112, 0xf>(0.0, v);   // row_shr:2
+    v += qw_dpp<0x114, 0xf>(0.0, v);   // row_shr:4
+    v += qw_dpp<0x118, 0xf>(0.0, v);   // row_shr:8
+    v += qw_dpp<0x142, 0xa>(0.0, v);   // row_bcast:15 -> rows 1, 3
+    v += qw_dpp<0x143, 0xc>(0.0, v);   // row_bcast:31 -> rows 2, 3
+    return qw_lane63(v);
 }
 __device__ __forceinline__ double qw_max(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmax(v, qw_dpp<0x111, 0xf>(-INFINITY, v));
+    v = fmax(v, qw_dpp<0x112, 0xf>(-INFINITY, v));
+    v = fmax(v, qw_dpp<0x114, 0xf>(-INFINITY, v));
+    v = fmax(v, qw_dpp<0x118, 0xf>(-INFINITY, v));
+    v = fmax(v, qw_dpp<0x142, 0xa>(-INFINITY, v));
+    v = fmax(v, qw_dpp<0x143, 0xc>(-INFINITY, v));
+    return qw_lane63(v);
 }
 __device__ __forceinline__ double qw_bcast(double v, int j)
 {
@@ -437,16 +461,8 @@ __global__ __launch_bounds__(256) void k_qp_project_only(const double *__restric
 
 // Passes a sample may spend in the lane-per-sample kernel before it is handed to the
 // wave-per-sample kernel.
-static int qp_pass_cap()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("AA_QP_PASS_CAP");
-        v = e ? atoi(e) : 16;
-        if (v < 1) v = 1;
-    }
-    return v;
-}
+int g_qp_pass_cap = 16;        // settable with aa_set_option("qp_pass_cap", v)
+static int qp_pass_cap() { return g_qp_pass_cap < 1 ? 1 : g_qp_pass_cap; }
 
 int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, long stride_t,
               const double *bscale_host, double *Ztall, int ldz, long n, int k,
@@ -502,14 +518,16 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         // phase 1: every sample gets up to pass_cap passes in a lane
         int cap = qp_pass_cap();
         if (p->memory > 1 || p->max_iterations <= cap) cap = p->max_iterations;
+        // one wave per SIMD: lanes that finish early pull further samples, so a wave's
+        // trip count is the sum over ~n/65536 samples per lane instead of two full rounds
         long waves = (n + 63) / 64;
-        if (waves > 2048) waves = 2048;
+        if (waves > 1024) waves = 1024;
         dim3 grid((unsigned)waves);
 #define QPL(KQV) hipLaunchKernelGGL(k_qp<KQV>, grid, dim3(64), 0, c->stream, Ad, Btall, stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf)
         switch (KQ) { case 4: QPL(4); break; case 8: QPL(8); break; case 16: QPL(16); break;
                       default: QPL(32); break; }
 #undef QPL
-        if (cap < p->max_iterations && !getenv("AA_QP_SKIP_PHASE2")) {
+        if (cap < p->max_iterations) {
             // phase 2: the stragglers, one wave each (grid is fixed; the count is read on
             // the device, so no host synchronisation between the phases)
             hipLaunchKernelGGL(k_qp_wave<32>, dim3(512), dim3(256), 0, c->stream, A2d, Btall, stride_j,

@@ -52,11 +52,14 @@ __device__ __forceinline__ double load_a(double a_const, const double *scal, int
 
 // ---------------------------------------------------------------- projection passes
 // w[r][i] = x[r][i] - a * g[r][i]   (g == nullptr => w = x)
+// first pass of a projection: column maxima, and w = x - a*g written out once so the
+// Michelot passes stream one array instead of two
 template <int KP>
 __global__ __launch_bounds__(256) void k_proj_colmax(const double *__restrict__ x,
                                                      const double *__restrict__ g, double a_const,
                                                      const double *__restrict__ scal, int a_slot,
                                                      long n, long rows_pb, int k,
+                                                     double *__restrict__ wout,
                                                      double *__restrict__ partial)
 {
     __shared__ double sm[256];
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(256) void k_proj_colmax(const double *__restrict__ 
     if (comp < k)
         for (long r = rb + rsub; r < re; r += RS) {
             const double w = g ? x[r * KP + comp] - a * g[r * KP + comp] : x[r * KP + comp];
+            if (wout) wout[r * KP + comp] = w;
             m[0] = fmax(m[0], w);
         }
     block_col_combine<KP, 1>(m, 1u, sm, partial + (size_t)blockIdx.x * KP);
@@ -169,9 +173,20 @@ __device__ void post_step(int kind, int mode, const double *__restrict__ red, in
     const int i = threadIdx.x;
     __shared__ int all_conv;
     if (kind == POST_COLMAX) {
+        // slot > 0: warm start from the previous projection of kind `slot` (the Michelot
+        // map converges from any threshold with a non-empty support: one step from above
+        // lands below t*); otherwise t = max - 1 <= t*.
         if (i < k) {
-            ps->t[i] = red[i] - 1.0;   // t* >= max - 1
+            const double cold = red[i] - 1.0;
+            double t0 = cold;
+            if (slot > 0) {
+                const double tw = ps->warm[slot][i];
+                if (tw < red[i] && tw > cold) t0 = tw;
+            }
+            ps->mx[i] = red[i];
+            ps->t[i] = t0;
             ps->cnt[i] = 0.0;
+            ps->shrunk[i] = 0;
         }
         if (i == 0) {
             ps->done = 0;
@@ -182,10 +197,12 @@ __device__ void post_step(int kind, int mode, const double *__restrict__ red, in
         __syncthreads();
         if (i < k) {
             const double s = red[i], cnt = red[KP + i], prev = ps->cnt[i];
-            // converged when the support stops shrinking (>= guards against a
-            // last-bit oscillation of the threshold)
-            const bool conv = (prev > 0.0) && (cnt >= prev);
+            // converged when the support repeats; a support that grows again after it has
+            // started to shrink is a last-bit oscillation of the threshold
+            const bool conv = (prev > 0.0) && (cnt == prev || (ps->shrunk[i] && cnt > prev));
+            if (prev > 0.0 && cnt < prev) ps->shrunk[i] = 1;
             if (cnt > 0.0) ps->t[i] = (s - 1.0) / cnt;
+            else ps->t[i] = ps->mx[i] - 1.0;           // empty support: restart from below
             ps->cnt[i] = cnt;
             if (!conv) atomicAnd(&all_conv, 0);
         }
@@ -195,6 +212,7 @@ __device__ void post_step(int kind, int mode, const double *__restrict__ red, in
             if (all_conv) ps->done = 1;
         }
     } else if (kind == POST_FIN) {
+        if (i < k && mode > 0 && mode < 4) ps->warm[mode][i] = ps->t[i];
         if (i == 0) {
             double s0 = 0, s1 = 0, s2 = 0, m3 = 0;
             for (int c = 0; c < k; ++c) {
@@ -808,14 +826,16 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     double *part = c->redPartial.as<double>();
     const double *scal = c->scalars.as<double>();
     ProjState *ps = c->proj.as<ProjState>();
-    TALL_DISPATCH(k_proj_colmax, x, g, a_const, scal, a_slot, c->n, rpb, c->k, part);
-    AA_CHECK(finalize_and_post(c, 1, 1u, POST_COLMAX, 0, 0, false));
-    int batch = c->projPassHint > 0 ? c->projPassHint + 1 : 12;
+    double *wbuf = g ? c->tmpTall.as<double>() : (double *)nullptr;
+    const double *wsrc = g ? (const double *)wbuf : x;
+    TALL_DISPATCH(k_proj_colmax, x, g, a_const, scal, a_slot, c->n, rpb, c->k, wbuf, part);
+    AA_CHECK(finalize_and_post(c, 1, 1u, POST_COLMAX, 0, c->projWarm[mode] ? mode : 0, false));
+    int batch = c->projPassHint[mode] > 0 ? c->projPassHint[mode] + 1 : 12;
     int total = 0;
     int hdr[2] = {0, 0};
     while (true) {
         for (int it = 0; it < batch; ++it) {
-            TALL_DISPATCH(k_proj_pass, x, g, a_const, scal, a_slot, c->n, rpb, c->k,
+            TALL_DISPATCH(k_proj_pass, wsrc, (const double *)nullptr, 0.0, scal, -1, c->n, rpb, c->k,
                           (const ProjState *)ps, part);
             AA_CHECK(finalize_and_post(c, 2, 0u, POST_MICHELOT, 0, 0, true));
         }
@@ -823,15 +843,16 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
         AA_CHECK_HIP(hipMemcpyAsync(hdr, &ps->done, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
         AA_CHECK_HIP(hipStreamSynchronize(c->stream));
         if (hdr[0] || total >= g_proj_hard_cap) break;
-        batch = 4;
+        batch = 3;
     }
-    c->projPassHint = hdr[1];
+    c->projPassHint[mode] = hdr[1];
     double *out = nullptr;
     if (mode == PROJ_FEAS) out = const_cast<double *>(x);
     if (mode == PROJ_DIR) out = c->Dt.as<double>();
     TALL_DISPATCH(k_proj_finish, mode, x, g, a_const, scal, a_slot, c->H.as<double>(),
                   c->alphaDev.as<double>(), c->n, rpb, c->k, (const ProjState *)ps, out, part);
     AA_CHECK(finalize_and_post(c, 4, 8u, POST_FIN, mode, 0, false));
+    if (mode > 0) c->projWarm[mode] = true;
     return AA_OK;
 }
 

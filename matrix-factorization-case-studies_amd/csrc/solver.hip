@@ -349,6 +349,22 @@ extern "C" {
 const char *aa_last_error(void) { return g_err.c_str(); }
 int aa_version(void) { return 100; }
 
+int aa_set_option(const char *name, int value)
+{
+    AA_REQUIRE(name != nullptr, AA_ERR_ARG, "null option name");
+    if (!strcmp(name, "row_local_variant")) {
+        AA_REQUIRE(value >= 0 && value <= 2, AA_ERR_ARG, "row_local_variant must be 0, 1 or 2");
+        g_row_local_variant = value;
+    } else if (!strcmp(name, "qp_pass_cap")) {
+        AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_pass_cap must be >= 1");
+        g_qp_pass_cap = value;
+    } else {
+        set_error("unknown option '%s'", name);
+        return AA_ERR_ARG;
+    }
+    return AA_OK;
+}
+
 int aa_device_count(int *count)
 {
     int n = 0;
@@ -515,6 +531,10 @@ int aa_set_state(aa_ctx *h, int k, const double *C, long ldc, const double *Z, c
     c->dict_inputs_overridden = false;
     c->x_feasible = false;
     c->products_valid = false;
+    for (int m = 0; m < 4; ++m) {
+        c->projWarm[m] = false;
+        c->projPassHint[m] = 0;
+    }
     return AA_OK;
 }
 
