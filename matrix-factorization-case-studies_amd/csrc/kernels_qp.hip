@@ -462,6 +462,7 @@ __global__ __launch_bounds__(256) void k_qp_project_only(const double *__restric
 // Passes a sample may spend in the lane-per-sample kernel before it is handed to the
 // wave-per-sample kernel.
 int g_qp_pass_cap = 16;        // settable with aa_set_option("qp_pass_cap", v)
+int g_qp_mode = 0;             // 0: lane-per-sample then wave-per-sample; 1: wave-per-sample only
 static int qp_pass_cap() { return g_qp_pass_cap < 1 ? 1 : g_qp_pass_cap; }
 
 int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, long stride_t,
@@ -472,8 +473,8 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     while (KQ < k) KQ *= 2;
     AA_REQUIRE(KQ <= 64, AA_ERR_ARG, "QP: k = %d > 64 unsupported", k);
     AA_REQUIRE(n < (1L << 31), AA_ERR_ARG, "QP: too many samples");
-    const bool wave_only = KQ > 32;
-    const int KW = wave_only ? 64 : 32;            // A padding of the wave kernel
+    const bool wave_only = KQ > 32 || g_qp_mode == 1;
+    const int KW = KQ > 32 ? 64 : 32;              // A padding of the wave kernel
     // scratch layout: QpHeader | A[KQ*KQ] | A2[KW*KW] | bscale[64] | ovf_rows[n] | ovf[n]
     const size_t off_A = 64;
     const size_t off_A2 = off_A + (size_t)KQ * KQ * sizeof(double);
@@ -511,9 +512,14 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     } else if (wave_only) {
         long blocks = (n + 3) / 4;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_qp_wave<64>, dim3((unsigned)blocks), dim3(256), 0, c->stream, A2d, Btall,
-                           stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr,
-                           (const int *)ovf_rows, (const QpCarry *)ovf);
+        if (KW == 64)
+            hipLaunchKernelGGL(k_qp_wave<64>, dim3((unsigned)blocks), dim3(256), 0, c->stream, A2d, Btall,
+                               stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr,
+                               (const int *)ovf_rows, (const QpCarry *)ovf);
+        else
+            hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)blocks), dim3(256), 0, c->stream, A2d, Btall,
+                               stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr,
+                               (const int *)ovf_rows, (const QpCarry *)ovf);
     } else {
         // phase 1: every sample gets up to pass_cap passes in a lane
         int cap = qp_pass_cap();

@@ -20,6 +20,8 @@
 
 namespace aa {
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------- helpers
 template <int KP, int NV>
 __device__ __forceinline__ void block_col_combine(const double (&v)[NV], unsigned max_mask,
@@ -292,6 +294,10 @@ __global__ __launch_bounds__(256) void k_post(int kind, int mode, const double *
 //   data form:   Graw = (C X X')', H = XX'Z, scale = 1/n   (archetypal_analysis.py:293-301)
 //   kernel form: Graw = (C K)',    H = K Z,  scale = 1/k   (archetypal_analysis.py:284-290)
 // optional: v0 = <d, g>.
+// The k x k product runs on v_mfma_f64_16x16x4_f64: a wave owns 16 rows; A-operand lane l
+// = Graw[r0 + (l&15)][4s + (l>>4)], B-operand = M[16*ti + (l&15)][4s + (l>>4)] (held in
+// registers for the whole kernel); D[row = (l>>4) + 4*reg][col = l&15] is written as four
+// 128-byte row segments per register.
 template <int KP>
 __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
                                               const double *__restrict__ H,
@@ -302,33 +308,60 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
                                               const double *__restrict__ d,
                                               double *__restrict__ partial)
 {
-    constexpr int RS = 256 / KP;
-    __shared__ double Ms[KP][KP + 1];
-    __shared__ double row[RS][KP];
+    constexpr int T = KP / 16;       // component tiles
+    constexpr int S = KP / 4;        // contraction steps
     __shared__ double sm[256];
-    const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
-    for (int e = t; e < KP * KP; e += 256) Ms[e / KP][e % KP] = M[e];
-    const double al = alpha[comp];
-    const long rb = (long)blockIdx.x * rows_pb;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lr = lane >> 4, lc = lane & 15;
+    double mreg[T][S];
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+        for (int s = 0; s < S; ++s) mreg[ti][s] = M[(16 * ti + lc) * KP + 4 * s + lr];
+    double al[T];
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti) al[ti] = alpha[16 * ti + lc];
+    const long rb = (long)blockIdx.x * rows_pb;      // rows_pb is a multiple of 64
     long re = rb + rows_pb;
-    if (re > n) re = n;
-    double v[1] = {0.0};
-    __syncthreads();
-    for (long r0 = rb; r0 < re; r0 += RS) {
-        const long r = r0 + rsub;
-        const bool ok = r < re;
-        row[rsub][comp] = ok ? Graw[r * KP + comp] : 0.0;
-        __syncthreads();
-        if (ok && comp < k) {
-            double s = 0.0;
-            for (int j = 0; j < k; ++j) s = fma(Ms[comp][j], row[rsub][j], s);
-            const double ge = (s - H[r * KP + comp] * al) * scale;
-            gout[r * KP + comp] = ge;
-            if (d) v[0] += d[r * KP + comp] * ge;
-        }
-        __syncthreads();
+    double dot = 0.0;
+    for (long r0 = rb + 16 * wave; r0 < re; r0 += 64) {
+        if (r0 >= n) break;                           // wave-uniform
+        f64x4 acc[T];
+#pragma unroll
+        for (int ti = 0; ti < T; ++ti) acc[ti] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        double gv[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) gv[s] = Graw[(r0 + lc) * KP + 4 * s + lr];   // rows < n_pad
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int ti = 0; ti < T; ++ti)
+                acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(gv[s], mreg[ti][s], acc[ti], 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const long r = r0 + lr + 4 * reg;
+                const int comp = 16 * ti + lc;
+                if (r < n && comp < k) {
+                    const long e = r * KP + comp;
+                    const double ge = (acc[ti][reg] - H[e] * al[ti]) * scale;
+                    gout[e] = ge;
+                    if (d) dot += d[e] * ge;
+                }
+            }
     }
-    if (partial) block_col_combine<KP, 1>(v, 0u, sm, partial + (size_t)blockIdx.x * KP);
+    if (partial) {
+        // fixed-order block sum of the per-thread dot products -> one value per block,
+        // stored in component slot 0 (the finalize step adds the k slots)
+        sm[threadIdx.x] = dot;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x < KP) partial[(size_t)blockIdx.x * KP + threadIdx.x] = threadIdx.x == 0 ? sm[0] : 0.0;
+    }
 }
 
 // v0 = sum x * H * alpha   (tr(C * H D), archetypal_analysis.py:267,279)
@@ -386,39 +419,64 @@ __global__ __launch_bounds__(256) void k_wide_to_T(const double *__restrict__ sr
 
 // ---------------------------------------------------------------- Gram products
 // tall:  out[i][j] = sum_r A[r][i] * B[r][j]      (Z'Z, C (XX'Z), (CK) C')
+// v_mfma_f64_16x16x4_f64 with the contraction over 4 rows per instruction: lane l
+// supplies A[r + (l>>4)][16*ti + (l&15)] and B[r + (l>>4)][16*tj + (l&15)] (four whole
+// 128-byte row segments per load); D[row = (l>>4) + 4*reg][col = l&15].  The 4 waves of
+// a block take interleaved 4-row groups and are combined through LDS in a fixed order.
+// Rows in [n, n_pad) are zero in every tall array, so no row guard is needed.
 template <int KP>
 __global__ __launch_bounds__(256) void k_gram_tall(const double *__restrict__ A,
-                                                   const double *__restrict__ B, long n,
+                                                   const double *__restrict__ B, long n_pad,
                                                    long rows_pb, double *__restrict__ partial)
 {
-    constexpr int JT = KP * KP / 256;          // outputs per thread (4 or 16)
-    constexpr int TPI = KP / JT;               // threads per i
-    __shared__ double As[32][KP + 1], Bs[32][KP + 1];
-    const int t = threadIdx.x, i = t / TPI, j0 = (t % TPI) * JT;
+    constexpr int T = KP / 16;
+    __shared__ double comb[3][KP * KP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lr = lane >> 4, lc = lane & 15;
     const long rb = (long)blockIdx.x * rows_pb;
     long re = rb + rows_pb;
-    if (re > n) re = n;
-    double acc[JT];
+    if (re > n_pad) re = n_pad;
+    f64x4 acc[T][T];
 #pragma unroll
-    for (int q = 0; q < JT; ++q) acc[q] = 0.0;
-    for (long r0 = rb; r0 < re; r0 += 32) {
-        for (int e = t; e < 32 * KP; e += 256) {
-            const long r = r0 + e / KP;
-            const bool ok = r < re;
-            As[e / KP][e % KP] = ok ? A[r * KP + e % KP] : 0.0;
-            Bs[e / KP][e % KP] = ok ? B[r * KP + e % KP] : 0.0;
-        }
-        __syncthreads();
-        for (int rr = 0; rr < 32; ++rr) {
-            const double a = As[rr][i];
+    for (int ti = 0; ti < T; ++ti)
 #pragma unroll
-            for (int q = 0; q < JT; ++q) acc[q] = fma(a, Bs[rr][j0 + q], acc[q]);
+        for (int tj = 0; tj < T; ++tj) acc[ti][tj] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (long r = rb + 4 * wave; r < re; r += 16) {
+        double av[T], bv[T];
+#pragma unroll
+        for (int ti = 0; ti < T; ++ti) {
+            av[ti] = A[(r + lr) * KP + 16 * ti + lc];
+            bv[ti] = B[(r + lr) * KP + 16 * ti + lc];
         }
-        __syncthreads();
+#pragma unroll
+        for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < T; ++tj)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
     }
-    double *dst = partial + (size_t)blockIdx.x * KP * KP;
+    // combine the 4 waves: waves 1..3 park their tiles in LDS, wave 0 adds them in order
+    if (wave > 0) {
 #pragma unroll
-    for (int q = 0; q < JT; ++q) dst[i * KP + j0 + q] = acc[q];
+        for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < T; ++tj)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    comb[wave - 1][(16 * ti + lr + 4 * reg) * KP + 16 * tj + lc] = acc[ti][tj][reg];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double *dst = partial + (size_t)blockIdx.x * KP * KP;
+#pragma unroll
+        for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < T; ++tj)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int e = (16 * ti + lr + 4 * reg) * KP + 16 * tj + lc;
+                    dst[e] = ((acc[ti][tj][reg] + comb[0][e]) + comb[1][e]) + comb[2][e];
+                }
+    }
 }
 
 // wide:  out[i][j] = sum_c A[i][c] * B[j][c]      ((CX)(CX)', (CX)(DX)', (DX)(DX)')
@@ -758,6 +816,7 @@ int tall_setup(Ctx *c)
     c->tallBlocks = (int)nb;
     // gram partials: tall grams use tallBlocks blocks, wide grams p_pad/128 blocks
     long gb = nb > c->p_pad / 128 ? nb : c->p_pad / 128;
+    if (gb < 128) gb = 128;          // tall Grams use up to 128 blocks whatever n is
     size_t need = (size_t)gb * c->KP * c->KP * sizeof(double);
     size_t need2 = (size_t)nb * 4 * c->KP * sizeof(double) + 4 * c->KP * sizeof(double);
     // residual / distance partials: one per 4 rows
@@ -859,7 +918,7 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
 int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, double scale,
                 const double *d_for_dot, int dot_slot)
 {
-    const long rpb = tall_rows_pb(c);
+    const long rpb = round_up((c->n + c->tallBlocks - 1) / c->tallBlocks, 64);
     double *part = c->redPartial.as<double>();
     TALL_DISPATCH(k_grad, Graw, H, c->Mdev.as<double>(), c->alphaDev.as<double>(), scale, c->n,
                   rpb, c->k, gout, d_for_dot, d_for_dot ? part : (double *)nullptr);
@@ -888,15 +947,15 @@ int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const doubl
 
 int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev)
 {
-    const int want = c->tallBlocks > 128 ? 128 : c->tallBlocks;
-    const long rpb = round_up((c->n + want - 1) / want, 32);
-    const int nb = (int)((c->n + rpb - 1) / rpb);
+    const int want = c->KP == 32 ? 64 : 128;
+    long rpb = round_up((c->n_pad + want - 1) / want, 16);
+    const int nb = (int)((c->n_pad + rpb - 1) / rpb);
     double *part = c->redPartial.as<double>();
     const int elems = c->KP * c->KP;
     if (c->KP == 32)
-        hipLaunchKernelGGL(k_gram_tall<32>, dim3(nb), dim3(256), 0, c->stream, A, B, c->n, rpb, part);
+        hipLaunchKernelGGL(k_gram_tall<32>, dim3(nb), dim3(256), 0, c->stream, A, B, c->n_pad, rpb, part);
     else
-        hipLaunchKernelGGL(k_gram_tall<64>, dim3(nb), dim3(256), 0, c->stream, A, B, c->n, rpb, part);
+        hipLaunchKernelGGL(k_gram_tall<64>, dim3(nb), dim3(256), 0, c->stream, A, B, c->n_pad, rpb, part);
     hipLaunchKernelGGL(k_gram_finalize, dim3((elems + 255) / 256), dim3(256), 0, c->stream, part,
                        nb, elems, out_dev);
     AA_CHECK_HIP(hipGetLastError());

@@ -1,0 +1,23 @@
+#!/bin/bash
+# scratch: HBM traffic counters for the two GEMM kernels (separate --pmc passes, as the
+# MI355X guide prescribes; no sys/hip trace domains together with --pmc)
+mkdir -p gpurun_out
+cd /tmp && export TMPDIR=/tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
+  echo "pmc $C exit=$?"
+done
+cd $GRAFT_REPO_ROOT
+python3 - <<'PY'
+import csv, glob, collections
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob("gpurun_out/pmc_%s/**/*counter_collection.csv" % C, recursive=True)
+    agg = collections.defaultdict(list)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == C:
+                agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    print("==", C, "(KB per dispatch; FETCH_SIZE under-reports wide streaming reads by 2x on gfx950)")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:8]:
+        print("%-60s n=%4d mean=%12.1f KB" % (k[-60:], len(v), sum(v) / len(v)))
+PY
