@@ -130,6 +130,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     Comm *comm = nullptr;
     int rank = 0, world = 1;
+    bool force_comm = false;                   // AA_FORCE_RCCL=1: use RCCL even with one rank
 
     // data
     int form = AA_FORM_DATA;

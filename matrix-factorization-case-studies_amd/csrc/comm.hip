@@ -75,7 +75,11 @@ int comm_init(Ctx *c, const void *id128, int rank, int world)
     AA_REQUIRE(world >= 1 && rank >= 0 && rank < world, AA_ERR_ARG, "bad rank/world %d/%d", rank, world);
     c->rank = rank;
     c->world = world;
-    if (world == 1) return AA_OK;
+    // AA_FORCE_RCCL=1: build a 1-rank communicator too (exercises the RCCL path on a
+    // single-GPU box; every all-reduce then really goes through ncclAllReduce)
+    const char *force = getenv("AA_FORCE_RCCL");
+    c->force_comm = force && force[0] == '1';
+    if (world == 1 && !c->force_comm) return AA_OK;
     AA_CHECK(rccl_load());
     ncclUniqueId id;
     memcpy(id.internal, id128, 128);
@@ -96,7 +100,7 @@ void comm_destroy(Ctx *c)
 
 int comm_allreduce(Ctx *c, double *dev, long count, int op)
 {
-    if (c->world <= 1 || !c->comm) return AA_OK;
+    if ((c->world <= 1 && !c->force_comm) || !c->comm) return AA_OK;
     AA_CHECK_NCCL(g_rccl.AllReduce(dev, dev, (size_t)count, kNcclFloat64, op ? kNcclMax : kNcclSum,
                                    c->comm->comm, c->stream));
     return AA_OK;

@@ -413,7 +413,7 @@ int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *out
         else
             hipLaunchKernelGGL(k_reduce_rows_f32<2>, grid, block, 0, c->stream, c->X.as<float>(),
                                c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
-        float *oT = (c->world > 1) ? nullptr : reinterpret_cast<float *>(outT);
+        float *oT = ((c->world > 1 || c->force_comm)) ? nullptr : reinterpret_cast<float *>(outT);
         if (!main_only)
             hipLaunchKernelGGL((k_reduce_partials<float, float>), dim3((unsigned)((elems + 255) / 256)),
                            block, 0, c->stream, part, c->nslab, elems, out_wide, oT);
@@ -426,7 +426,7 @@ int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *out
         else
             hipLaunchKernelGGL(k_reduce_rows_f64<64>, grid, block, 0, c->stream, c->X.as<double>(),
                                c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
-        double *oT = (c->world > 1 || outT == (void *)out_wide) ? nullptr
+        double *oT = ((c->world > 1 || c->force_comm) || outT == (void *)out_wide) ? nullptr
                                                                 : reinterpret_cast<double *>(outT);
         if (!main_only)
             hipLaunchKernelGGL((k_reduce_partials<double, double>),
@@ -435,7 +435,7 @@ int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *out
     }
     AA_CHECK_HIP(hipGetLastError());
     if (main_only) return AA_OK;
-    if (c->world > 1) {
+    if ((c->world > 1 || c->force_comm)) {
         AA_CHECK(comm_allreduce(c, out_wide, elems, 0));
         if (outT && outT != (void *)out_wide) AA_CHECK(launch_wide_to_T(c, out_wide, outT));
     }

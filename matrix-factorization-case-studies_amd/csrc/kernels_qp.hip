@@ -30,23 +30,42 @@ template <int KQ>
 __device__ __forceinline__ double qp_project_threshold(const double (&x)[KQ], const double (&g)[KQ],
                                                        double a, int k)
 {
-    // threshold t of the projection of w = x - a*g (components >= k excluded)
-    double mx = -INFINITY;
+    // threshold t of the projection of w = x - a*g (components >= k excluded).  Sums and
+    // maxima run in NP interleaved chains (combined in a fixed order) so that one lane's
+    // dependent fp64 adds do not serialise the SIMD.
+    constexpr int NP = KQ >= 4 ? 4 : 1;
+    double mxp[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) mxp[q] = -INFINITY;
 #pragma unroll
     for (int i = 0; i < KQ; ++i)
-        if (i < k) mx = fmax(mx, x[i] - a * g[i]);
+        if (i < k) mxp[i % NP] = fmax(mxp[i % NP], x[i] - a * g[i]);
+    double mx = mxp[0];
+#pragma unroll
+    for (int q = 1; q < NP; ++q) mx = fmax(mx, mxp[q]);
     double t = mx - 1.0;
     int prev = 0;
     for (int pass = 0; pass < KQ + 2; ++pass) {
-        double s = 0.0;
-        int c = 0;
+        double sp[NP];
+        int cp[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            sp[q] = 0.0;
+            cp[q] = 0;
+        }
 #pragma unroll
         for (int i = 0; i < KQ; ++i) {
             const double w = x[i] - a * g[i];
-            if (i < k && w > t) {
-                s += w;
-                c += 1;
-            }
+            const bool in = (i < k) && (w > t);
+            sp[i % NP] += in ? w : 0.0;
+            cp[i % NP] += in ? 1 : 0;
+        }
+        double s = sp[0];
+        int c = cp[0];
+#pragma unroll
+        for (int q = 1; q < NP; ++q) {
+            s += sp[q];
+            c += cp[q];
         }
         const double tn = (s - 1.0) / (double)c;
         const bool conv = (prev > 0) && (c >= prev);
@@ -536,7 +555,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         if (cap < p->max_iterations) {
             // phase 2: the stragglers, one wave each (grid is fixed; the count is read on
             // the device, so no host synchronisation between the phases)
-            hipLaunchKernelGGL(k_qp_wave<32>, dim3(512), dim3(256), 0, c->stream, A2d, Btall, stride_j,
+            hipLaunchKernelGGL(k_qp_wave<32>, dim3(1024), dim3(256), 0, c->stream, A2d, Btall, stride_j,
                                stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                (const int *)ovf_rows, (const QpCarry *)ovf);
         }

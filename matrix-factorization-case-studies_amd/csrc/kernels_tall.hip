@@ -843,7 +843,7 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
     double *red = red_buf(c);
     ProjState *ps = c->proj.as<ProjState>();
     const ProjState *gate = gated ? ps : (const ProjState *)nullptr;
-    if (c->world <= 1) {
+    if ((c->world <= 1 && !c->force_comm)) {
         hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(256), 0, c->stream, part, c->tallBlocks, NV,
                            c->KP, max_mask, red, gate, kind, mode, c->k, ps, c->scalars.as<double>(),
                            slot);
@@ -959,7 +959,7 @@ int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev)
     hipLaunchKernelGGL(k_gram_finalize, dim3((elems + 255) / 256), dim3(256), 0, c->stream, part,
                        nb, elems, out_dev);
     AA_CHECK_HIP(hipGetLastError());
-    if (c->world > 1) AA_CHECK(comm_allreduce(c, out_dev, elems, 0));
+    if ((c->world > 1 || c->force_comm)) AA_CHECK(comm_allreduce(c, out_dev, elems, 0));
     return AA_OK;
 }
 
@@ -1063,7 +1063,7 @@ int launch_row_sqnorm_sum(Ctx *c, double *trace_out_host)
     double *out = red_buf(c);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, part, (long)nb, out);
     AA_CHECK_HIP(hipGetLastError());
-    if (c->world > 1) AA_CHECK(comm_allreduce(c, out, 1, 0));
+    if ((c->world > 1 || c->force_comm)) AA_CHECK(comm_allreduce(c, out, 1, 0));
     AA_CHECK_HIP(hipMemcpyAsync(trace_out_host, out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
     return AA_OK;
@@ -1120,7 +1120,7 @@ int launch_residual_cost(Ctx *c, const double *Ztall, const double *Wwide, const
     double *out = c->gramOut.as<double>();
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, part, nb, out);
     AA_CHECK_HIP(hipGetLastError());
-    if (c->world > 1) AA_CHECK(comm_allreduce(c, out, 1, 0));
+    if ((c->world > 1 || c->force_comm)) AA_CHECK(comm_allreduce(c, out, 1, 0));
     AA_CHECK_HIP(hipMemcpyAsync(out_host, out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
     return AA_OK;

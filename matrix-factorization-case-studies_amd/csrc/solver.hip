@@ -427,7 +427,7 @@ int aa_ctx_allreduce_host(aa_ctx *h, double *buf, int count, int op)
 {
     AA_REQUIRE(h && buf && count >= 0, AA_ERR_ARG, "bad arguments");
     Ctx *c = &h->c;
-    if (c->world <= 1 || count == 0) return AA_OK;
+    if ((c->world <= 1 && !c->force_comm) || count == 0) return AA_OK;
     AA_CHECK_HIP(hipSetDevice(c->device));
     DevBuf tmp;
     AA_CHECK(tmp.alloc((size_t)count * sizeof(double)));
@@ -455,7 +455,7 @@ int aa_set_data(aa_ctx *h, const void *X, int host_dtype, long n, long p, long l
     Ctx *c = &h->c;
     AA_CHECK_HIP(hipSetDevice(c->device));
     if (form == AA_FORM_KERNEL)
-        AA_REQUIRE(c->world == 1 && n == p && n_global == n && row_offset == 0, AA_ERR_ARG,
+        AA_REQUIRE((c->world == 1 && !c->force_comm) && n == p && n_global == n && row_offset == 0, AA_ERR_ARG,
                    "kernel form needs a square matrix on a single rank");
     AA_REQUIRE(n_global >= n && row_offset >= 0 && row_offset + n <= n_global, AA_ERR_ARG, "bad shard");
     c->form = form;
@@ -675,7 +675,7 @@ int aa_distance_column(aa_ctx *h, long j, double *d)
             AA_CHECK(c->wideScratch.alloc((size_t)32 * c->p_pad * sizeof(double)));
         const long jl = j - c->row_offset;
         const bool own = jl >= 0 && jl < c->n;
-        if (c->world == 1) {
+        if ((c->world == 1 && !c->force_comm)) {
             AA_CHECK_HIP(hipMemcpyAsync(c->wideScratch.p,
                                         reinterpret_cast<unsigned char *>(c->X.p) + (size_t)jl * c->p_pad * es,
                                         (size_t)c->p_pad * es, hipMemcpyDeviceToDevice, c->stream));

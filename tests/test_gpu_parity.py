@@ -514,3 +514,40 @@ def test_qp_pass_cap_invariance(cdr, orc, cap):
     assert np.abs(got - want).max() < 2e-6
     assert abs(it.mean() - wit.mean()) < 0.05 * wit.mean()
     _assert_simplex(got)
+
+
+def test_rccl_path_single_rank(cdr, orc):
+    """The multi-rank code path (RCCL all-reduce at every splice point: split-row GEMM
+    result, projection passes, Grams, packed scalars, FurthestSum row broadcast) run on one
+    GPU with a 1-rank communicator (AA_FORCE_RCCL=1): identical results to the direct path."""
+    import os
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(17)
+    n, p, k = 900, 260, 6
+    X = rng.standard_normal((n, p)).astype(np.float32)
+    C = orc.right_stochastic_matrix((k, n), rng)
+    Z = orc.right_stochastic_matrix((n, k), rng)
+
+    def run(force):
+        if force:
+            os.environ["AA_FORCE_RCCL"] = "1"
+        try:
+            with _backend.Context(dtype="float32") as ctx:
+                if force:
+                    ctx.comm_init(_backend.comm_unique_id(), 0, 1)
+                ctx.set_data(X)
+                ctx.set_state(C, Z, np.ones(k))
+                c0 = ctx.prepare()
+                costs = ctx.outer_iterations(3, dict(max_iterations=1), {})
+                d = ctx.distance_column(5)
+                Cf, Zf, _ = ctx.get_state()
+                total = ctx.allreduce_host([1.5, 2.5])
+            return c0, costs, d, Cf, Zf, total
+        finally:
+            os.environ.pop("AA_FORCE_RCCL", None)
+
+    a, b = run(False), run(True)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    assert np.allclose(a[2], b[2], rtol=1e-6, atol=1e-6)   # the row travels through float64
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert np.array_equal(b[5], [1.5, 2.5])

@@ -1,56 +1,28 @@
-# scratch: on-GPU tuning sweep (row-local variants, QP pass cap); not part of the product
-import sys, time, json
+# scratch: QP schedule tuning on the benchmark problem
+import sys, time
 sys.path.insert(0, "matrix-factorization-case-studies_amd"); sys.path.insert(0, ".")
 import numpy as np
 import bench
 from convex_dim_red import _backend
 n, p, k = bench.N_SAMPLES, bench.N_FEATURES, bench.N_COMPONENTS
-t = time.time(); X = bench.synthetic_rows(0, n); C0, Z0 = bench.start_factors(n, k)
-print("datagen %.1fs" % (time.time() - t), flush=True)
+X = bench.synthetic_rows(0, n); C0, Z0 = bench.start_factors(n, k)
 ctx = _backend.Context(dtype="float32")
-ctx.set_data(X); ctx.set_state(C0, Z0, np.ones(k)); ctx.prepare()
-ctx.outer_iterations(3, dict(max_iterations=1), {})
-C3, Z3, _ = ctx.get_state()
-print("reduce_rows ms:", ctx.time_kernel(0, 10), flush=True)
-for v in (0, 1, 2):
-    _backend.set_option("row_local_variant", v)
-    print("row_local variant %d ms: %.4f" % (v, ctx.time_kernel(1, 10)), flush=True)
-_backend.set_option("row_local_variant", 2)
-for cap in (8, 12, 16):
-    _backend.set_option("qp_pass_cap", cap)
-    ts = []
-    for rep in range(2):
-        ctx.set_state(C3, Z3, np.ones(k)); ctx.prepare()
-        t = time.perf_counter(); st = ctx.weights_update(); ts.append(time.perf_counter() - t)
-    print("qp cap %4d: weights_update %.3f ms (min of 2)  passes total %d max %d overflow %d"
-          % (cap, 1e3 * min(ts), st.total_passes, st.max_passes, st.reserved), flush=True)
-_backend.set_option("qp_pass_cap", 16)
-_backend.set_option("qp_mode", 1)
-for rep in range(2):
-    ctx.set_state(C3, Z3, np.ones(k)); ctx.prepare()
-    t = time.perf_counter(); st = ctx.weights_update(); dt = time.perf_counter() - t
-    print("qp wave-only: weights_update %.3f ms  passes total %d max %d" % (1e3 * dt, st.total_passes, st.max_passes), flush=True)
-# early state (heavy tail): right after prepare from the random start
-for mode in (0, 1):
-    _backend.set_option("qp_mode", mode)
-    ctx.set_state(C0, Z0, np.ones(k)); ctx.prepare(); ctx.dictionary_update(max_iterations=1)
-    t = time.perf_counter(); st = ctx.weights_update(); dt = time.perf_counter() - t
-    print("[iter 1] qp mode %d: weights_update %.3f ms  passes total %d max %d overflow %d" % (mode, 1e3 * dt, st.total_passes, st.max_passes, st.reserved), flush=True)
-_backend.set_option("qp_mode", 0)
-# later-iteration state (QP work changes as the factors converge)
-ctx.set_state(C3, Z3, np.ones(k)); ctx.prepare(); ctx.outer_iterations(25, dict(max_iterations=1), {})
-C9, Z9, _ = ctx.get_state()
-for cap in (12,):
-    _backend.set_option("qp_pass_cap", cap)
-    ctx.set_state(C9, Z9, np.ones(k)); ctx.prepare()
-    t = time.perf_counter(); st = ctx.weights_update(); dt = time.perf_counter() - t
-    print("[iter 28] qp cap %4d: weights_update %.3f ms  passes total %d max %d overflow %d"
-          % (cap, 1e3 * dt, st.total_passes, st.max_passes, st.reserved), flush=True)
-_backend.set_option("qp_mode", 1)
-ctx.set_state(C9, Z9, np.ones(k)); ctx.prepare()
-t = time.perf_counter(); st = ctx.weights_update(); dt = time.perf_counter() - t
-print("[iter 28] qp wave-only: weights_update %.3f ms  passes total %d max %d" % (1e3 * dt, st.total_passes, st.max_passes), flush=True)
-_backend.set_option("qp_mode", 0)
-t = time.perf_counter(); st = ctx.dictionary_update(max_iterations=1); print("dictionary_update %.3f ms" % (1e3 * (time.perf_counter() - t)))
-t = time.perf_counter(); st = ctx.dictionary_update(max_iterations=1); print("dictionary_update %.3f ms (warm)" % (1e3 * (time.perf_counter() - t)))
+ctx.set_data(X)
+def run(label, n_outer=12, **opts):
+    for key, val in opts.items(): _backend.set_option(key, val)
+    ctx.set_state(C0, Z0, np.ones(k)); ctx.prepare()
+    ctx.outer_iterations(2, dict(max_iterations=1), {})
+    t = time.perf_counter(); costs = ctx.outer_iterations(n_outer, dict(max_iterations=1), {}); dt = time.perf_counter() - t
+    tq = []
+    for _ in range(3):
+        t = time.perf_counter(); st = ctx.weights_update(); tq.append(time.perf_counter() - t)
+    print("%-44s %.3f ms/outer (iters 3-%d); weights_update %.3f ms; final cost %.9f; long+overflow %d max %d"
+          % (label, 1e3 * dt / n_outer, 2 + n_outer, 1e3 * min(tq), costs[-1], st.reserved, st.max_passes), flush=True)
+run("schedule off", qp_schedule=0)
+run("schedule on  long 32 side 64", qp_schedule=1, qp_long_threshold=32, qp_side_blocks=64)
+run("schedule on  long 24 side 64", qp_long_threshold=24)
+run("schedule on  long 48 side 32", qp_long_threshold=48, qp_side_blocks=32)
+run("schedule on  long 32 side 128", qp_long_threshold=32, qp_side_blocks=128)
+run("schedule on  long 32 side 64 cap 12", qp_side_blocks=64, qp_pass_cap=12)
+run("schedule on  long 32 side 64 cap 24", qp_pass_cap=24)
 ctx.close()
