@@ -111,38 +111,33 @@ def cpu_baseline(k, p, spg_kw, n_sample, steps):
                 used_c=orc.clib() is not None)
 
 
-def converged_parity(k, p, dtype, device, spg_kw, qp_kw, n_small=1500, tol_rel=1e-7, max_outer=600):
-    """Run-to-convergence comparison (the north star's 'reconstruction error within 1e-5
-    rel of the NumPy reference'): oracle (float64 CPU) and HIP path from the same start on
-    the first n_small rows, stopped by abs_delta_f < tol_rel * initial cost."""
+def converged_parity(k, p, dtype, device, spg_kw, qp_kw, n_small=1500, n_outer=250):
+    """Near-convergence comparison (the north star's 'reconstruction error within 1e-5 rel
+    of the NumPy reference'): oracle (float64 CPU, reference op sequence) and the HIP path
+    run the SAME fixed number of outer iterations (no stopping test: a |delta cost| rule
+    stops the two runs at different iterations on a flat cost curve) from the same start on
+    the first n_small rows of the workload; the reconstruction errors are then compared in
+    residual form, computed on the host in float64 for both."""
     import warnings
     from convex_dim_red import archetypal_analysis as aa
     from oracle import aa_oracle as orc
     X = synthetic_rows(0, n_small).astype(np.float64)
     C, Z = start_factors(n_small, k)
     trace = float((X * X).sum())
+    kw = dict(tolerance=0, max_iterations=n_outer, dictionary_solver_kwargs=spg_kw,
+              weights_solver_kwargs=qp_kw, require_monotonic_cost_decrease=False)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        c0 = orc.iterate_aa(X, Z, C, np.ones(k), tolerance=0, max_iterations=1, trace_XXt=trace,
-                            update_weights=False, update_dictionary=False)[3]
-        tol = tol_rel * c0
         t0 = time.perf_counter()
-        oZ, oC, _, ocost, oit, _, _ = orc.iterate_aa(
-            X, Z, C, np.ones(k), tolerance=tol, max_iterations=max_outer, trace_XXt=trace,
-            dictionary_solver_kwargs=spg_kw, weights_solver_kwargs=qp_kw,
-            require_monotonic_cost_decrease=False)
+        oZ, oC, _, ocost, oit, _, _ = orc.iterate_aa(X, Z, C, np.ones(k), trace_XXt=trace, **kw)
         t_cpu = time.perf_counter() - t0
         Xh = X.astype(np.float32) if dtype == "float32" else X
         t0 = time.perf_counter()
-        hZ, hC, _, hcost, hit, _, _ = aa._iterate_aa(
-            Xh, Z, C, np.ones(k), tolerance=tol, max_iterations=max_outer, dtype=dtype,
-            dictionary_solver_kwargs=spg_kw, weights_solver_kwargs=qp_kw,
-            require_monotonic_cost_decrease=False)
+        hZ, hC, _, hcost, hit, _, _ = aa._iterate_aa(Xh, Z, C, np.ones(k), dtype=dtype, **kw)
         t_hip = time.perf_counter() - t0
     rec_o = 0.5 * np.linalg.norm(X - oZ.dot(oC.dot(X))) ** 2 / n_small
     rec_h = 0.5 * np.linalg.norm(X - hZ.dot(hC.dot(X))) ** 2 / n_small
-    return {"rows": n_small, "tolerance": tol, "oracle_cost": ocost, "hip_cost": hcost,
-            "oracle_n_iter": int(oit), "hip_n_iter": int(hit),
+    return {"rows": n_small, "outer_iterations": n_outer, "oracle_cost": ocost, "hip_cost": hcost,
             "oracle_reconstruction_error": rec_o, "hip_reconstruction_error": rec_h,
             "rel_diff_reconstruction_error": abs(rec_h - rec_o) / rec_o,
             "argmax_equal": bool(np.array_equal(oC.argmax(axis=1), hC.argmax(axis=1))),
@@ -155,8 +150,8 @@ def converged_parity(k, p, dtype, device, spg_kw, qp_kw, n_small=1500, tol_rel=1
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=N_SAMPLES)
     ap.add_argument("--p", type=int, default=N_FEATURES)
     ap.add_argument("--k", type=int, default=N_COMPONENTS)

@@ -94,6 +94,7 @@ int aa_device_count(int *count);
  *   "row_local_variant" 0|1|2  float32 row-local GEMM: direct / wave-private LDS / block-tiled
  *   "qp_pass_cap"       >= 1   SPG passes a sample spends in the lane-per-sample QP kernel
  *                               before it moves to the wave-per-sample kernel
+ *   "qp_refill_min"     1..64  idle lanes of a wave that trigger pulling new samples
  *   "qp_mode"           0|1    0: lane-per-sample kernel then wave-per-sample kernel;
  *                               1: wave-per-sample kernel for every sample */
 int aa_set_option(const char *name, int value);

@@ -213,6 +213,7 @@ int launch_simplex_rows_generic(hipStream_t s, const double *in, double *out, lo
 extern int g_row_local_variant;   // kernels_gemm.hip
 extern int g_qp_pass_cap;         // kernels_qp.hip
 extern int g_qp_mode;             // kernels_qp.hip
+extern int g_qp_refill_min;       // kernels_qp.hip
 
 // ------------------------------------------------------------------ comm.hip
 int comm_unique_id(void *id128);

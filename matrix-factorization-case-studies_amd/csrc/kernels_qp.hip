@@ -98,18 +98,96 @@ struct QpHeader {
 // column, conflict-free), A transposed as AsT[j][i] so one step reads a contiguous,
 // wave-uniform (broadcast) 8*KQ-byte row.  The j loop is a real loop: its loads depend
 // on j, so the compiler cannot hoist the whole matrix into registers.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned lds_byte_address(const void *p)
+{
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)p;
+}
+
+// Batched LDS reads with ONE wait.  Under the register pressure of this kernel hipcc
+// otherwise re-uses a single VGPR quad for every ds_read_b128 of the mat-vec and waits
+// lgkmcnt(0) after each one (61 % of the wave's cycles parked in s_waitcnt: SQ_WAIT_ANY).
+// Loads and their s_waitcnt sit in one asm statement with early-clobber outputs.
+__device__ __forceinline__ void lds_read_x8(unsigned addr, f64x2 (&q)[8])
+{
+    asm volatile("ds_read_b128 %0, %8\n\t"
+                 "ds_read_b128 %1, %8 offset:16\n\t"
+                 "ds_read_b128 %2, %8 offset:32\n\t"
+                 "ds_read_b128 %3, %8 offset:48\n\t"
+                 "ds_read_b128 %4, %8 offset:64\n\t"
+                 "ds_read_b128 %5, %8 offset:80\n\t"
+                 "ds_read_b128 %6, %8 offset:96\n\t"
+                 "ds_read_b128 %7, %8 offset:112\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]),
+                   "=&v"(q[6]), "=&v"(q[7])
+                 : "v"(addr)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_read_x4(unsigned addr, f64x2 (&q)[4])
+{
+    asm volatile("ds_read_b128 %0, %4\n\t"
+                 "ds_read_b128 %1, %4 offset:16\n\t"
+                 "ds_read_b128 %2, %4 offset:32\n\t"
+                 "ds_read_b128 %3, %4 offset:48\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
+                 : "v"(addr)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_read_x2(unsigned addr, f64x2 (&q)[2])
+{
+    asm volatile("ds_read_b128 %0, %2\n\t"
+                 "ds_read_b128 %1, %2 offset:16\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(q[0]), "=&v"(q[1])
+                 : "v"(addr)
+                 : "memory");
+}
+
+// out = A v for the sample of this lane.  v sits in LDS as vl[j*64] (lane-private
+// column, conflict-free), A transposed as AsT[j][i] so one step reads a contiguous,
+// wave-uniform (broadcast) 8*KQ-byte row.  The j loop is a real loop: its loads depend
+// on j, so the compiler cannot hoist the whole matrix into registers.
 template <int KQ>
 __device__ __forceinline__ void qp_matvec(const double *__restrict__ AsT,
                                           const double *__restrict__ vl, int k, double (&out)[KQ])
 {
 #pragma unroll
     for (int i = 0; i < KQ; ++i) out[i] = 0.0;
-#pragma unroll 2
+    const unsigned a0 = lds_byte_address(AsT);
     for (int j = 0; j < k; ++j) {
         const double vj = vl[j * 64];
-        const double *col = AsT + j * KQ;
+        const unsigned row = a0 + (unsigned)(j * KQ * 8);
+        if constexpr (KQ >= 16) {
 #pragma unroll
-        for (int i = 0; i < KQ; ++i) out[i] = fma(col[i], vj, out[i]);
+            for (int h = 0; h < KQ / 16; ++h) {
+                f64x2 q[8];
+                lds_read_x8(row + h * 128, q);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    out[h * 16 + 2 * i] = fma(q[i][0], vj, out[h * 16 + 2 * i]);
+                    out[h * 16 + 2 * i + 1] = fma(q[i][1], vj, out[h * 16 + 2 * i + 1]);
+                }
+            }
+        } else if constexpr (KQ == 8) {
+            f64x2 q[4];
+            lds_read_x4(row, q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                out[2 * i] = fma(q[i][0], vj, out[2 * i]);
+                out[2 * i + 1] = fma(q[i][1], vj, out[2 * i + 1]);
+            }
+        } else {
+            f64x2 q[2];
+            lds_read_x2(row, q);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                out[2 * i] = fma(q[i][0], vj, out[2 * i]);
+                out[2 * i + 1] = fma(q[i][1], vj, out[2 * i + 1]);
+            }
+        }
     }
 }
 
@@ -120,7 +198,8 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                                            double *__restrict__ Z, int ldz, long n, int k,
                                            aa_qp_params p, int pass_cap, int *__restrict__ iters,
                                            QpHeader *__restrict__ hdr,
-                                           int *__restrict__ ovf_rows, QpCarry *__restrict__ ovf)
+                                           int *__restrict__ ovf_rows, QpCarry *__restrict__ ovf,
+                                           int g_refill)
 {
     __shared__ __attribute__((aligned(16))) double AsT[KQ * KQ];
     __shared__ double vbuf[KQ * 64];
@@ -129,6 +208,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
     double *vl = vbuf + threadIdx.x;
 
     double x[KQ], g[KQ], Ad[KQ];
+    const int refill_min = g_refill;
     double f = 0.0, alpha = 1.0, fmem[QP_MAXMEM];
     int n_iter = 0, n_feval = 0;
     long row = -1;
@@ -137,7 +217,12 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
 
     // the trip bound is a watchdog only (each sample needs <= max_iterations trips)
     for (long trip = 0; trip < (1L << 24); ++trip) {
-        if (!active && !exhausted) {
+        // Refill idle lanes in batches: the start-up of a sample (strided loads, a
+        // projection and a mat-vec) is executed by the whole wave, so it is only entered
+        // when enough lanes are waiting (or nothing else is left to do).
+        const int n_idle = __popcll(__ballot(!active && !exhausted));
+        const bool refill = n_idle >= refill_min || !__any(active);
+        if (refill && !active && !exhausted) {
             const unsigned int nxt = atomicAdd(&hdr->next_row, 1u);
             if ((long)nxt < n) {
                 row = (long)nxt;
@@ -321,21 +406,26 @@ __device__ __forceinline__ double qw_bcast(double v, int j)
     hi = __builtin_amdgcn_readlane(hi, j);
     return __hiloint2double(hi, lo);
 }
-// threshold of the projection of the wave-distributed vector w (w = -inf on idle lanes)
+// threshold of the projection of the wave-distributed vector w (w = -inf on idle lanes).
+// The Michelot passes compare w*|S| > sum_S - 1 instead of w > (sum_S - 1)/|S|: no fp64
+// division (a ~300-cycle dependent sequence) on the critical path of a pass; the
+// threshold itself is formed once, by the same closed form (sum_S - 1)/|S|.
 __device__ __forceinline__ double qw_threshold(double w, int k)
 {
-    double t = qw_max(w) - 1.0;
+    const double t0 = qw_max(w) - 1.0;
+    bool in = w > t0;
     int prev = 0;
+    double s = 0.0;
+    int c = 1;
     for (int pass = 0; pass < k + 2; ++pass) {
-        const bool in = w > t;
-        const int c = __popcll(__ballot(in));
-        const double s = qw_sum(in ? w : 0.0);
+        c = __popcll(__ballot(in));
+        s = qw_sum(in ? w : 0.0);
         const bool conv = (prev > 0) && (c >= prev);
-        t = (s - 1.0) / (double)c;
         prev = c;
         if (conv) break;
+        in = w * (double)c > s - 1.0;
     }
-    return t;
+    return (s - 1.0) / (double)c;
 }
 
 template <int KQ>
@@ -375,10 +465,13 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             const double t0 = qw_threshold(live ? x : -INFINITY, k);
             x = live ? fmax(x - t0, 0.0) : 0.0;
         }
-        double g = 0.0;
+        double g = 0.0, g1 = 0.0;
 #pragma unroll
-        for (int j = 0; j < KQ; ++j) g = fma(Arow[j], qw_bcast(x, j), g);
-        g += b;
+        for (int j = 0; j < KQ; j += 2) {
+            g = fma(Arow[j], qw_bcast(x, j), g);
+            g1 = fma(Arow[j + 1], qw_bcast(x, j + 1), g1);
+        }
+        g = (g + g1) + b;
         if (fresh) {
             f = 0.5 * (qw_sum(x * g) + qw_sum(x * b));
             n_iter = 0;
@@ -407,9 +500,13 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             const double d = live ? fmax(x - alpha * g - td, 0.0) - x : 0.0;
             const double delta = qw_sum(d * g);
             const double dd = qw_sum(d * d);
-            double Ad = 0.0;
+            double Ad = 0.0, Ad1 = 0.0;
 #pragma unroll
-            for (int j = 0; j < KQ; ++j) Ad = fma(Arow[j], qw_bcast(d, j), Ad);
+            for (int j = 0; j < KQ; j += 2) {
+                Ad = fma(Arow[j], qw_bcast(d, j), Ad);
+                Ad1 = fma(Arow[j + 1], qw_bcast(d, j + 1), Ad1);
+            }
+            Ad += Ad1;
             const double dAd = qw_sum(d * Ad);
 
 #pragma unroll
@@ -480,7 +577,8 @@ __global__ __launch_bounds__(256) void k_qp_project_only(const double *__restric
 
 // Passes a sample may spend in the lane-per-sample kernel before it is handed to the
 // wave-per-sample kernel.
-int g_qp_pass_cap = 16;        // settable with aa_set_option("qp_pass_cap", v)
+int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
+int g_qp_refill_min = 24;      // idle lanes of a wave that trigger a refill (1..64)
 int g_qp_mode = 0;             // 0: lane-per-sample then wave-per-sample; 1: wave-per-sample only
 static int qp_pass_cap() { return g_qp_pass_cap < 1 ? 1 : g_qp_pass_cap; }
 
@@ -548,7 +646,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         long waves = (n + 63) / 64;
         if (waves > 1024) waves = 1024;
         dim3 grid((unsigned)waves);
-#define QPL(KQV) hipLaunchKernelGGL(k_qp<KQV>, grid, dim3(64), 0, c->stream, Ad, Btall, stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf)
+#define QPL(KQV) hipLaunchKernelGGL(k_qp<KQV>, grid, dim3(64), 0, c->stream, Ad, Btall, stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf, g_qp_refill_min)
         switch (KQ) { case 4: QPL(4); break; case 8: QPL(8); break; case 16: QPL(16); break;
                       default: QPL(32); break; }
 #undef QPL

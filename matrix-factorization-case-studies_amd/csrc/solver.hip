@@ -358,6 +358,9 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "qp_pass_cap")) {
         AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_pass_cap must be >= 1");
         g_qp_pass_cap = value;
+    } else if (!strcmp(name, "qp_refill_min")) {
+        AA_REQUIRE(value >= 1 && value <= 64, AA_ERR_ARG, "qp_refill_min must be in 1..64");
+        g_qp_refill_min = value;
     } else if (!strcmp(name, "qp_mode")) {
         AA_REQUIRE(value == 0 || value == 1, AA_ERR_ARG, "qp_mode must be 0 or 1");
         g_qp_mode = value;

@@ -510,7 +510,7 @@ def test_qp_pass_cap_invariance(cdr, orc, cap):
     try:
         got, it = _backend.qp_batch(A, B, Z0, "kn", return_iters=True)
     finally:
-        _backend.set_option("qp_pass_cap", 16)
+        _backend.set_option("qp_pass_cap", 24)
     assert np.abs(got - want).max() < 2e-6
     assert abs(it.mean() - wit.mean()) < 0.05 * wit.mean()
     _assert_simplex(got)

@@ -5,7 +5,7 @@ TAG=${1:-x}
 timeout -k 10 700 python -m pytest tests/test_gpu_parity.py -q -m gpu --timeout 300 -p no:cacheprovider > gpurun_out/t_$TAG.log 2>&1
 rc=$?; echo "pytest exit=$rc" >> gpurun_out/t_$TAG.log; tail -4 gpurun_out/t_$TAG.log
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pytest timed out; stopping"; exit 1; fi
-timeout -k 10 500 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+timeout -k 10 500 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 rc=$?; echo "bench exit=$rc"
 if [ $rc -ne 0 ]; then tail -20 gpurun_out/bench_$TAG.err; exit 1; fi
 cat gpurun_out/bench_$TAG.json

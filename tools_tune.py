@@ -1,6 +1,6 @@
-# scratch: QP schedule tuning on the benchmark problem
-import sys, time
-sys.path.insert(0, "matrix-factorization-case-studies_amd"); sys.path.insert(0, ".")
+# scratch: QP knob tuning on the benchmark problem
+import sys, time, os
+_R = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, os.path.join(_R, "matrix-factorization-case-studies_amd")); sys.path.insert(0, _R)
 import numpy as np
 import bench
 from convex_dim_red import _backend
@@ -8,21 +8,24 @@ n, p, k = bench.N_SAMPLES, bench.N_FEATURES, bench.N_COMPONENTS
 X = bench.synthetic_rows(0, n); C0, Z0 = bench.start_factors(n, k)
 ctx = _backend.Context(dtype="float32")
 ctx.set_data(X)
-def run(label, n_outer=12, **opts):
+ctx.set_state(C0, Z0, np.ones(k)); ctx.prepare()
+ctx.outer_iterations(8, dict(max_iterations=1), {})
+C8, Z8, _ = ctx.get_state()
+def run(label, **opts):
     for key, val in opts.items(): _backend.set_option(key, val)
-    ctx.set_state(C0, Z0, np.ones(k)); ctx.prepare()
-    ctx.outer_iterations(2, dict(max_iterations=1), {})
-    t = time.perf_counter(); costs = ctx.outer_iterations(n_outer, dict(max_iterations=1), {}); dt = time.perf_counter() - t
-    tq = []
-    for _ in range(3):
-        t = time.perf_counter(); st = ctx.weights_update(); tq.append(time.perf_counter() - t)
-    print("%-44s %.3f ms/outer (iters 3-%d); weights_update %.3f ms; final cost %.9f; long+overflow %d max %d"
-          % (label, 1e3 * dt / n_outer, 2 + n_outer, 1e3 * min(tq), costs[-1], st.reserved, st.max_passes), flush=True)
-run("schedule off", qp_schedule=0)
-run("schedule on  long 32 side 64", qp_schedule=1, qp_long_threshold=32, qp_side_blocks=64)
-run("schedule on  long 24 side 64", qp_long_threshold=24)
-run("schedule on  long 48 side 32", qp_long_threshold=48, qp_side_blocks=32)
-run("schedule on  long 32 side 128", qp_long_threshold=32, qp_side_blocks=128)
-run("schedule on  long 32 side 64 cap 12", qp_side_blocks=64, qp_pass_cap=12)
-run("schedule on  long 32 side 64 cap 24", qp_pass_cap=24)
+    ts = []; mx = []
+    ctx.set_state(C8, Z8, np.ones(k)); ctx.prepare()
+    for it in range(6):
+        ctx.dictionary_update(max_iterations=1)
+        t = time.perf_counter(); st = ctx.weights_update(); ts.append(time.perf_counter() - t); mx.append(st.max_passes)
+    print("%-40s weights_update ms: %s  max passes %s overflow(last) %d" % (label, " ".join("%.2f" % (1e3 * t) for t in ts), mx, st.reserved), flush=True)
+run("cap 16 refill 16")
+run("cap 16 refill 1", qp_refill_min=1)
+run("cap 16 refill 32", qp_refill_min=32)
+run("cap 16 refill 48", qp_refill_min=48)
+run("cap 24 refill 16", qp_refill_min=16, qp_pass_cap=24)
+run("cap 32 refill 16", qp_pass_cap=32)
+run("cap 48 refill 16", qp_pass_cap=48)
+run("cap 32 refill 32", qp_pass_cap=32, qp_refill_min=32)
+run("cap 12 refill 16", qp_pass_cap=12, qp_refill_min=16)
 ctx.close()
