@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const TP *__restrict__ 
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= elems) return;
     double s = 0.0;
+#pragma unroll 16
     for (long sl = 0; sl < nslab; ++sl) s += (double)partial[sl * elems + idx];
     out[idx] = s;
     if (outT) outT[idx] = (TO)s;

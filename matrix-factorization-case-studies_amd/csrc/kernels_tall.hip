@@ -441,18 +441,26 @@ __global__ __launch_bounds__(256) void k_gram_tall(const double *__restrict__ A,
     for (int ti = 0; ti < T; ++ti)
 #pragma unroll
         for (int tj = 0; tj < T; ++tj) acc[ti][tj] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    for (long r = rb + 4 * wave; r < re; r += 16) {
-        double av[T], bv[T];
+    // 4 row groups (64 block-rows) per step: 8*T loads in flight before the first MFMA
+    constexpr int UG = 4;
+    for (long r = rb + 4 * wave; r < re; r += 16 * UG) {
+        double av[UG][T], bv[UG][T];
 #pragma unroll
-        for (int ti = 0; ti < T; ++ti) {
-            av[ti] = A[(r + lr) * KP + 16 * ti + lc];
-            bv[ti] = B[(r + lr) * KP + 16 * ti + lc];
+        for (int u = 0; u < UG; ++u) {
+            const long rr = r + 16 * u + lr;           // < n_pad + AA_SLACK_ROWS (zero rows)
+#pragma unroll
+            for (int ti = 0; ti < T; ++ti) {
+                av[u][ti] = A[rr * KP + 16 * ti + lc];
+                bv[u][ti] = B[rr * KP + 16 * ti + lc];
+            }
         }
 #pragma unroll
-        for (int ti = 0; ti < T; ++ti)
+        for (int u = 0; u < UG; ++u)
 #pragma unroll
-            for (int tj = 0; tj < T; ++tj)
-                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
+            for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < T; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][ti], bv[u][tj], acc[ti][tj], 0, 0, 0);
     }
     // combine the 4 waves: waves 1..3 park their tiles in LDS, wave 0 adds them in order
     if (wave > 0) {
@@ -948,7 +956,7 @@ int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const doubl
 int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev)
 {
     const int want = c->KP == 32 ? 64 : 128;
-    long rpb = round_up((c->n_pad + want - 1) / want, 16);
+    long rpb = round_up((c->n_pad + want - 1) / want, 64);     // 4 row groups per step
     const int nb = (int)((c->n_pad + rpb - 1) / rpb);
     double *part = c->redPartial.as<double>();
     const int elems = c->KP * c->KP;

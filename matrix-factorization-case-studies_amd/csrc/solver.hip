@@ -68,7 +68,7 @@ static int ensure_problem(Ctx *c, int k)
     }
     // split-row decomposition of the reduce-over-rows GEMM
     const long colgroups = c->dtype == AA_F32 ? (c->p_pad + 511) / 512 : (c->p_pad + 255) / 256;
-    long nslab = (1024 + colgroups - 1) / colgroups;
+    long nslab = (512 + colgroups - 1) / colgroups;     // ~2 blocks per CU; 64 slabs at p = 4096
     if (nslab > 128) nslab = 128;
     if (nslab < 1) nslab = 1;
     long rps = round_up((c->n_pad + nslab - 1) / nslab, 16);
