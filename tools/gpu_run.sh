@@ -1,5 +1,5 @@
 #!/bin/bash
-# scratch helper for gpurun calls (not part of the product): tests, bench, rocprof
+# helper for gpurun calls (run from the repo root): tests, bench, rocprofv3 kernel stats
 mkdir -p gpurun_out
 TAG=${1:-x}
 timeout -k 10 700 python -m pytest tests/test_gpu_parity.py -q -m gpu --timeout 300 -p no:cacheprovider > gpurun_out/t_$TAG.log 2>&1

@@ -1,6 +1,6 @@
 # scratch: QP knob tuning on the benchmark problem
 import sys, time, os
-_R = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, os.path.join(_R, "matrix-factorization-case-studies_amd")); sys.path.insert(0, _R)
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(_R, "matrix-factorization-case-studies_amd")); sys.path.insert(0, _R)
 import numpy as np
 import bench
 from convex_dim_red import _backend
