@@ -221,6 +221,21 @@ def main():
     if rank != 0:
         return
 
+    # HBM traffic of the two pass kernels from the PMC counters (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate passes, tools/gpu_pmc.sh; FETCH_SIZE doubled as the MI355X guide
+    # prescribes for 16-B/lane streaming reads on gfx950).  Counters cannot be read from
+    # inside this process, so the last committed measurement of the same configuration is
+    # reported (profiles/pmc_traffic.json) -- null when there is none for this shape.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if (pmc.get("n"), pmc.get("p"), pmc.get("k"), pmc.get("n_gpus")) == (n, p, k, world) \
+                and pmc.get("dtype") == args.dtype:
+            traffic = 0.5 * (pmc["reduce_rows_bytes"] + pmc["row_local_bytes"])
+    except (OSError, ValueError, KeyError):
+        pass
+
     es = 4 if args.dtype == "float32" else 8
     n_loc = hi - lo
     bytes_pass = float(n_loc) * p * es                     # algorithmic bytes of one pass over X
@@ -247,7 +262,7 @@ def main():
                                % (n, p, k, world),
                    "parallelism": "rows/%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "k_reduce_rows_f32 / k_row_local_f32 (mean of the two pass kernels)",
                      "ms_reduce_rows": ms_reduce, "ms_row_local": ms_local,
                      "bytes_per_launch": bytes_pass, "flops_per_launch": flops_pass,

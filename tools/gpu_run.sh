@@ -2,7 +2,7 @@
 # helper for gpurun calls (run from the repo root): tests, bench, rocprofv3 kernel stats
 mkdir -p gpurun_out
 TAG=${1:-x}
-timeout -k 10 700 python -m pytest tests/test_gpu_parity.py -q -m gpu --timeout 300 -p no:cacheprovider > gpurun_out/t_$TAG.log 2>&1
+timeout -k 10 700 python -m pytest tests -q -m gpu --timeout 300 -p no:cacheprovider > gpurun_out/t_$TAG.log 2>&1
 rc=$?; echo "pytest exit=$rc" >> gpurun_out/t_$TAG.log; tail -4 gpurun_out/t_$TAG.log
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pytest timed out; stopping"; exit 1; fi
 timeout -k 10 500 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
