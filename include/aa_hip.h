@@ -91,10 +91,19 @@ const char *aa_last_error(void);
 int aa_version(void);
 int aa_device_count(int *count);
 /* Process-wide tuning knobs (results are identical up to rounding for every setting):
- *   "row_local_variant" 0|1|2  float32 row-local GEMM: direct / wave-private LDS / block-tiled
+ *   "row_local_variant" -1..8  float32 row-local GEMM: -1 (default) chosen by size (8 for
+ *                               >= 32768 rows per GPU, else 4), 0 direct, 1 wave-private LDS, 2..7
+ *                               block-tiled (2: 64-column tiles, 3: 64 double-buffered,
+ *                               4: 128, 5: 32 double-buffered, 6: 128 double-buffered, 7: 32),
+ *                               8 wave-streaming (wave-private X tiles, shared B slabs)
+ *   "row_local_waves"   0..16  waves per block of variant 8 (0: one block per CU)
+ *   "proj_mode"         0|1    column simplex projection: 0 candidate lists (single rank),
+ *                               1 iterative full passes (always used with > 1 rank)
  *   "qp_pass_cap"       >= 1   SPG passes a sample spends in the lane-per-sample QP kernel
  *                               before it moves to the wave-per-sample kernel
  *   "qp_refill_min"     1..64  idle lanes of a wave that trigger pulling new samples
+ *   "qp_waves"          >= 1   most waves (64 samples each) the lane-per-sample kernel runs
+ *                               at once; samples beyond that are pulled in as lanes free up
  *   "qp_mode"           0|1    0: lane-per-sample kernel then wave-per-sample kernel;
  *                               1: wave-per-sample kernel for every sample */
 int aa_set_option(const char *name, int value);

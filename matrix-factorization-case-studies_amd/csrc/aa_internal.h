@@ -160,6 +160,7 @@ struct Ctx {
     DevBuf redOut;                             // finalized [NV][KP] reduction results
     DevBuf scalars;                            // SC_COUNT doubles
     DevBuf proj;                               // ProjState
+    DevBuf projList, projSegCnt;               // candidate lists of the column projection
     DevBuf Mdev, alphaDev;                     // KP*KP, KP
     DevBuf qpIters;                            // n ints
     DevBuf qpStats;                            // 2 long long
@@ -210,10 +211,13 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
               const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats);
 int launch_simplex_rows_generic(hipStream_t s, const double *in, double *out, long rows, long cols);
 
+extern int g_proj_mode;           // kernels_tall.hip
 extern int g_row_local_variant;   // kernels_gemm.hip
+extern int g_row_local_waves;     // kernels_gemm.hip
 extern int g_qp_pass_cap;         // kernels_qp.hip
 extern int g_qp_mode;             // kernels_qp.hip
 extern int g_qp_refill_min;       // kernels_qp.hip
+extern int g_qp_waves;            // kernels_qp.hip
 
 // ------------------------------------------------------------------ comm.hip
 int comm_unique_id(void *id128);

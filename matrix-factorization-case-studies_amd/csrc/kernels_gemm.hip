@@ -278,24 +278,36 @@ __global__ __launch_bounds__(256) void k_row_local_f32_lds(const float *__restri
 }
 
 // row-local, float32 MFMA, classic block-tiled form: the 4 waves of a block own 32 rows
-// each (X tiles wave-private in LDS) and SHARE the [KP][64] tile of the small operand B
+// each (X tiles wave-private in LDS) and SHARE the [KP][TC] tile of the small operand B
 // through LDS, so B crosses L2->L1 once per block instead of once per wave (in the
 // wave-private kernels B traffic equals the X traffic).  Both tiles are register-
-// prefetched one step ahead; 16-byte chunk c of row r sits at chunk c ^ (r & 15)
-// (rows are 256 B = one LDS bank row) => conflict-free ds_read_b128 fragments.
-template <int NCT>
+// prefetched one step ahead.  TC = tile columns (32/64/128); DB = double-buffered LDS
+// (one barrier per tile instead of two).  16-byte chunk c of row r sits at a swizzled
+// chunk so that the 16 lanes of a ds_read_b128 group (16 rows, same logical chunk) hit 16
+// different bank groups: c ^ (r & 15) for rows >= 256 B, c ^ ((r >> 1) & 7) for 128-B rows.
+template <int TC>
+__device__ __forceinline__ int rl_phys_chunk(int row, int chunk)
+{
+    if constexpr (TC >= 64) return chunk ^ (row & 15);
+    else return chunk ^ ((row >> 1) & 7);
+}
+
+template <int NCT, int TC, bool DB>
 __global__ __launch_bounds__(256) void k_row_local_f32_blk(const float *__restrict__ X, long ldx,
                                                            const float *__restrict__ B, int p_pad,
                                                            double *__restrict__ out, long n_pad)
 {
     constexpr int KP = 32 * NCT;
-    constexpr int TC = 64;                       // tile columns
-    __shared__ __attribute__((aligned(16))) float xs[4][32 * TC];
-    __shared__ __attribute__((aligned(16))) float bs[KP * TC];
+    constexpr int CPR = TC / 4;                  // 16-byte chunks per tile row
+    constexpr int RPI = 64 / CPR;                // tile rows covered by one wave-instruction
+    constexpr int NXI = 32 / RPI;                // X load instructions per wave per tile
+    constexpr int NBI = KP * CPR / 256;          // B load instructions per thread per tile
+    constexpr int NBUF = DB ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float xs[NBUF][4][32 * TC];
+    __shared__ __attribute__((aligned(16))) float bs[NBUF][KP * TC];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const long r0 = ((long)blockIdx.x * 4 + wave) * 32;      // grid = n_pad / 128 exactly
     const int h = lane >> 5, j = lane & 31;
-    float *myx = xs[wave];
 
     f32x16 acc[NCT];
 #pragma unroll
@@ -303,57 +315,73 @@ __global__ __launch_bounds__(256) void k_row_local_f32_blk(const float *__restri
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
 
-    // X: instruction e covers rows 4e..4e+3 (lane>>4) x 16 chunks (lane&15)
-    const int xr = lane >> 4, xc = lane & 15;
+    const int xr = lane / CPR, xc = lane % CPR;
     const float *gx = X + (r0 + xr) * ldx + 4 * xc;
-    // B: KP*16 chunks, thread t takes chunks t + 256*e (e < 2*NCT)
-    f32x4 sx[8], sb[2 * NCT];
+    f32x4 sx[NXI], sb[NBI];
+    auto load_tile = [&](int c0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sx[e] = *reinterpret_cast<const f32x4 *>(gx + (long)(4 * e) * ldx);
+        for (int e = 0; e < NXI; ++e)
+            sx[e] = *reinterpret_cast<const f32x4 *>(gx + (long)(RPI * e) * ldx + c0);
 #pragma unroll
-    for (int e = 0; e < 2 * NCT; ++e) {
-        const int cid = t + 256 * e;
-        sb[e] = *reinterpret_cast<const f32x4 *>(B + (long)(cid >> 4) * p_pad + 4 * (cid & 15));
-    }
-
-    for (int c0 = 0; c0 < p_pad; c0 += TC) {
+        for (int e = 0; e < NBI; ++e) {
+            const int cid = t + 256 * e;
+            sb[e] = *reinterpret_cast<const f32x4 *>(B + (long)(cid / CPR) * p_pad + c0 + 4 * (cid % CPR));
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float *myx = xs[buf][wave];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int row = 4 * e + xr;
-            *reinterpret_cast<f32x4 *>(myx + ((row * 16 + (xc ^ (row & 15))) << 2)) = sx[e];
+        for (int e = 0; e < NXI; ++e) {
+            const int row = RPI * e + xr;
+            *reinterpret_cast<f32x4 *>(myx + ((row * CPR + rl_phys_chunk<TC>(row, xc)) << 2)) = sx[e];
         }
 #pragma unroll
-        for (int e = 0; e < 2 * NCT; ++e) {
-            const int cid = t + 256 * e, comp = cid >> 4, ch = cid & 15;
-            *reinterpret_cast<f32x4 *>(bs + ((comp * 16 + (ch ^ (comp & 15))) << 2)) = sb[e];
+        for (int e = 0; e < NBI; ++e) {
+            const int cid = t + 256 * e, comp = cid / CPR, ch = cid % CPR;
+            *reinterpret_cast<f32x4 *>(bs[buf] + ((comp * CPR + rl_phys_chunk<TC>(comp, ch)) << 2)) = sb[e];
         }
-        __syncthreads();
-        if (c0 + TC < p_pad) {
+    };
+    auto compute_tile = [&](int buf) {
+        const float *myx = xs[buf][wave];
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                sx[e] = *reinterpret_cast<const f32x4 *>(gx + (long)(4 * e) * ldx + c0 + TC);
-#pragma unroll
-            for (int e = 0; e < 2 * NCT; ++e) {
-                const int cid = t + 256 * e;
-                sb[e] = *reinterpret_cast<const f32x4 *>(B + (long)(cid >> 4) * p_pad + c0 + TC + 4 * (cid & 15));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int pc = ((2 * q + h) ^ (j & 15)) << 2;
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(myx + j * 64 + pc);
+        for (int q = 0; q < TC / 8; ++q) {
+            const int pc = rl_phys_chunk<TC>(j, 2 * q + h) << 2;
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(myx + j * TC + pc);
             f32x4 bv[NCT];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
-                bv[ct] = *reinterpret_cast<const f32x4 *>(bs + (ct * 32 + j) * 64 + pc);
+                bv[ct] = *reinterpret_cast<const f32x4 *>(bs[buf] + (ct * 32 + j) * TC + pc);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct)
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[ct][m], acc[ct], 0, 0, 0);
         }
+    };
+
+    load_tile(0);
+    if constexpr (DB) {
+        store_tile(0);
         __syncthreads();
+        int buf = 0;
+        for (int c0 = 0; c0 < p_pad; c0 += TC) {
+            const bool more = c0 + TC < p_pad;
+            if (more) load_tile(c0 + TC);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(buf);
+            if (more) store_tile(buf ^ 1);     // last read two barriers ago
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else {
+        for (int c0 = 0; c0 < p_pad; c0 += TC) {
+            store_tile(0);
+            __syncthreads();
+            if (c0 + TC < p_pad) load_tile(c0 + TC);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(0);
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
@@ -362,6 +390,128 @@ __global__ __launch_bounds__(256) void k_row_local_f32_blk(const float *__restri
             const long row = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
             out[row * KP + ct * 32 + j] = (double)acc[ct][reg];
         }
+}
+
+// row-local, float32 MFMA, "wave-streaming" form.  The block-tiled kernel above spends
+// its time at block barriers (two per 64..128 columns), so HBM time and MFMA time add up
+// instead of overlapping.  Here a block is W waves on one CU; every wave owns one 32-row
+// tile for the whole kernel and streams its X through a WAVE-PRIVATE LDS tile (coalesced
+// 256-byte row segments in, MFMA fragment layout out; only s_waitcnt, no barrier), one
+// tile register-prefetched ahead.  The small operand B is shared by the whole block as
+// double-buffered 128-column slabs in LDS: one barrier per 128 columns, B crosses
+// L2->LDS once per W*32 rows.  Dynamic LDS = 2 slabs (KP*512 B each) + W * 8 KB.
+template <int NCT>
+__global__ __launch_bounds__(NCT == 1 ? 1024 : 768) void k_row_local_f32_ws(const float *__restrict__ X, long ldx,
+                                                           const float *__restrict__ B, int p_pad,
+                                                           double *__restrict__ out, long n_pad,
+                                                           int W)
+{
+    constexpr int KP = 32 * NCT;
+    constexpr int SB = 128, TC = 64;
+    constexpr int NBI = 2 * NCT;                 // B chunks per thread per slab at >= 512 threads
+    extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, nthreads = blockDim.x;
+    float *bs = ws_smem;
+    float *xs = ws_smem + 2 * KP * SB + wave * (32 * TC);
+    const long r0 = ((long)blockIdx.x * W + wave) * 32;
+    const bool active = r0 < n_pad;              // wave-uniform
+    // surplus waves of the last block recompute the last tile (no branches in the loop)
+    const long r0c = active ? r0 : n_pad - 32;
+    const int h = lane >> 5, j = lane & 31;
+
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+
+    f32x4 sb[NBI], sx[8];
+    auto load_b = [&](int c0) {
+#pragma unroll
+        for (int e = 0; e < NBI; ++e) {
+            const int cid = (t + e * nthreads) & (KP * 32 - 1);   // >= 512 threads: wraps only
+            sb[e] = *reinterpret_cast<const f32x4 *>(B + (long)(cid >> 5) * p_pad + c0 + 4 * (cid & 31));
+        }                                                          // onto identical data
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < NBI; ++e) {
+            const int cid = (t + e * nthreads) & (KP * 32 - 1);
+            const int comp = cid >> 5, ch = cid & 31;
+            *reinterpret_cast<f32x4 *>(bs + buf * (KP * SB) + ((comp * 32 + (ch ^ (comp & 15))) << 2)) = sb[e];
+        }
+    };
+    const int xr = lane >> 4, xc = lane & 15;
+    const float *gx = X + (r0c + xr) * ldx + 4 * xc;
+    auto load_x = [&](int c0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            sx[e] = *reinterpret_cast<const f32x4 *>(gx + (long)(4 * e) * ldx + c0);
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = 4 * e + xr;
+            *reinterpret_cast<f32x4 *>(xs + ((row * 16 + (xc ^ (row & 15))) << 2)) = sx[e];
+        }
+    };
+    auto compute = [&](int buf, int half) {
+        const float *bb = bs + buf * (KP * SB);
+        f32x4 a, bv[NCT], an, bn[NCT];
+        auto frag = [&](int q, f32x4 &fa, f32x4 (&fb)[NCT]) {
+            const int pcx = ((2 * q + h) ^ (j & 15)) << 2;
+            const int pcb = ((half * 16 + 2 * q + h) ^ (j & 15)) << 2;
+            fa = *reinterpret_cast<const f32x4 *>(xs + j * TC + pcx);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                fb[ct] = *reinterpret_cast<const f32x4 *>(bb + (ct * 32 + j) * SB + pcb);
+        };
+        frag(0, a, bv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q + 1 < 8) frag(q + 1, an, bn);     // fragments of the next step in flight
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[ct][m], acc[ct], 0, 0, 0);
+            a = an;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) bv[ct] = bn[ct];
+        }
+    };
+
+    const int nslab = p_pad / SB;
+    load_b(0);
+    load_x(0);
+    store_b(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int c0 = s * SB;
+        const int snext = s + 1 < nslab ? s + 1 : s;       // last slab: harmless reload
+        store_x();                                // wave-private: LDS is in order per wave
+        load_x(c0 + TC);
+        load_b(snext * SB);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(s & 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        store_x();
+        store_b((s + 1) & 1);                     // that buffer was last read before the previous barrier
+        load_x(snext * SB);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(s & 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    if (active) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long row = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                out[row * KP + ct * 32 + j] = (double)acc[ct][reg];
+            }
+    }
 }
 
 // row-local, float64 VALU: block = 64 rows, X tile staged through LDS with coalesced
@@ -444,23 +594,69 @@ int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *out
 }
 
 // 0: operands straight from global memory; 1: X staged in wave-private LDS;
-// 2 (default): block-tiled, B shared through LDS.  Settable with aa_set_option.
-int g_row_local_variant = 2;
-static int row_local_variant() { return g_row_local_variant; }
+// >= 2: block-tiled, B shared through LDS: 2 = 64-column tiles, 3 = 64 double-buffered,
+// 4 (default) = 128, 5 = 32 double-buffered, 6 = 128 double-buffered, 7 = 32;
+// 8: wave-streaming (wave-private X tiles, B slabs shared per block).  aa_set_option.
+int g_row_local_variant = -1;   // -1: by size (8 when there are >= 8 tiles per CU-block, else 4)
+int g_row_local_waves = 0;     // variant 8: waves per block (0 = one block per CU)
+static int row_local_variant(const Ctx *c)
+{
+    if (g_row_local_variant >= 0) return g_row_local_variant;
+    return c->n_pad / 32 >= 8 * 128 ? 8 : 4;
+}
 
 int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
 {
     dim3 block(256);
-    if (c->dtype == AA_F32 && row_local_variant() == 2) {
+    if (c->dtype == AA_F32 && row_local_variant(c) == 8) {
+        // wave-streaming kernel: W waves per block, one block per CU where possible
+        const float *B = reinterpret_cast<const float *>(B_wideT);
+        const int nct = c->KP / 32;
+        const long tiles = c->n_pad / 32;
+        const int wmax = nct == 1 ? 16 : 12;              // 160 KB of LDS
+        int W = g_row_local_waves > 0 ? g_row_local_waves : (int)((tiles + 255) / 256);
+        if (W < 8) W = 8;                                 // the B slab loader assumes >= 512 threads
+        if (W > wmax) W = wmax;
+        const size_t lds = ((size_t)2 * c->KP * 128 + (size_t)W * 32 * 64) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_local_f32_ws<1>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_local_f32_ws<2>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        dim3 grid((unsigned)((tiles + W - 1) / W)), blk((unsigned)(64 * W));
+        if (nct == 1)
+            hipLaunchKernelGGL(k_row_local_f32_ws<1>, grid, blk, lds, c->stream, c->X.as<float>(),
+                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W);
+        else
+            hipLaunchKernelGGL(k_row_local_f32_ws<2>, grid, blk, lds, c->stream, c->X.as<float>(),
+                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W);
+    } else if (c->dtype == AA_F32 && row_local_variant(c) >= 2) {
         const float *B = reinterpret_cast<const float *>(B_wideT);
         dim3 grid((unsigned)(c->n_pad / 128));
-        if (c->KP == 32)
-            hipLaunchKernelGGL(k_row_local_f32_blk<1>, grid, block, 0, c->stream, c->X.as<float>(),
-                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
-        else
-            hipLaunchKernelGGL(k_row_local_f32_blk<2>, grid, block, 0, c->stream, c->X.as<float>(),
-                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
-    } else if (c->dtype == AA_F32 && row_local_variant() == 1) {
+#define RLB(NCTV, TCV, DBV)                                                                   \
+    hipLaunchKernelGGL((k_row_local_f32_blk<NCTV, TCV, DBV>), grid, block, 0, c->stream,       \
+                       c->X.as<float>(), c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad)
+        const int v = row_local_variant(c);
+        if (c->KP == 32) {
+            switch (v) {
+                case 3: RLB(1, 64, true); break;
+                case 4: RLB(1, 128, false); break;
+                case 5: RLB(1, 32, true); break;
+                case 6: RLB(1, 128, true); break;
+                case 7: RLB(1, 32, false); break;
+                default: RLB(1, 64, false); break;
+            }
+        } else {
+            switch (v) {
+                case 3: case 5: case 6: RLB(2, 64, true); break;
+                default: RLB(2, 64, false); break;
+            }
+        }
+#undef RLB
+    } else if (c->dtype == AA_F32 && row_local_variant(c) == 1) {
         const float *B = reinterpret_cast<const float *>(B_wideT);
         dim3 grid((unsigned)(c->n_pad / 128));
         if (c->KP == 32)

@@ -580,6 +580,7 @@ __global__ __launch_bounds__(256) void k_qp_project_only(const double *__restric
 int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
 int g_qp_refill_min = 24;      // idle lanes of a wave that trigger a refill (1..64)
 int g_qp_mode = 0;             // 0: lane-per-sample then wave-per-sample; 1: wave-per-sample only
+int g_qp_waves = 1024;         // most waves the lane-per-sample kernel is launched with
 static int qp_pass_cap() { return g_qp_pass_cap < 1 ? 1 : g_qp_pass_cap; }
 
 int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, long stride_t,
@@ -644,7 +645,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         // one wave per SIMD: lanes that finish early pull further samples, so a wave's
         // trip count is the sum over ~n/65536 samples per lane instead of two full rounds
         long waves = (n + 63) / 64;
-        if (waves > 1024) waves = 1024;
+        if (waves > g_qp_waves) waves = g_qp_waves;
         dim3 grid((unsigned)waves);
 #define QPL(KQV) hipLaunchKernelGGL(k_qp<KQV>, grid, dim3(64), 0, c->stream, Ad, Btall, stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf, g_qp_refill_min)
         switch (KQ) { case 4: QPL(4); break; case 8: QPL(8); break; case 16: QPL(16); break;

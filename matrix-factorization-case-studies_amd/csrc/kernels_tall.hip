@@ -164,10 +164,173 @@ __global__ __launch_bounds__(256) void k_proj_finish(int mode, const double *__r
     block_col_combine<KP, 4>(v, 8u, sm, partial + (size_t)blockIdx.x * 4 * KP);
 }
 
+// ---------------------------------------------------------------- candidate-list projection
+// Single-rank fast path.  Every Michelot iterate from ANY threshold with a non-empty
+// support is a Newton step on the convex, decreasing phi(t) = sum max(w - t, 0) - 1 and
+// therefore a lower bound of the root t*.  So after ONE pass (column maxima plus the
+// Newton step from the previous projection's threshold, fused) the candidates
+// {w > t_lower} contain the support; they are copied once into per-thread segments (no
+// atomics, fixed order => deterministic) and one block per column finishes the fixed point
+// on that short list.  3 passes over the array + 1 tiny kernel, no host synchronisation,
+// instead of 2 + (Michelot passes) full passes with a host check.
+//
+// first pass: w = x - a*g (written once), v0 = max w, v1/v2 = sum / count of {w > warm t}
+template <int KP>
+__global__ __launch_bounds__(256) void k_proj_first(const double *__restrict__ x,
+                                                    const double *__restrict__ g, double a_const,
+                                                    const double *__restrict__ scal, int a_slot,
+                                                    long n, long rows_pb, int k, int warm_slot,
+                                                    const ProjState *__restrict__ ps,
+                                                    double *__restrict__ wout,
+                                                    double *__restrict__ partial)
+{
+    __shared__ double sm[3 * 256];
+    constexpr int RS = 256 / KP;
+    const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
+    const double a = load_a(a_const, scal, a_slot);
+    const long rb = (long)blockIdx.x * rows_pb;
+    long re = rb + rows_pb;
+    if (re > n) re = n;
+    double v[3] = {-INFINITY, 0.0, 0.0};
+    if (comp < k) {
+        const double th = warm_slot > 0 ? ps->warm[warm_slot][comp] : INFINITY;
+        for (long r = rb + rsub; r < re; r += RS) {
+            const double w = g ? x[r * KP + comp] - a * g[r * KP + comp] : x[r * KP + comp];
+            if (wout) wout[r * KP + comp] = w;
+            v[0] = fmax(v[0], w);
+            if (w > th) {
+                v[1] += w;
+                v[2] += 1.0;
+            }
+        }
+    }
+    block_col_combine<KP, 3>(v, 1u, sm, partial + (size_t)blockIdx.x * 3 * KP);
+}
+
+// candidates {w > t_lower}: thread (rsub, comp) of block b appends its own rows, in row
+// order, to segment (comp, b*RS + rsub) of `list` ([KP][nseg][segcap]); counts in segcnt
+template <int KP>
+__global__ __launch_bounds__(256) void k_proj_collect(const double *__restrict__ w, long n,
+                                                      long rows_pb, int k,
+                                                      const ProjState *__restrict__ ps,
+                                                      double *__restrict__ list,
+                                                      int *__restrict__ segcnt)
+{
+    constexpr int RS = 256 / KP;
+    const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
+    if (comp >= k) return;
+    const long rb = (long)blockIdx.x * rows_pb;
+    long re = rb + rows_pb;
+    if (re > n) re = n;
+    const long segcap = rows_pb / RS;
+    const long nseg = (long)gridDim.x * RS;
+    const long seg = (long)blockIdx.x * RS + rsub;
+    double *dst = list + ((long)comp * nseg + seg) * segcap;
+    const double th = ps->t[comp];
+    int cnt = 0;
+    for (long r = rb + rsub; r < re; r += RS) {
+        const double v = w[r * KP + comp];
+        if (v > th) dst[cnt++] = v;
+    }
+    segcnt[(long)comp * nseg + seg] = cnt;
+}
+
+// one block per column: Michelot's fixed point on the candidate list, started from the
+// lower bound.  Lists of <= PROJ_LDS_CAP candidates are gathered into LDS first.
+#define PROJ_LDS_CAP 2048
+__global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ list,
+                                                    const int *__restrict__ segcnt, long nseg,
+                                                    long segcap, ProjState *__restrict__ ps)
+{
+    __shared__ double u[PROJ_LDS_CAP];
+    __shared__ double rs[256];
+    __shared__ int rm[256];
+    __shared__ int scan[256];
+    const int comp = blockIdx.x, t = threadIdx.x;
+    const int spt = (int)((nseg + 255) / 256);          // consecutive segments per thread
+    const long s0 = (long)t * spt;
+    const int *mycnt = segcnt + (long)comp * nseg;
+    const double *mylist = list + (long)comp * nseg * segcap;
+
+    int mine = 0;
+    for (int q = 0; q < spt; ++q)
+        if (s0 + q < nseg) mine += mycnt[s0 + q];
+    scan[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {            // inclusive Hillis-Steele scan
+        const int add = t >= off ? scan[t - off] : 0;
+        __syncthreads();
+        scan[t] += add;
+        __syncthreads();
+    }
+    const int total = scan[255];
+    const bool in_lds = total <= PROJ_LDS_CAP;
+    if (in_lds) {
+        int pos = scan[t] - mine;
+        for (int q = 0; q < spt; ++q)
+            if (s0 + q < nseg) {
+                const int c = mycnt[s0 + q];
+                const double *src = mylist + (s0 + q) * segcap;
+                for (int i = 0; i < c; ++i) u[pos++] = src[i];
+            }
+    }
+    __syncthreads();
+
+    double th = ps->t[comp];
+    int prev = -1, conv = 0;
+    if (total == 0) {
+        conv = 1;                                        // cannot happen (max w > t_lower)
+    } else {
+        for (int it = 0; it < 200 && !conv; ++it) {
+            double s = 0.0;
+            int m = 0;
+            if (in_lds) {
+                for (int i = t; i < total; i += 256) {
+                    const double v = u[i];
+                    if (v > th) { s += v; m += 1; }
+                }
+            } else {
+                for (int q = 0; q < spt; ++q)
+                    if (s0 + q < nseg) {
+                        const int c = mycnt[s0 + q];
+                        const double *src = mylist + (s0 + q) * segcap;
+                        for (int i = 0; i < c; ++i) {
+                            const double v = src[i];
+                            if (v > th) { s += v; m += 1; }
+                        }
+                    }
+            }
+            rs[t] = s;
+            rm[t] = m;
+            __syncthreads();
+            for (int off = 128; off > 0; off >>= 1) {    // fixed tree => deterministic
+                if (t < off) {
+                    rs[t] += rs[t + off];
+                    rm[t] += rm[t + off];
+                }
+                __syncthreads();
+            }
+            const double S = rs[0];
+            const int M = rm[0];
+            __syncthreads();
+            // supports shrink monotonically from a lower bound; a repeat (or a last-bit
+            // regrowth) is the fixed point
+            if (M == prev || (prev > 0 && M > prev) || M == 0) conv = 1;
+            if (M > 0 && M != prev) th = (S - 1.0) / (double)M;
+            if (M > 0) prev = M;
+        }
+    }
+    if (t == 0) {
+        ps->t[comp] = th;
+        ps->cnt[comp] = (double)prev;
+        ps->shrunk[comp] = conv;                         // list mode: "column converged"
+    }
+}
+
 // ---------------------------------------------------------------- finalize
 // partial [nb][NV][KP] -> red [NV][KP] (fixed order), then (single rank) the post step
 // in the same launch.  One block of 256 threads.
-enum { POST_NONE = -1, POST_COLMAX = 0, POST_MICHELOT, POST_FIN, POST_SCALAR_SUM };
+enum { POST_NONE = -1, POST_COLMAX = 0, POST_MICHELOT, POST_FIN, POST_SCALAR_SUM, POST_FIRST };
 
 __device__ void post_step(int kind, int mode, const double *__restrict__ red, int KP, int k,
                           ProjState *__restrict__ ps, double *__restrict__ scal, int slot)
@@ -194,6 +357,25 @@ __device__ void post_step(int kind, int mode, const double *__restrict__ red, in
             ps->done = 0;
             ps->passes = 0;
         }
+    } else if (kind == POST_FIRST) {
+        // red = [max | sum of {w > warm t} | count]: lower bound of t* = the larger of
+        // max - 1 and the Newton step from the warm threshold
+        if (i < k) {
+            const double cold = red[i] - 1.0, cnt = red[2 * KP + i];
+            double t0 = cold;
+            if (cnt > 0.0) {
+                const double t1 = (red[KP + i] - 1.0) / cnt;
+                if (t1 > cold && t1 < red[i]) t0 = t1;
+            }
+            ps->mx[i] = red[i];
+            ps->t[i] = t0;
+            ps->cnt[i] = 0.0;
+            ps->shrunk[i] = 0;
+        }
+        if (i == 0) {
+            ps->done = 0;
+            ps->passes = -1;                  // list mode: POST_FIN derives `done`
+        }
     } else if (kind == POST_MICHELOT) {
         if (i == 0) all_conv = 1;
         __syncthreads();
@@ -216,6 +398,11 @@ __device__ void post_step(int kind, int mode, const double *__restrict__ red, in
     } else if (kind == POST_FIN) {
         if (i < k && mode > 0 && mode < 4) ps->warm[mode][i] = ps->t[i];
         if (i == 0) {
+            if (ps->passes < 0) {
+                int all = 1;
+                for (int c = 0; c < k; ++c) all &= ps->shrunk[c];
+                ps->done = all;
+            }
             double s0 = 0, s1 = 0, s2 = 0, m3 = 0;
             for (int c = 0; c < k; ++c) {
                 s0 += red[c];
@@ -837,6 +1024,11 @@ int tall_setup(Ctx *c)
     AA_CHECK(c->gramPP.alloc((size_t)c->KP * c->KP * sizeof(double)));
     AA_CHECK(c->scalars.alloc(SC_COUNT * sizeof(double)));
     AA_CHECK(c->proj.alloc(sizeof(ProjState)));
+    {   // candidate lists of the projection: [KP][tallBlocks * RS][rows_pb / RS]
+        const long rpb = tall_rows_pb(c);
+        AA_CHECK(c->projList.alloc((size_t)c->KP * c->tallBlocks * rpb * sizeof(double)));
+        AA_CHECK(c->projSegCnt.alloc((size_t)c->KP * c->tallBlocks * (256 / c->KP) * sizeof(int)));
+    }
     AA_CHECK(c->Mdev.alloc((size_t)c->KP * c->KP * sizeof(double)));
     AA_CHECK(c->alphaDev.alloc((size_t)c->KP * sizeof(double)));
     return AA_OK;
@@ -861,9 +1053,13 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
                            c->scalars.as<double>(), slot);
         // sums and maxima are reduced separately; layout red[a][KP].  (When a gated pass
         // has already converged the reduced values are stale but unused: k_post exits.)
-        for (int a = 0; a < NV; ++a) {
+        // one all-reduce per run of consecutive values with the same operation
+        for (int a = 0; a < NV;) {
             const int op = (max_mask >> a) & 1u;
-            AA_CHECK(comm_allreduce(c, red + (size_t)a * c->KP, c->KP, op));
+            int b = a + 1;
+            while (b < NV && (int)((max_mask >> b) & 1u) == op) ++b;
+            AA_CHECK(comm_allreduce(c, red + (size_t)a * c->KP, (long)(b - a) * c->KP, op));
+            a = b;
         }
         hipLaunchKernelGGL(k_post, dim3(1), dim3(256), 0, c->stream, kind, mode, red, c->KP, c->k, ps,
                            c->scalars.as<double>(), slot, gated ? 1 : 0);
@@ -887,6 +1083,8 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
 // synchronisation, cheaper than enqueuing a dozen passes that exit immediately).
 static int g_proj_hard_cap = 200;
 
+int g_proj_mode = 0;   // 0: candidate lists (single rank), 1: iterative full passes
+
 int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode)
 {
     const long rpb = tall_rows_pb(c);
@@ -895,24 +1093,38 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     ProjState *ps = c->proj.as<ProjState>();
     double *wbuf = g ? c->tmpTall.as<double>() : (double *)nullptr;
     const double *wsrc = g ? (const double *)wbuf : x;
-    TALL_DISPATCH(k_proj_colmax, x, g, a_const, scal, a_slot, c->n, rpb, c->k, wbuf, part);
-    AA_CHECK(finalize_and_post(c, 1, 1u, POST_COLMAX, 0, c->projWarm[mode] ? mode : 0, false));
-    int batch = c->projPassHint[mode] > 0 ? c->projPassHint[mode] + 1 : 12;
-    int total = 0;
-    int hdr[2] = {0, 0};
-    while (true) {
-        for (int it = 0; it < batch; ++it) {
-            TALL_DISPATCH(k_proj_pass, wsrc, (const double *)nullptr, 0.0, scal, -1, c->n, rpb, c->k,
-                          (const ProjState *)ps, part);
-            AA_CHECK(finalize_and_post(c, 2, 0u, POST_MICHELOT, 0, 0, true));
+    const bool lists = g_proj_mode == 0 && c->world <= 1 && !c->force_comm;
+    if (lists) {
+        const int RS = 256 / c->KP;
+        const long nseg = (long)c->tallBlocks * RS, segcap = rpb / RS;
+        TALL_DISPATCH(k_proj_first, x, g, a_const, scal, a_slot, c->n, rpb, c->k,
+                      c->projWarm[mode] ? mode : 0, (const ProjState *)ps, wbuf, part);
+        AA_CHECK(finalize_and_post(c, 3, 1u, POST_FIRST, 0, 0, false));
+        TALL_DISPATCH(k_proj_collect, wsrc, c->n, rpb, c->k, (const ProjState *)ps,
+                      c->projList.as<double>(), c->projSegCnt.as<int>());
+        hipLaunchKernelGGL(k_proj_solve, dim3(c->k), dim3(256), 0, c->stream,
+                           (const double *)c->projList.as<double>(),
+                           (const int *)c->projSegCnt.as<int>(), nseg, segcap, ps);
+    } else {
+        TALL_DISPATCH(k_proj_colmax, x, g, a_const, scal, a_slot, c->n, rpb, c->k, wbuf, part);
+        AA_CHECK(finalize_and_post(c, 1, 1u, POST_COLMAX, 0, c->projWarm[mode] ? mode : 0, false));
+        int batch = c->projPassHint[mode] > 0 ? c->projPassHint[mode] + 1 : 12;
+        int total = 0;
+        int hdr[2] = {0, 0};
+        while (true) {
+            for (int it = 0; it < batch; ++it) {
+                TALL_DISPATCH(k_proj_pass, wsrc, (const double *)nullptr, 0.0, scal, -1, c->n, rpb,
+                              c->k, (const ProjState *)ps, part);
+                AA_CHECK(finalize_and_post(c, 2, 0u, POST_MICHELOT, 0, 0, true));
+            }
+            total += batch;
+            AA_CHECK_HIP(hipMemcpyAsync(hdr, &ps->done, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
+            AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+            if (hdr[0] || total >= g_proj_hard_cap) break;
+            batch = 3;
         }
-        total += batch;
-        AA_CHECK_HIP(hipMemcpyAsync(hdr, &ps->done, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
-        AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-        if (hdr[0] || total >= g_proj_hard_cap) break;
-        batch = 3;
+        c->projPassHint[mode] = hdr[1];
     }
-    c->projPassHint[mode] = hdr[1];
     double *out = nullptr;
     if (mode == PROJ_FEAS) out = const_cast<double *>(x);
     if (mode == PROJ_DIR) out = c->Dt.as<double>();

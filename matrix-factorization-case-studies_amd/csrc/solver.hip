@@ -353,7 +353,7 @@ int aa_set_option(const char *name, int value)
 {
     AA_REQUIRE(name != nullptr, AA_ERR_ARG, "null option name");
     if (!strcmp(name, "row_local_variant")) {
-        AA_REQUIRE(value >= 0 && value <= 2, AA_ERR_ARG, "row_local_variant must be 0, 1 or 2");
+        AA_REQUIRE(value >= -1 && value <= 8, AA_ERR_ARG, "row_local_variant must be in -1..8");
         g_row_local_variant = value;
     } else if (!strcmp(name, "qp_pass_cap")) {
         AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_pass_cap must be >= 1");
@@ -361,6 +361,15 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "qp_refill_min")) {
         AA_REQUIRE(value >= 1 && value <= 64, AA_ERR_ARG, "qp_refill_min must be in 1..64");
         g_qp_refill_min = value;
+    } else if (!strcmp(name, "row_local_waves")) {
+        AA_REQUIRE(value == 0 || (value >= 8 && value <= 16), AA_ERR_ARG, "row_local_waves must be 0 or 8..16");
+        g_row_local_waves = value;
+    } else if (!strcmp(name, "proj_mode")) {
+        AA_REQUIRE(value == 0 || value == 1, AA_ERR_ARG, "proj_mode must be 0 or 1");
+        g_proj_mode = value;
+    } else if (!strcmp(name, "qp_waves")) {
+        AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_waves must be >= 1");
+        g_qp_waves = value;
     } else if (!strcmp(name, "qp_mode")) {
         AA_REQUIRE(value == 0 || value == 1, AA_ERR_ARG, "qp_mode must be 0 or 1");
         g_qp_mode = value;

@@ -467,11 +467,12 @@ def test_dictionary_update_wide_k_vs_oracle(cdr, orc, dtype, k):
     assert (st.n_iter, st.n_feval) == (want[2], want[3])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("k", [7, 40])
 def test_row_local_variants_agree(cdr, orc, variant, k):
-    """The three float32 row-local GEMM kernels (direct, wave-private LDS, block-tiled)
-    give the same Gram products."""
+    """The float32 row-local GEMM kernels (direct, wave-private LDS, and the block-tiled
+    family with 32/64/128-column tiles, single or double buffered) give the same Gram
+    products."""
     from convex_dim_red import _backend
     rng = np.random.RandomState(k)
     n, p = 1111, 450
@@ -487,7 +488,7 @@ def test_row_local_variants_agree(cdr, orc, variant, k):
             ctx.prepare()
             ZtZ, CKCt, CKZ, trace = ctx.grams()
     finally:
-        _backend.set_option("row_local_variant", 2)
+        _backend.set_option("row_local_variant", -1)
     want = C.dot(Xd.dot(Xd.T.dot(Z)))
     assert np.abs(CKZ - want).max() < 3e-5 * np.abs(want).max()
 
@@ -531,6 +532,8 @@ def test_rccl_path_single_rank(cdr, orc):
     def run(force):
         if force:
             os.environ["AA_FORCE_RCCL"] = "1"
+        # multi-rank contexts always use the iterative projection; compare like with like
+        _backend.set_option("proj_mode", 1)
         try:
             with _backend.Context(dtype="float32") as ctx:
                 if force:
@@ -545,9 +548,52 @@ def test_rccl_path_single_rank(cdr, orc):
             return c0, costs, d, Cf, Zf, total
         finally:
             os.environ.pop("AA_FORCE_RCCL", None)
+            _backend.set_option("proj_mode", 0)
 
     a, b = run(False), run(True)
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
     assert np.allclose(a[2], b[2], rtol=1e-6, atol=1e-6)   # the row travels through float64
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     assert np.array_equal(b[5], [1.5, 2.5])
+
+
+@pytest.mark.parametrize("n,k,dense", [(900, 6, False), (7000, 5, True), (7000, 40, True),
+                                       (3000, 33, False)])
+def test_projection_modes_agree(cdr, orc, n, k, dense):
+    """Column simplex projection by candidate lists (one Newton step from the previous
+    threshold, then the fixed point on the short list) and by iterative full passes give
+    the same dictionary; `dense` starts from a dictionary whose columns have more than
+    2048 non-zeros, so the list solver runs from global memory instead of LDS."""
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(n + k)
+    p = 120
+    X = rng.standard_normal((n, p))
+    C = orc.right_stochastic_matrix((k, n), rng)
+    if not dense:
+        C = C ** 6
+        C /= C.sum(axis=1, keepdims=True)
+    Z = orc.right_stochastic_matrix((n, k), rng)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = orc.update_aa_dictionary(X, C, np.ones(k), (X * X).sum(), X.dot(X.T.dot(Z)),
+                                        Z.T.dot(Z), max_iterations=4)
+    res = []
+    for mode in (0, 1):
+        _backend.set_option("proj_mode", mode)
+        try:
+            with _backend.Context(dtype="float64") as ctx:
+                ctx.set_data(X)
+                ctx.set_state(C, Z, np.ones(k))
+                ctx.prepare()
+                st = ctx.dictionary_update(max_iterations=4)
+                res.append((ctx.get_state()[0], st.f, st.n_iter, st.n_feval, st.flags))
+        finally:
+            _backend.set_option("proj_mode", 0)
+    for got in res:
+        assert np.abs(got[0] - want[0]).max() < 1e-11
+        assert abs(got[1] - want[1]) < 1e-10 * abs(want[1])
+        assert got[2:4] == (want[2], want[3])
+        assert np.abs(got[0].sum(axis=1) - 1).max() < 1e-13 and got[0].min() >= 0
+    assert np.abs(res[0][0] - res[1][0]).max() < 1e-13
+    assert np.array_equal(res[0][0] > 0, res[1][0] > 0) or \
+        np.abs(res[0][0] - res[1][0])[(res[0][0] > 0) != (res[1][0] > 0)].max() < 1e-15
