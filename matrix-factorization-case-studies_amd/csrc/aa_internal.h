@@ -144,7 +144,7 @@ struct Ctx {
     int k = 0, KP = 0;
     bool have_state = false, grams_valid = false, gpnh_valid = false;
     std::vector<double> alpha;                 // host copy
-    std::vector<double> ZtZ, CKCt, CKZ;        // host copies (k x k, dense k)
+    std::vector<double> ZtZ, CKCt, CKZ;        // host copies (k x k, dense k), fetched on demand
     bool dict_inputs_overridden = false;
 
     // tall arrays
@@ -156,7 +156,9 @@ struct Ctx {
     DevBuf partial;                            // GEMM split-row partials
     DevBuf redPartial;                         // tall/wide reduction partials
     DevBuf gramOut;                            // up to 4 KPxKP results
-    DevBuf gramPP;                             // (CX)(CX)' / C K C' of the current dictionary
+    DevBuf gramState;                          // [3][KP*KP] on the device: Z'Z | C K C' | C K Z
+    DevBuf costDev;                            // costs recorded by aa_outer_iterations
+    bool host_grams_valid = false;             // the host copies below match gramState
     DevBuf redOut;                             // finalized [NV][KP] reduction results
     DevBuf scalars;                            // SC_COUNT doubles
     DevBuf proj;                               // ProjState
@@ -194,6 +196,9 @@ int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const doubl
                            int slot);   // sum x*H*alpha (alpha_dev nullable => 1)
 int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev); // A'B  (KPxKP)
 int launch_gram_wide(Ctx *c, const double *A, const double *B, double *out_dev); // A B' (KPxKP)
+int launch_scale_gram(Ctx *c, double *dst, const double *src);      // dst = D src D
+int launch_aa_cost(Ctx *c, double *out_dev);                        // cost from gramState
+int launch_set_scalars(Ctx *c, double trace, double fnorm);          // SC_TRACE, SC_FNORM
 int launch_wide_axpy_lambda(Ctx *c, double *P, const double *Q, void *PT);   // P += lambda*Q; PT = T(P)
 int launch_wide_to_T(Ctx *c, const double *src, void *dstT);
 int launch_transpose_wide_to_tall(Ctx *c, const double *wide, double *tall); // [KP][p_pad] -> [n_pad][KP] (kernel form)
@@ -206,14 +211,19 @@ int launch_residual_cost(Ctx *c, const double *Ztall, const double *Wwide, const
                          double *out_host);
 
 // ------------------------------------------------------------------ kernels_qp.hip
+// A_host (k x k) and bscale_host (k or null) come from the host, or -- A_host == nullptr --
+// the Hessian is D G D with G = gram_dev (KP x KP, device) and D = bscale = alphaDev, set
+// up by a kernel (no host synchronisation).
 int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, long stride_t,
               const double *bscale_host /*k or null*/, double *Ztall, int ldz, long n, int k,
-              const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats);
+              const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats,
+              const double *gram_dev = nullptr);
 int launch_simplex_rows_generic(hipStream_t s, const double *in, double *out, long rows, long cols);
 
 extern int g_proj_mode;           // kernels_tall.hip
 extern int g_row_local_variant;   // kernels_gemm.hip
 extern int g_row_local_waves;     // kernels_gemm.hip
+extern int g_row_local_stagger;   // kernels_gemm.hip
 extern int g_qp_pass_cap;         // kernels_qp.hip
 extern int g_qp_mode;             // kernels_qp.hip
 extern int g_qp_refill_min;       // kernels_qp.hip

@@ -404,13 +404,14 @@ template <int NCT>
 __global__ __launch_bounds__(NCT == 1 ? 1024 : 768) void k_row_local_f32_ws(const float *__restrict__ X, long ldx,
                                                            const float *__restrict__ B, int p_pad,
                                                            double *__restrict__ out, long n_pad,
-                                                           int W)
+                                                           int W, int stagger)
 {
     constexpr int KP = 32 * NCT;
     constexpr int SB = 128, TC = 64;
     constexpr int NBI = 2 * NCT;                 // B chunks per thread per slab at >= 512 threads
     extern __shared__ __attribute__((aligned(16))) float ws_smem[];
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, nthreads = blockDim.x;
+    const int t = threadIdx.x, lane = t & 63, nthreads = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // scalar: uniform row base
     float *bs = ws_smem;
     float *xs = ws_smem + 2 * KP * SB + wave * (32 * TC);
     const long r0 = ((long)blockIdx.x * W + wave) * 32;
@@ -481,14 +482,20 @@ __global__ __launch_bounds__(NCT == 1 ? 1024 : 768) void k_row_local_f32_ws(cons
         }
     };
 
+    // blocks start at different column slabs (cyclic order) so that the chip does not
+    // sweep one narrow column band of X -- one set of HBM channels -- at a time
     const int nslab = p_pad / SB;
-    load_b(0);
-    load_x(0);
+    const int s_first = (int)(((long)blockIdx.x * stagger) % nslab);
+    load_b(s_first * SB);
+    load_x(s_first * SB);
     store_b(0);
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
-        const int c0 = s * SB;
-        const int snext = s + 1 < nslab ? s + 1 : s;       // last slab: harmless reload
+        int scur = s_first + s;
+        if (scur >= nslab) scur -= nslab;
+        const int c0 = scur * SB;
+        int snext = s + 1 < nslab ? scur + 1 : scur;       // last slab: harmless reload
+        if (snext >= nslab) snext -= nslab;
         store_x();                                // wave-private: LDS is in order per wave
         load_x(c0 + TC);
         load_b(snext * SB);
@@ -597,7 +604,8 @@ int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *out
 // >= 2: block-tiled, B shared through LDS: 2 = 64-column tiles, 3 = 64 double-buffered,
 // 4 (default) = 128, 5 = 32 double-buffered, 6 = 128 double-buffered, 7 = 32;
 // 8: wave-streaming (wave-private X tiles, B slabs shared per block).  aa_set_option.
-int g_row_local_variant = -1;   // -1: by size (8 when there are >= 8 tiles per CU-block, else 4)
+int g_row_local_variant = -1;   // -1: by size (8 from 32768 rows per GPU, else 4)
+int g_row_local_stagger = 0;   // variant 8: column-slab offset between consecutive blocks
 int g_row_local_waves = 0;     // variant 8: waves per block (0 = one block per CU)
 static int row_local_variant(const Ctx *c)
 {
@@ -629,10 +637,10 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
         dim3 grid((unsigned)((tiles + W - 1) / W)), blk((unsigned)(64 * W));
         if (nct == 1)
             hipLaunchKernelGGL(k_row_local_f32_ws<1>, grid, blk, lds, c->stream, c->X.as<float>(),
-                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W);
+                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, g_row_local_stagger);
         else
             hipLaunchKernelGGL(k_row_local_f32_ws<2>, grid, blk, lds, c->stream, c->X.as<float>(),
-                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W);
+                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, g_row_local_stagger);
     } else if (c->dtype == AA_F32 && row_local_variant(c) >= 2) {
         const float *B = reinterpret_cast<const float *>(B_wideT);
         dim3 grid((unsigned)(c->n_pad / 128));

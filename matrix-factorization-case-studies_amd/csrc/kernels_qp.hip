@@ -25,55 +25,73 @@
 namespace aa {
 
 #define QP_MAXMEM 8
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// Threshold t of the projection of w = x - a*g (components >= k excluded).
+//
+// Fixed-point form of Michelot's algorithm on a SUPPORT MASK: from a support S,
+//   t_S = (sum_S w - 1)/|S|,   S' = {i : w_i > t_S},
+// until S' == S.  The fixed point is unique (it is the KKT condition of the projection),
+// so any start gives the support -- and, summing it in the same fixed order, the same
+// threshold -- the reference's sorted scan finds (simplex_projection.py:13-27).  `mask`
+// carries the support of the sample's previous projection: SPG identifies the active set
+// after a few passes, after which one sum and one comparison sweep confirm it (the cold
+// start from {w > max - 1} costs a maximum sweep and typically 3-5 rounds).  After the
+// first round every S is threshold-induced with t below the root (a Newton step on a
+// convex decreasing function), so supports only shrink: a support that fails to shrink
+// is the fixed point up to rounding.  The comparison is w*|S| > sum_S - 1: no fp64
+// division inside the loop.  Sums run in NP interleaved chains combined in a fixed order.
+template <int KQ> struct QpMask { typedef unsigned int type; };
+template <> struct QpMask<64> { typedef unsigned long long type; };
 
 template <int KQ>
 __device__ __forceinline__ double qp_project_threshold(const double (&x)[KQ], const double (&g)[KQ],
-                                                       double a, int k)
+                                                       double a, int k,
+                                                       typename QpMask<KQ>::type &mask)
 {
-    // threshold t of the projection of w = x - a*g (components >= k excluded).  Sums and
-    // maxima run in NP interleaved chains (combined in a fixed order) so that one lane's
-    // dependent fp64 adds do not serialise the SIMD.
+    typedef typename QpMask<KQ>::type M;
     constexpr int NP = KQ >= 4 ? 4 : 1;
-    double mxp[NP];
+    M m = mask;
+    double s = 0.0;
+    int c = 1;
+    for (int pass = 0; pass < 2 * KQ + 8; ++pass) {
+        if (m == (M)0) {                       // cold start, or the warm guess emptied
+            double mxp[NP];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) mxp[q] = -INFINITY;
+            for (int q = 0; q < NP; ++q) mxp[q] = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < KQ; ++i)
-        if (i < k) mxp[i % NP] = fmax(mxp[i % NP], x[i] - a * g[i]);
-    double mx = mxp[0];
+            for (int i = 0; i < KQ; ++i)
+                if (i < k) mxp[i % NP] = fmax(mxp[i % NP], x[i] - a * g[i]);
+            double mx = mxp[0];
 #pragma unroll
-    for (int q = 1; q < NP; ++q) mx = fmax(mx, mxp[q]);
-    double t = mx - 1.0;
-    int prev = 0;
-    for (int pass = 0; pass < KQ + 2; ++pass) {
-        double sp[NP];
-        int cp[NP];
+            for (int q = 1; q < NP; ++q) mx = fmax(mx, mxp[q]);
+            const double t0 = mx - 1.0;
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            sp[q] = 0.0;
-            cp[q] = 0;
+            for (int i = 0; i < KQ; ++i)
+                if (i < k && x[i] - a * g[i] > t0) m |= (M)1 << i;
         }
+        double sp[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) sp[q] = 0.0;
 #pragma unroll
         for (int i = 0; i < KQ; ++i) {
             const double w = x[i] - a * g[i];
-            const bool in = (i < k) && (w > t);
-            sp[i % NP] += in ? w : 0.0;
-            cp[i % NP] += in ? 1 : 0;
+            sp[i % NP] += ((m >> i) & (M)1) ? w : 0.0;
         }
-        double s = sp[0];
-        int c = cp[0];
+        s = sp[0];
 #pragma unroll
-        for (int q = 1; q < NP; ++q) {
-            s += sp[q];
-            c += cp[q];
-        }
-        const double tn = (s - 1.0) / (double)c;
-        const bool conv = (prev > 0) && (c >= prev);
-        t = tn;
-        prev = c;
-        if (conv) break;
+        for (int q = 1; q < NP; ++q) s += sp[q];
+        c = __popcll((unsigned long long)m);
+        const double sm1 = s - 1.0, cd = (double)c;
+        M nm = 0;
+#pragma unroll
+        for (int i = 0; i < KQ; ++i)
+            if (i < k && (x[i] - a * g[i]) * cd > sm1) nm |= (M)1 << i;
+        if (nm == m || (pass >= 2 && __popcll((unsigned long long)nm) >= c)) break;
+        m = nm;
     }
-    return t;
+    mask = m;
+    return (s - 1.0) / (double)c;
 }
 
 // Continuation record of a sample whose SPG loop hit the phase-1 pass cap.
@@ -191,6 +209,57 @@ __device__ __forceinline__ void qp_matvec(const double *__restrict__ AsT,
     }
 }
 
+// Mat-vec of the whole wave on the f64 matrix cores (KQ >= 16): the 64 directions of the
+// wave form a KQ x 64 matrix D that already sits in LDS (vbuf[j][sample], written one
+// column per lane), so  (A D)' = D' A'  is a 64 x KQ x KQ GEMM in 16x16x4 tiles:
+//   A-operand lane l = D[4s + (l>>4)][16mt + (l&15)]   (ds_read_b64 from vbuf)
+//   B-operand lane l = A[16nt + (l&15)][4s + (l>>4)]   (constant: KQ/2 registers per lane)
+//   D-result  lane l, reg r = (A d)[component 16nt + (l&15)] of sample 16mt + (l>>4) + 4r,
+// which goes back through LDS (abuf[component][sample]) so that every lane ends up with the
+// KQ components of ITS sample.  Compared with the per-lane FMA loop this needs no broadcast
+// reads of A at all (512 ds_read_b128 and their waits per mat-vec) and 64 instead of 1024
+// arithmetic instructions.  Row strides: 80 doubles for vbuf and 66 for abuf make the
+// fragment reads and the result writes bank-conflict free (the lane-private accesses stay
+// unit stride).  Every lane must take part (a lane's fragments belong to other samples):
+// call with the full wave, outside divergent control flow.
+#define QP_VS 80
+#define QP_AS 66
+template <int KQ>
+__device__ __forceinline__ void qp_matvec_mfma(const double (&Breg)[KQ / 16][KQ / 4],
+                                               const double *__restrict__ vbuf,
+                                               double *__restrict__ abuf, int lane,
+                                               double (&out)[KQ])
+{
+    constexpr int NT = KQ / 16, NS = KQ / 4;
+    const int lc = lane & 15, lr = lane >> 4;
+    // the columns were written by other lanes of this wave (see the note below)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        double a[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a[s] = vbuf[(4 * s + lr) * QP_VS + 16 * mt + lc];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], Breg[nt][s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) abuf[(16 * nt + lc) * QP_AS + 16 * mt + lr + 4 * r] = acc[r];
+        }
+    }
+    // one wave per block: LDS executes a wave's operations in order; the barrier only
+    // keeps the compiler from moving the column reads above the tile writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) out[i] = abuf[i * QP_AS + lane];
+}
+
 template <int KQ>
 __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][KQ]*/,
                                            const double *__restrict__ B, long stride_j,
@@ -201,19 +270,42 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                                            int *__restrict__ ovf_rows, QpCarry *__restrict__ ovf,
                                            int g_refill)
 {
-    __shared__ __attribute__((aligned(16))) double AsT[KQ * KQ];
-    __shared__ double vbuf[KQ * 64];
-    for (int e = threadIdx.x; e < KQ * KQ; e += 64) AsT[(e % KQ) * KQ + e / KQ] = A[e];
+    constexpr bool MFMA = KQ >= 16;
+    constexpr int VS = MFMA ? QP_VS : 64;              // row stride of the direction buffer
+    __shared__ __attribute__((aligned(16))) double AsT[MFMA ? 2 : KQ * KQ];
+    __shared__ double vbuf[KQ * VS];
+    __shared__ double abuf[MFMA ? KQ * QP_AS : 1];
+    const int lane = threadIdx.x;
+    double Breg[MFMA ? KQ / 16 : 1][MFMA ? KQ / 4 : 1];
+    if constexpr (MFMA) {
+#pragma unroll
+        for (int nt = 0; nt < KQ / 16; ++nt)
+#pragma unroll
+            for (int s = 0; s < KQ / 4; ++s)
+                Breg[nt][s] = A[(16 * nt + (lane & 15)) * KQ + 4 * s + (lane >> 4)];
+    } else {
+        for (int e = threadIdx.x; e < KQ * KQ; e += 64) AsT[(e % KQ) * KQ + e / KQ] = A[e];
+        Breg[0][0] = 0.0;
+    }
     __syncthreads();
     double *vl = vbuf + threadIdx.x;
 
     double x[KQ], g[KQ], Ad[KQ];
     const int refill_min = g_refill;
     double f = 0.0, alpha = 1.0, fmem[QP_MAXMEM];
+    double delta = 0.0, dd = 0.0;
     int n_iter = 0, n_feval = 0;
     long row = -1;
     bool active = false, exhausted = false;
+    typename QpMask<KQ>::type support = 0;   // support of this sample's latest projection
     const int mem = p.memory < 1 ? 1 : (p.memory > QP_MAXMEM ? QP_MAXMEM : p.memory);
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) vl[i * VS] = 0.0;
+
+    auto matvec = [&](double (&out)[KQ]) {            // out = A v, v = this lane's LDS column
+        if constexpr (MFMA) qp_matvec_mfma<KQ>(Breg, vbuf, abuf, lane, out);
+        else qp_matvec<KQ>(AsT, vl, k, out);
+    };
 
     // the trip bound is a watchdog only (each sample needs <= max_iterations trips)
     for (long trip = 0; trip < (1L << 24); ++trip) {
@@ -222,49 +314,56 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
         // when enough lanes are waiting (or nothing else is left to do).
         const int n_idle = __popcll(__ballot(!active && !exhausted));
         const bool refill = n_idle >= refill_min || !__any(active);
+        bool starting = false;
         if (refill && !active && !exhausted) {
             const unsigned int nxt = atomicAdd(&hdr->next_row, 1u);
             if ((long)nxt < n) {
                 row = (long)nxt;
-                active = true;
+                starting = true;
                 // ---- start-up: x = P(z0); g = A x + b; f = x'(g + b)/2      (spg.py:298-315)
-                double b[KQ];
 #pragma unroll
                 for (int i = 0; i < KQ; ++i) {
                     x[i] = (i < k) ? Z[row * ldz + i] : 0.0;
                     g[i] = 0.0;
-                    b[i] = (i < k) ? -B[i * stride_j + row * stride_t] * (bscale ? bscale[i] : 1.0) : 0.0;
                 }
-                const double t0 = qp_project_threshold<KQ>(x, g, 0.0, k);
+                support = 0;
+                const double t0 = qp_project_threshold<KQ>(x, g, 0.0, k, support);
 #pragma unroll
                 for (int i = 0; i < KQ; ++i) x[i] = (i < k) ? fmax(x[i] - t0, 0.0) : 0.0;
 #pragma unroll
-                for (int i = 0; i < KQ; ++i) vl[i * 64] = x[i];
-                qp_matvec<KQ>(AsT, vl, k, g);
+                for (int i = 0; i < KQ; ++i) vl[i * VS] = x[i];
+            } else {
+                exhausted = true;   // queue drained: this lane idles
+            }
+        }
+        if (__any(starting)) {                         // wave-uniform: the mat-vec is collective
+            matvec(Ad);
+            if (starting) {
                 double xg = 0.0, xb = 0.0;
 #pragma unroll
                 for (int i = 0; i < KQ; ++i) {
-                    g[i] += b[i];
+                    const double bi =
+                        (i < k) ? -B[i * stride_j + row * stride_t] * (bscale ? bscale[i] : 1.0) : 0.0;
+                    g[i] = Ad[i] + bi;
                     xg = fma(x[i], g[i], xg);
-                    xb = fma(x[i], b[i], xb);
+                    xb = fma(x[i], bi, xb);
                 }
                 f = 0.5 * (xg + xb);
                 n_feval = 1;
                 n_iter = 0;
 #pragma unroll
                 for (int i = 0; i < QP_MAXMEM; ++i) fmem[i] = NAN;
-            } else {
-                exhausted = true;   // queue drained: this lane idles
+                active = true;
             }
         }
         if (!__any(active)) break;
         if (active) {
-            // ---- one pass of the loop at spg.py:318-396
+            // ---- one pass of the loop at spg.py:318-396, up to the search direction
             if (n_iter == 0) {
                 if (p.alpha_min <= p.alpha0 && p.alpha0 <= p.alpha_max) {
                     alpha = p.alpha0;
                 } else {
-                    const double t1 = qp_project_threshold<KQ>(x, g, 1.0, k);
+                    const double t1 = qp_project_threshold<KQ>(x, g, 1.0, k, support);
                     double ainv = 0.0;
 #pragma unroll
                     for (int i = 0; i < KQ; ++i)
@@ -273,19 +372,22 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                     alpha = fmin(fmax(p.alpha_min, 1.0 / ainv), p.alpha_max);
                 }
             }
-            const double td = qp_project_threshold<KQ>(x, g, alpha, k);
-            double delta = 0.0, dd = 0.0;
+            const double td = qp_project_threshold<KQ>(x, g, alpha, k, support);
+            delta = 0.0;
+            dd = 0.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
                 const double di = (i < k) ? fmax(x[i] - alpha * g[i] - td, 0.0) - x[i] : 0.0;
-                vl[i * 64] = di;                 // the direction lives in LDS only
+                vl[i * VS] = di;                 // the direction lives in LDS only
                 delta = fma(di, g[i], delta);
                 dd = fma(di, di, dd);
             }
-            qp_matvec<KQ>(AsT, vl, k, Ad);
+        }
+        matvec(Ad);                                    // collective (idle lanes: stale columns)
+        if (active) {
             double dAd = 0.0;
 #pragma unroll
-            for (int i = 0; i < KQ; ++i) dAd = fma(vl[i * 64], Ad[i], dAd);
+            for (int i = 0; i < KQ; ++i) dAd = fma(vl[i * VS], Ad[i], dAd);
             // non-monotone reference value (spg.py:341-344): roll, store, nanmax
 #pragma unroll
             for (int i = QP_MAXMEM - 1; i > 0; --i)
@@ -310,7 +412,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             }
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
-                x[i] = fma(lam, vl[i * 64], x[i]);
+                x[i] = fma(lam, vl[i * VS], x[i]);
                 g[i] = fma(lam, Ad[i], g[i]);
             }
             const double sksk = lam * lam * dd;
@@ -319,7 +421,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             f = f_new;
             n_feval += 1;
 
-            const double tr = qp_project_threshold<KQ>(x, g, 1.0, k);
+            const double tr = qp_project_threshold<KQ>(x, g, 1.0, k, support);
             double r2 = 0.0, rinf = 0.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i)
@@ -373,12 +475,16 @@ __device__ __forceinline__ double qw_dpp(double old, double v)
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double qw_lane63(double v)
+__device__ __forceinline__ double qw_readlane(double v, int l)
 {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
+// HALF (k <= 32): lanes 32..63 MIRROR lanes 0..31 (lane l+32 holds component l too), the
+// total of a half needs one step less (lane 31 / lane 63), and two different quantities
+// -- one per half -- are reduced by the same five instructions.
+template <bool HALF>
 __device__ __forceinline__ double qw_sum(double v)
 {
     v += qw_dpp<0x111, 0xf>(0.0, v);   // row_shr:1
@@ -386,9 +492,29 @@ __device__ __forceinline__ double qw_sum(double v)
     v += qw_dpp<0x114, 0xf>(0.0, v);   // row_shr:4
     v += qw_dpp<0x118, 0xf>(0.0, v);   // row_shr:8
     v += qw_dpp<0x142, 0xa>(0.0, v);   // row_bcast:15 -> rows 1, 3
+    if constexpr (HALF) return qw_readlane(v, 31);
     v += qw_dpp<0x143, 0xc>(0.0, v);   // row_bcast:31 -> rows 2, 3
-    return qw_lane63(v);
+    return qw_readlane(v, 63);
 }
+// sums of a and b over the components (both arguments valid in every lane)
+template <bool HALF>
+__device__ __forceinline__ void qw_sum2(double a, double b, int lane, double &sa, double &sb)
+{
+    if constexpr (HALF) {
+        double v = lane < 32 ? a : b;
+        v += qw_dpp<0x111, 0xf>(0.0, v);
+        v += qw_dpp<0x112, 0xf>(0.0, v);
+        v += qw_dpp<0x114, 0xf>(0.0, v);
+        v += qw_dpp<0x118, 0xf>(0.0, v);
+        v += qw_dpp<0x142, 0xa>(0.0, v);
+        sa = qw_readlane(v, 31);
+        sb = qw_readlane(v, 63);
+    } else {
+        sa = qw_sum<false>(a);
+        sb = qw_sum<false>(b);
+    }
+}
+template <bool HALF>
 __device__ __forceinline__ double qw_max(double v)
 {
     v = fmax(v, qw_dpp<0x111, 0xf>(-INFINITY, v));
@@ -396,36 +522,55 @@ __device__ __forceinline__ double qw_max(double v)
     v = fmax(v, qw_dpp<0x114, 0xf>(-INFINITY, v));
     v = fmax(v, qw_dpp<0x118, 0xf>(-INFINITY, v));
     v = fmax(v, qw_dpp<0x142, 0xa>(-INFINITY, v));
+    if constexpr (HALF) return qw_readlane(v, 31);
     v = fmax(v, qw_dpp<0x143, 0xc>(-INFINITY, v));
-    return qw_lane63(v);
+    return qw_readlane(v, 63);
 }
-__device__ __forceinline__ double qw_bcast(double v, int j)
+// Threshold of the projection of the wave-distributed vector w (w = -inf on lanes without
+// a component): the support-mask fixed point described at qp_project_threshold, the mask
+// being a wave-uniform bit set (one reduction per round; a confirmed warm support costs
+// exactly one).  Division-free comparison w*|S| > sum_S - 1.
+template <bool HALF>
+__device__ __forceinline__ double qw_threshold(double w, int comp, unsigned long long &mask)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, j);
-    hi = __builtin_amdgcn_readlane(hi, j);
-    return __hiloint2double(hi, lo);
-}
-// threshold of the projection of the wave-distributed vector w (w = -inf on idle lanes).
-// The Michelot passes compare w*|S| > sum_S - 1 instead of w > (sum_S - 1)/|S|: no fp64
-// division (a ~300-cycle dependent sequence) on the critical path of a pass; the
-// threshold itself is formed once, by the same closed form (sum_S - 1)/|S|.
-__device__ __forceinline__ double qw_threshold(double w, int k)
-{
-    const double t0 = qw_max(w) - 1.0;
-    bool in = w > t0;
-    int prev = 0;
+    const unsigned long long full = HALF ? 0xffffffffull : ~0ull;
+    unsigned long long m = mask;
     double s = 0.0;
     int c = 1;
-    for (int pass = 0; pass < k + 2; ++pass) {
-        c = __popcll(__ballot(in));
-        s = qw_sum(in ? w : 0.0);
-        const bool conv = (prev > 0) && (c >= prev);
-        prev = c;
-        if (conv) break;
-        in = w * (double)c > s - 1.0;
+    for (int pass = 0; pass < 136; ++pass) {
+        if (m == 0ull) {                       // cold start, or the warm guess emptied
+            const double t0 = qw_max<HALF>(w) - 1.0;
+            m = __ballot(w > t0) & full;
+        }
+        const bool in = (m >> comp) & 1ull;
+        c = __popcll(m);
+        s = qw_sum<HALF>(in ? w : 0.0);
+        const unsigned long long nm = __ballot(w * (double)c > s - 1.0) & full;
+        if (nm == m || (pass >= 2 && __popcll(nm) >= c)) break;
+        m = nm;
     }
+    mask = m;
     return (s - 1.0) / (double)c;
+}
+
+// out_i = sum_j Arow[j] * v_j (lane = component i; v distributed one component per lane).
+// Blocks of four columns whose v entries are all zero are skipped (their terms are exact
+// zeros): the SPG direction is non-zero only on the union of two small supports.
+template <int KQ>
+__device__ __forceinline__ double qw_matvec(const double (&Arow)[KQ], double v)
+{
+    const unsigned long long nz = __ballot(v != 0.0);
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < KQ; j += 4) {
+        if ((nz >> j) & 0xfull) {
+            a0 = fma(Arow[j], qw_readlane(v, j), a0);
+            a1 = fma(Arow[j + 1], qw_readlane(v, j + 1), a1);
+            a0 = fma(Arow[j + 2], qw_readlane(v, j + 2), a0);
+            a1 = fma(Arow[j + 3], qw_readlane(v, j + 3), a1);
+        }
+    }
+    return a0 + a1;
 }
 
 template <int KQ>
@@ -438,12 +583,14 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
                                                  const int *__restrict__ ovf_rows,
                                                  const QpCarry *__restrict__ ovf)
 {
+    constexpr bool HALF = KQ == 32;
     const int lane = threadIdx.x & 63;
-    const bool live = lane < k;
-    // row `lane` of A in registers
+    const int comp = HALF ? (lane & 31) : lane;     // HALF: the upper half mirrors the lower
+    const bool live = comp < k;
+    // row `comp` of A in registers
     double Arow[KQ];
 #pragma unroll
-    for (int j = 0; j < KQ; ++j) Arow[j] = (lane < KQ) ? A[lane * KQ + j] : 0.0;
+    for (int j = 0; j < KQ; ++j) Arow[j] = A[comp * KQ + j];
     const int mem = p.memory < 1 ? 1 : (p.memory > QP_MAXMEM ? QP_MAXMEM : p.memory);
     // n_fresh >= 0: process rows [0, n_fresh) from scratch; otherwise the overflow list
     const bool fresh = n_fresh >= 0;
@@ -455,25 +602,22 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
     for (unsigned int slot = wave_id; slot < count; slot += n_waves) {
         const long row = fresh ? (long)slot : (long)ovf_rows[slot];
 
-        double x = live ? Z[row * ldz + lane] : 0.0;
-        const double b = live ? -B[lane * stride_j + row * stride_t] * (bscale ? bscale[lane] : 1.0) : 0.0;
+        double x = live ? Z[row * ldz + comp] : 0.0;
+        const double b = live ? -B[comp * stride_j + row * stride_t] * (bscale ? bscale[comp] : 1.0) : 0.0;
         double f, alpha = 1.0, fmem[QP_MAXMEM];
         int n_iter, n_feval;
+        unsigned long long support = 0ull;      // support of the latest projection
 #pragma unroll
         for (int i = 0; i < QP_MAXMEM; ++i) fmem[i] = NAN;
         if (fresh) {
-            const double t0 = qw_threshold(live ? x : -INFINITY, k);
+            const double t0 = qw_threshold<HALF>(live ? x : -INFINITY, comp, support);
             x = live ? fmax(x - t0, 0.0) : 0.0;
         }
-        double g = 0.0, g1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < KQ; j += 2) {
-            g = fma(Arow[j], qw_bcast(x, j), g);
-            g1 = fma(Arow[j + 1], qw_bcast(x, j + 1), g1);
-        }
-        g = (g + g1) + b;
+        double g = qw_matvec<KQ>(Arow, x) + b;
         if (fresh) {
-            f = 0.5 * (qw_sum(x * g) + qw_sum(x * b));
+            double xg, xb;
+            qw_sum2<HALF>(x * g, x * b, lane, xg, xb);
+            f = 0.5 * (xg + xb);
             n_iter = 0;
             n_feval = 1;
         } else {
@@ -490,24 +634,18 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
                 if (p.alpha_min <= p.alpha0 && p.alpha0 <= p.alpha_max) {
                     alpha = p.alpha0;
                 } else {
-                    const double t1 = qw_threshold(live ? x - g : -INFINITY, k);
-                    double ainv = qw_max(live ? fabs(fmax(x - g - t1, 0.0) - x) : 0.0);
+                    const double t1 = qw_threshold<HALF>(live ? x - g : -INFINITY, comp, support);
+                    double ainv = qw_max<HALF>(live ? fabs(fmax(x - g - t1, 0.0) - x) : 0.0);
                     if (fabs(ainv) < 1e-12) ainv = 1.0;
                     alpha = fmin(fmax(p.alpha_min, 1.0 / ainv), p.alpha_max);
                 }
             }
-            const double td = qw_threshold(live ? x - alpha * g : -INFINITY, k);
+            const double td = qw_threshold<HALF>(live ? x - alpha * g : -INFINITY, comp, support);
             const double d = live ? fmax(x - alpha * g - td, 0.0) - x : 0.0;
-            const double delta = qw_sum(d * g);
-            const double dd = qw_sum(d * d);
-            double Ad = 0.0, Ad1 = 0.0;
-#pragma unroll
-            for (int j = 0; j < KQ; j += 2) {
-                Ad = fma(Arow[j], qw_bcast(d, j), Ad);
-                Ad1 = fma(Arow[j + 1], qw_bcast(d, j + 1), Ad1);
-            }
-            Ad += Ad1;
-            const double dAd = qw_sum(d * Ad);
+            double delta, dd;
+            qw_sum2<HALF>(d * g, d * d, lane, delta, dd);
+            const double Ad = qw_matvec<KQ>(Arow, d);
+            const double dAd = qw_sum<HALF>(d * Ad);
 
 #pragma unroll
             for (int i = QP_MAXMEM - 1; i > 0; --i)
@@ -538,15 +676,16 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             f = f_new;
             n_feval += 1;
 
-            const double tr = qw_threshold(live ? x - g : -INFINITY, k);
+            const double tr = qw_threshold<HALF>(live ? x - g : -INFINITY, comp, support);
             const double r = live ? fmax(x - g - tr, 0.0) - x : 0.0;
-            const double r2 = qw_sum(r * r);
-            const double rinf = qw_max(fabs(r));
+            const double r2 = qw_sum<HALF>(r * r);
+            // max |r| < epsilon_one  <=>  no lane has |r| >= epsilon_one (no reduction)
+            const bool rinf_small = __ballot(!(fabs(r) < p.epsilon_one)) == 0ull;
             n_iter += 1;
-            const bool conv = (sqrt(r2) < p.epsilon_two) || (rinf < p.epsilon_one);
+            const bool conv = (sqrt(r2) < p.epsilon_two) || rinf_small;
             if (conv || n_feval > p.max_feval || n_iter >= p.max_iterations) break;
         }
-        if (live) Z[row * ldz + lane] = x;
+        if (live && lane == comp) Z[row * ldz + comp] = x;
         if (lane == 0) {
             if (iters) iters[row] = n_iter;
             atomicAdd(&hdr->total_passes, (unsigned long long)n_iter);
@@ -569,7 +708,8 @@ __global__ __launch_bounds__(256) void k_qp_project_only(const double *__restric
         x[i] = (i < k) ? Z0[row * ldz + i] : 0.0;
         g[i] = 0.0;
     }
-    const double t0 = qp_project_threshold<KQ>(x, g, 0.0, k);
+    typename QpMask<KQ>::type support = 0;
+    const double t0 = qp_project_threshold<KQ>(x, g, 0.0, k, support);
 #pragma unroll
     for (int i = 0; i < KQ; ++i)
         if (i < k) Z[row * ldz + i] = fmax(x[i] - t0, 0.0);
@@ -583,9 +723,37 @@ int g_qp_mode = 0;             // 0: lane-per-sample then wave-per-sample; 1: wa
 int g_qp_waves = 1024;         // most waves the lane-per-sample kernel is launched with
 static int qp_pass_cap() { return g_qp_pass_cap < 1 ? 1 : g_qp_pass_cap; }
 
+// device-side set-up of the QP scratch: header zeroed, A = D G D padded to KQ and KW,
+// b-scale = D.  One block.
+__global__ __launch_bounds__(256) void k_qp_setup(QpHeader *__restrict__ hdr, double *__restrict__ Ad,
+                                                  double *__restrict__ A2d, double *__restrict__ bsd,
+                                                  const double *__restrict__ gram,
+                                                  const double *__restrict__ alpha, int k, int KQ,
+                                                  int KW, int KP)
+{
+    const int t = threadIdx.x;
+    if (t == 0) {
+        hdr->total_passes = 0ull;
+        hdr->max_passes = 0ull;
+        hdr->next_row = 0u;
+        hdr->n_overflow = 0u;
+        hdr->next_overflow = 0u;
+        hdr->pad = 0u;
+    }
+    for (int e = t; e < KQ * KQ; e += 256) {
+        const int i = e / KQ, j = e % KQ;
+        Ad[e] = (i < k && j < k) ? alpha[i] * gram[i * KP + j] * alpha[j] : 0.0;
+    }
+    for (int e = t; e < KW * KW; e += 256) {
+        const int i = e / KW, j = e % KW;
+        A2d[e] = (i < k && j < k) ? alpha[i] * gram[i * KP + j] * alpha[j] : 0.0;
+    }
+    if (t < 64) bsd[t] = t < k ? alpha[t] : 1.0;
+}
+
 int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, long stride_t,
               const double *bscale_host, double *Ztall, int ldz, long n, int k,
-              const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats)
+              const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats, const double *gram_dev)
 {
     int KQ = 4;
     while (KQ < k) KQ *= 2;
@@ -601,23 +769,32 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     const size_t off_ovf = off_rows + round_up((long)n * sizeof(int), 16);
     const size_t bytes = off_ovf + (size_t)n * sizeof(QpCarry);
     AA_CHECK(c->qpStats.alloc(bytes));
-    std::vector<unsigned char> host(off_rows, 0);
-    double *Ah = reinterpret_cast<double *>(host.data() + off_A);
-    double *A2h = reinterpret_cast<double *>(host.data() + off_A2);
-    for (int i = 0; i < k; ++i)
-        for (int j = 0; j < k; ++j) {
-            Ah[i * KQ + j] = A_host[i * k + j];
-            A2h[i * KW + j] = A_host[i * k + j];
-        }
-    double *bs = reinterpret_cast<double *>(host.data() + off_bs);
-    for (int i = 0; i < 64; ++i) bs[i] = (bscale_host && i < k) ? bscale_host[i] : 1.0;
-    AA_CHECK_HIP(hipMemcpyAsync(c->qpStats.p, host.data(), off_rows, hipMemcpyHostToDevice, c->stream));
-    AA_CHECK_HIP(hipStreamSynchronize(c->stream));   // host vector goes out of scope
+    if (A_host) {
+        std::vector<unsigned char> host(off_rows, 0);
+        double *Ah = reinterpret_cast<double *>(host.data() + off_A);
+        double *A2h = reinterpret_cast<double *>(host.data() + off_A2);
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) {
+                Ah[i * KQ + j] = A_host[i * k + j];
+                A2h[i * KW + j] = A_host[i * k + j];
+            }
+        double *bs = reinterpret_cast<double *>(host.data() + off_bs);
+        for (int i = 0; i < 64; ++i) bs[i] = (bscale_host && i < k) ? bscale_host[i] : 1.0;
+        AA_CHECK_HIP(hipMemcpyAsync(c->qpStats.p, host.data(), off_rows, hipMemcpyHostToDevice, c->stream));
+        AA_CHECK_HIP(hipStreamSynchronize(c->stream));   // host vector goes out of scope
+    } else {
+        AA_REQUIRE(gram_dev != nullptr, AA_ERR_ARG, "QP: no Hessian");
+        unsigned char *b0 = reinterpret_cast<unsigned char *>(c->qpStats.p);
+        hipLaunchKernelGGL(k_qp_setup, dim3(1), dim3(256), 0, c->stream, reinterpret_cast<QpHeader *>(b0),
+                           reinterpret_cast<double *>(b0 + off_A), reinterpret_cast<double *>(b0 + off_A2),
+                           reinterpret_cast<double *>(b0 + off_bs), gram_dev,
+                           (const double *)c->alphaDev.as<double>(), k, KQ, KW, c->KP);
+    }
     unsigned char *base = reinterpret_cast<unsigned char *>(c->qpStats.p);
     QpHeader *hdr = reinterpret_cast<QpHeader *>(base);
     const double *Ad = reinterpret_cast<const double *>(base + off_A);
     const double *A2d = reinterpret_cast<const double *>(base + off_A2);
-    const double *bsd = bscale_host ? reinterpret_cast<const double *>(base + off_bs) : nullptr;
+    const double *bsd = (bscale_host || !A_host) ? reinterpret_cast<const double *>(base + off_bs) : nullptr;
     int *ovf_rows = reinterpret_cast<int *>(base + off_rows);
     QpCarry *ovf = reinterpret_cast<QpCarry *>(base + off_ovf);
 

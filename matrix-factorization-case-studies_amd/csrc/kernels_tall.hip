@@ -1021,7 +1021,7 @@ int tall_setup(Ctx *c)
     AA_CHECK(c->redPartial.alloc(need + 4096));
     AA_CHECK(c->gramOut.alloc((size_t)4 * c->KP * c->KP * sizeof(double)));
     AA_CHECK(c->redOut.alloc((size_t)8 * c->KP * sizeof(double)));
-    AA_CHECK(c->gramPP.alloc((size_t)c->KP * c->KP * sizeof(double)));
+    AA_CHECK(c->gramState.alloc((size_t)3 * c->KP * c->KP * sizeof(double)));
     AA_CHECK(c->scalars.alloc(SC_COUNT * sizeof(double)));
     AA_CHECK(c->proj.alloc(sizeof(ProjState)));
     {   // candidate lists of the projection: [KP][tallBlocks * RS][rows_pb / RS]
@@ -1180,6 +1180,66 @@ int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev)
                        nb, elems, out_dev);
     AA_CHECK_HIP(hipGetLastError());
     if ((c->world > 1 || c->force_comm)) AA_CHECK(comm_allreduce(c, out_dev, elems, 0));
+    return AA_OK;
+}
+
+// dst[i][j] = alpha[i] * src[i][j] * alpha[j]  (KP x KP; M = D Z'Z D of archetypal_analysis.py:
+// 310,330 and the QP Hessian D C K C' D of :387), zero outside k x k
+__global__ __launch_bounds__(256) void k_scale_gram(double *__restrict__ dst,
+                                                    const double *__restrict__ src,
+                                                    const double *__restrict__ alpha, int k, int KP)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= KP * KP) return;
+    const int i = e / KP, j = e % KP;
+    dst[e] = (i < k && j < k) ? alpha[i] * src[e] * alpha[j] : 0.0;
+}
+
+// 0.5 (tr K - 2 tr(D C K Z) + tr(D Z'Z D C K C')) / n   (archetypal_analysis.py:553-556),
+// one thread, fixed order; state = [Z'Z | C K C' | C K Z]
+__global__ void k_aa_cost(const double *__restrict__ state, const double *__restrict__ alpha, int k,
+                          int KP, double trace, double n_global, double *__restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double *ZtZ = state, *CKCt = state + KP * KP, *CKZ = state + 2 * KP * KP;
+    double t1 = 0.0, t2 = 0.0;
+    for (int i = 0; i < k; ++i) t1 += alpha[i] * CKZ[i * KP + i];
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) t2 += alpha[i] * ZtZ[i * KP + j] * alpha[j] * CKCt[j * KP + i];
+    *out = 0.5 * (trace - 2.0 * t1 + t2) / n_global;
+}
+
+__global__ void k_set_scalars(double *__restrict__ sc, double trace, double fnorm)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        sc[SC_TRACE] = trace;
+        sc[SC_FNORM] = fnorm;
+    }
+}
+
+int launch_scale_gram(Ctx *c, double *dst, const double *src)
+{
+    const int elems = c->KP * c->KP;
+    hipLaunchKernelGGL(k_scale_gram, dim3((elems + 255) / 256), dim3(256), 0, c->stream, dst, src,
+                       (const double *)c->alphaDev.as<double>(), c->k, c->KP);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_aa_cost(Ctx *c, double *out_dev)
+{
+    hipLaunchKernelGGL(k_aa_cost, dim3(1), dim3(64), 0, c->stream,
+                       (const double *)c->gramState.as<double>(),
+                       (const double *)c->alphaDev.as<double>(), c->k, c->KP, c->trace,
+                       (double)c->n_global, out_dev);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_set_scalars(Ctx *c, double trace, double fnorm)
+{
+    hipLaunchKernelGGL(k_set_scalars, dim3(1), dim3(64), 0, c->stream, c->scalars.as<double>(), trace, fnorm);
+    AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
 

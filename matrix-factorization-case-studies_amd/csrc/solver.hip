@@ -83,6 +83,7 @@ static int ensure_problem(Ctx *c, int k)
     c->CKCt.assign((size_t)k * k, 0.0);
     c->CKZ.assign((size_t)k * k, 0.0);
     c->grams_valid = false;
+    c->host_grams_valid = false;
     c->gpnh_valid = false;
     c->have_state = false;
     c->dict_inputs_overridden = false;
@@ -129,15 +130,37 @@ static int download_tall(Ctx *c, const DevBuf &src, double *dst, long ld_row, lo
     return AA_OK;
 }
 
-static double host_cost(const Ctx *c)
-{   // archetypal_analysis.py:553-556
-    const int k = c->k;
-    double t1 = 0.0, t2 = 0.0;
-    for (int i = 0; i < k; ++i) t1 += c->alpha[i] * c->CKZ[(size_t)i * k + i];
-    for (int i = 0; i < k; ++i)
-        for (int j = 0; j < k; ++j)
-            t2 += c->alpha[i] * c->ZtZ[(size_t)i * k + j] * c->alpha[j] * c->CKCt[(size_t)j * k + i];
-    return 0.5 * (c->trace - 2.0 * t1 + t2) / (double)c->n_global;
+// device-resident Gram state [Z'Z | C K C' | C K Z]; the host copies follow on demand
+static inline double *dev_ZtZ(Ctx *c) { return c->gramState.as<double>(); }
+static inline double *dev_CKCt(Ctx *c) { return c->gramState.as<double>() + (size_t)c->KP * c->KP; }
+static inline double *dev_CKZ(Ctx *c) { return c->gramState.as<double>() + (size_t)2 * c->KP * c->KP; }
+
+static int sync_host_grams(Ctx *c)
+{
+    if (c->host_grams_valid) return AA_OK;
+    const size_t GS = (size_t)c->KP * c->KP;
+    std::vector<double> tmp(3 * GS);
+    AA_CHECK_HIP(hipMemcpyAsync(tmp.data(), c->gramState.p, tmp.size() * sizeof(double),
+                                hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    std::vector<double> *dst[3] = {&c->ZtZ, &c->CKCt, &c->CKZ};
+    for (int m = 0; m < 3; ++m) {
+        dst[m]->resize((size_t)c->k * c->k);
+        for (int i = 0; i < c->k; ++i)
+            for (int j = 0; j < c->k; ++j) (*dst[m])[(size_t)i * c->k + j] = tmp[m * GS + (size_t)i * c->KP + j];
+    }
+    c->host_grams_valid = true;
+    return AA_OK;
+}
+
+// cost of the current state (archetypal_analysis.py:553-556), evaluated on the device
+static int device_cost(Ctx *c, double *cost)
+{
+    AA_CHECK(c->costDev.alloc(64 * sizeof(double)));
+    AA_CHECK(launch_aa_cost(c, c->costDev.as<double>()));
+    AA_CHECK_HIP(hipMemcpyAsync(cost, c->costDev.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return AA_OK;
 }
 
 static int ensure_trace(Ctx *c)
@@ -151,8 +174,7 @@ static int ensure_trace(Ctx *c)
 // ----------------------------------------------------------------- Gram refresh
 static int refresh_after_dictionary(Ctx *c, bool recompute_products)
 {
-    double *gram = c->gramOut.as<double>();
-    double *gpp = c->gramPP.as<double>();
+    double *gpp = dev_CKCt(c);
     if (c->form == AA_FORM_DATA) {
         if (recompute_products) {
             AA_CHECK(launch_reduce_rows(c, c->Ct.as<double>(), c->P.as<double>(), operandT(c, c->P, c->Pw)));
@@ -167,17 +189,14 @@ static int refresh_after_dictionary(Ctx *c, bool recompute_products)
         AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), c->Ct.as<double>(), gpp));
     }
     c->products_valid = true;
-    AA_CHECK(fetch_gram(c, gpp, c->CKCt));
-    AA_CHECK(launch_gram_tall(c, c->Ct.as<double>(), c->H.as<double>(), gram));
-    AA_CHECK(fetch_gram(c, gram, c->CKZ));
+    AA_CHECK(launch_gram_tall(c, c->Ct.as<double>(), c->H.as<double>(), dev_CKZ(c)));
+    c->host_grams_valid = false;
     return AA_OK;
 }
 
 static int refresh_after_weights(Ctx *c)
 {
-    double *gram = c->gramOut.as<double>();
-    AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), gram));
-    AA_CHECK(fetch_gram(c, gram, c->ZtZ));
+    AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
     if (c->form == AA_FORM_DATA) {
         AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), operandT(c, c->ZtX, c->Qw)));
         AA_CHECK(launch_row_local(c, operandT(c, c->ZtX, c->Qw), c->H.as<double>()));
@@ -186,8 +205,8 @@ static int refresh_after_weights(Ctx *c)
                                                operandT(c, c->ZtX, c->Qw)));
         AA_CHECK(launch_row_local(c, operandT(c, c->ZtX, c->Qw), c->H.as<double>()));
     }
-    AA_CHECK(launch_gram_tall(c, c->Ct.as<double>(), c->H.as<double>(), gram));
-    AA_CHECK(fetch_gram(c, gram, c->CKZ));
+    AA_CHECK(launch_gram_tall(c, c->Ct.as<double>(), c->H.as<double>(), dev_CKZ(c)));
+    c->host_grams_valid = false;
     c->dict_inputs_overridden = false;
     return AA_OK;
 }
@@ -200,7 +219,7 @@ static int prepare(Ctx *c, double *cost)
     AA_CHECK(refresh_after_weights(c));          // ZtZ, H = XX'Z (or KZ), CKZ (overwritten below)
     AA_CHECK(refresh_after_dictionary(c, true)); // CX, C XX', C XX' C', C XX' Z
     c->grams_valid = true;
-    if (cost) *cost = host_cost(c);
+    if (cost) AA_CHECK(device_cost(c, cost));
     return AA_OK;
 }
 
@@ -219,15 +238,9 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
     AA_REQUIRE(sp->max_iterations >= 1, AA_ERR_ARG, "spg max_iterations must be >= 1");
     const int k = c->k, KP = c->KP;
     const bool data = c->form == AA_FORM_DATA;
-    // M = D Z'Z D  (archetypal_analysis.py:310,330)
-    std::vector<double> M((size_t)KP * KP, 0.0);
-    for (int i = 0; i < k; ++i)
-        for (int j = 0; j < k; ++j)
-            M[(size_t)i * KP + j] = c->alpha[i] * c->ZtZ[(size_t)i * k + j] * c->alpha[j];
-    AA_CHECK_HIP(hipMemcpy(c->Mdev.p, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice));
-    AA_CHECK(upload_alpha(c));
-    AA_CHECK(set_scalar(c, SC_TRACE, c->trace));
-    AA_CHECK(set_scalar(c, SC_FNORM, (double)k));     // archetypal_analysis.py:265,277
+    // M = D Z'Z D  (archetypal_analysis.py:310,330), formed on the device
+    AA_CHECK(launch_scale_gram(c, c->Mdev.as<double>(), dev_ZtZ(c)));
+    AA_CHECK(launch_set_scalars(c, c->trace, (double)k));   // archetypal_analysis.py:265,277
 
     double *x = c->Ct.as<double>();
     double *gram = c->gramOut.as<double>();
@@ -254,7 +267,7 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
             AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), x, gram));
         }
     } else {
-        AA_CHECK_HIP(hipMemcpyAsync(gram, c->gramPP.p, GS * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        AA_CHECK_HIP(hipMemcpyAsync(gram, dev_CKCt(c), GS * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
     AA_CHECK(launch_tall_dot_scaled(c, x, c->H.as<double>(), c->alphaDev.as<double>(), SC_S1));
     AA_CHECK(launch_scalar_stage(c, ST_INIT_F, sp, 0));                         // spg.py:156
@@ -298,13 +311,16 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
         AA_CHECK(launch_scalar_stage(c, ST_BB, sp, 0));                         // spg.py:232-244
         AA_CHECK(launch_proj(c, x, c->gn.as<double>(), 1.0, -1, PROJ_RES));     // spg.py:250
         AA_CHECK(launch_scalar_stage(c, ST_CONV, sp, 0));
-        AA_CHECK_HIP(hipMemcpyAsync(sc.data(), c->scalars.p, SC_COUNT * sizeof(double),
-                                    hipMemcpyDeviceToHost, c->stream));
-        AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-        flags = (int)sc[SC_FLAGS];
         if (data) std::swap(c->Gr, c->Gn);
         std::swap(c->gk, c->gn);
-        if (flags & (AA_SPG_FLAG_CONVERGED | AA_SPG_FLAG_MAX_FEVAL)) break;
+        // the host needs the flags only to decide on a further iteration or to report
+        if (st || it + 1 < sp->max_iterations) {
+            AA_CHECK_HIP(hipMemcpyAsync(sc.data(), c->scalars.p, SC_COUNT * sizeof(double),
+                                        hipMemcpyDeviceToHost, c->stream));
+            AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+            flags = (int)sc[SC_FLAGS];
+            if (flags & (AA_SPG_FLAG_CONVERGED | AA_SPG_FLAG_MAX_FEVAL)) break;
+        }
     }
     if (n_iter == sp->max_iterations - 1 && !(flags & AA_SPG_FLAG_CONVERGED))
         flags |= AA_SPG_FLAG_MAX_ITER;                                          // spg.py:278-281
@@ -323,12 +339,9 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
 static int weights_update(Ctx *c, const aa_qp_params *qp, aa_qp_stats *stats)
 {
     AA_REQUIRE(c->have_state && c->grams_valid, AA_ERR_STATE, "weights_update needs prepare() first");
-    const int k = c->k;
-    std::vector<double> A((size_t)k * k);
-    for (int i = 0; i < k; ++i)                                    // archetypal_analysis.py:387
-        for (int j = 0; j < k; ++j) A[(size_t)i * k + j] = c->alpha[i] * c->CKCt[(size_t)i * k + j] * c->alpha[j];
-    AA_CHECK(launch_qp(c, A.data(), c->Gr.as<double>(), 1, c->KP, c->alpha.data(), c->Zt.as<double>(),
-                       c->KP, c->n, k, qp, nullptr, stats));
+    // Hessian D C K C' D (archetypal_analysis.py:387) and b-scale D are set up on the device
+    AA_CHECK(launch_qp(c, nullptr, c->Gr.as<double>(), 1, c->KP, nullptr, c->Zt.as<double>(), c->KP, c->n,
+                       c->k, qp, nullptr, stats, dev_CKCt(c)));
     AA_CHECK(refresh_after_weights(c));
     return AA_OK;
 }
@@ -364,6 +377,9 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "row_local_waves")) {
         AA_REQUIRE(value == 0 || (value >= 8 && value <= 16), AA_ERR_ARG, "row_local_waves must be 0 or 8..16");
         g_row_local_waves = value;
+    } else if (!strcmp(name, "row_local_stagger")) {
+        AA_REQUIRE(value >= 0, AA_ERR_ARG, "row_local_stagger must be >= 0");
+        g_row_local_stagger = value;
     } else if (!strcmp(name, "proj_mode")) {
         AA_REQUIRE(value == 0 || value == 1, AA_ERR_ARG, "proj_mode must be 0 or 1");
         g_proj_mode = value;
@@ -419,7 +435,7 @@ int aa_ctx_destroy(aa_ctx *h)
     comm_destroy(c);
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->redPartial,
-                     &c->gramOut, &c->gramPP, &c->redOut, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters,
+                     &c->gramOut, &c->gramState, &c->costDev, &c->redOut, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters,
                      &c->qpStats};
     for (DevBuf *b : all) b->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -587,8 +603,8 @@ int aa_cost(aa_ctx *h, double *cost)
 {
     AA_REQUIRE(h && cost, AA_ERR_ARG, "null argument");
     AA_REQUIRE(h->c.grams_valid, AA_ERR_STATE, "Gram products not valid");
-    *cost = host_cost(&h->c);
-    return AA_OK;
+    AA_CHECK_HIP(hipSetDevice(h->c.device));
+    return device_cost(&h->c, cost);
 }
 
 int aa_get_grams(aa_ctx *h, double *ZtZ, double *CKCt, double *CKZ, double *trace)
@@ -596,6 +612,8 @@ int aa_get_grams(aa_ctx *h, double *ZtZ, double *CKCt, double *CKZ, double *trac
     AA_REQUIRE(h, AA_ERR_ARG, "null ctx");
     Ctx *c = &h->c;
     AA_REQUIRE(c->grams_valid, AA_ERR_STATE, "Gram products not valid");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_CHECK(sync_host_grams(c));
     const size_t kk = (size_t)c->k * c->k;
     if (ZtZ) memcpy(ZtZ, c->ZtZ.data(), kk * sizeof(double));
     if (CKCt) memcpy(CKCt, c->CKCt.data(), kk * sizeof(double));
@@ -611,7 +629,13 @@ int aa_set_dictionary_inputs(aa_ctx *h, const double *KZ, const double *ZtZ, dou
     AA_REQUIRE(c->have_state, AA_ERR_STATE, "set_state first");
     AA_CHECK_HIP(hipSetDevice(c->device));
     AA_CHECK(upload_tall(c, c->H, KZ, c->k, 1, c->n, c->k));
-    c->ZtZ.assign(ZtZ, ZtZ + (size_t)c->k * c->k);
+    {   // Z'Z goes to the device Gram state (padded to KP x KP)
+        std::vector<double> pad((size_t)c->KP * c->KP, 0.0);
+        for (int i = 0; i < c->k; ++i)
+            for (int j = 0; j < c->k; ++j) pad[(size_t)i * c->KP + j] = ZtZ[(size_t)i * c->k + j];
+        AA_CHECK_HIP(hipMemcpy(dev_ZtZ(c), pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    c->host_grams_valid = false;
     c->trace = trace;
     c->have_trace = true;
     c->dict_inputs_overridden = true;
@@ -638,12 +662,18 @@ int aa_outer_iterations(aa_ctx *h, int n_outer, const aa_spg_params *spg, const 
     AA_REQUIRE(h && spg && qp, AA_ERR_ARG, "null argument");
     Ctx *c = &h->c;
     AA_CHECK_HIP(hipSetDevice(c->device));
+    // costs are evaluated and kept on the device; the host waits once, at the end
+    if (costs && n_outer > 0) AA_CHECK(c->costDev.alloc((size_t)(2 * n_outer + 64) * sizeof(double)));
     for (int i = 0; i < n_outer; ++i) {
         AA_CHECK(dictionary_update(c, spg, nullptr, true));
-        if (costs) costs[2 * i] = host_cost(c);
+        if (costs) AA_CHECK(launch_aa_cost(c, c->costDev.as<double>() + 2 * i));
         AA_CHECK(weights_update(c, qp, nullptr));
-        if (costs) costs[2 * i + 1] = host_cost(c);
+        if (costs) AA_CHECK(launch_aa_cost(c, c->costDev.as<double>() + 2 * i + 1));
     }
+    if (costs && n_outer > 0)
+        AA_CHECK_HIP(hipMemcpyAsync(costs, c->costDev.p, (size_t)2 * n_outer * sizeof(double),
+                                    hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
     return AA_OK;
 }
 

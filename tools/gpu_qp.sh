@@ -1,0 +1,14 @@
+#!/bin/bash
+mkdir -p gpurun_out
+TAG=${1:-x}
+timeout -k 10 200 python tools/qp_latency.py > gpurun_out/qplat_$TAG.log 2>&1 || { echo "latency failed"; tail gpurun_out/qplat_$TAG.log; exit 1; }
+cat gpurun_out/qplat_$TAG.log
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/qpprof_$TAG -- python3 $GRAFT_REPO_ROOT/tools/qp_profile.py > $GRAFT_REPO_ROOT/gpurun_out/qpprof_$TAG.log 2>&1
+echo "rocprof exit=$?"; cat $GRAFT_REPO_ROOT/gpurun_out/qpprof_$TAG.log
+python3 - <<PY
+import csv,glob
+f=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/qpprof_$TAG/*/*kernel_stats.csv")[0]
+for r in list(csv.DictReader(open(f)))[:12]:
+    print("%-50s calls %5s avg %9.1f us tot %8.2f ms"%(r['Name'][:50], r['Calls'], float(r['AverageNs'])/1e3, float(r['TotalDurationNs'])/1e6))
+PY

@@ -19,12 +19,13 @@ def run(label, **opts):
         ctx.dictionary_update(max_iterations=1)
         t = time.perf_counter(); st = ctx.weights_update(); ts.append(time.perf_counter() - t); mx.append(st.max_passes)
     print("%-40s weights_update ms: %s  max passes %s overflow(last) %d" % (label, " ".join("%.2f" % (1e3 * t) for t in ts), mx, st.reserved), flush=True)
-run("waves 1024 (cap 24 refill 24)")
-for w in (1280, 1536, 1563, 2048, 3072):
-    run("waves %d" % w, qp_waves=w)
-run("waves 1563 refill 64", qp_waves=1563, qp_refill_min=64)
-run("waves 1563 cap 16", qp_waves=1563, qp_refill_min=24, qp_pass_cap=16)
-run("waves 1563 cap 32", qp_waves=1563, qp_pass_cap=32)
-run("waves 1536 cap 16", qp_waves=1536, qp_pass_cap=16)
-run("waves 1024 again", qp_waves=1024, qp_pass_cap=24, qp_refill_min=24)
+run("cap 24 refill 24")
+run("cap 16 refill 24", qp_pass_cap=16)
+run("cap 12 refill 24", qp_pass_cap=12)
+run("cap 8 refill 24", qp_pass_cap=8)
+run("cap 32 refill 24", qp_pass_cap=32)
+run("cap 16 refill 16", qp_pass_cap=16, qp_refill_min=16)
+run("cap 16 refill 32", qp_pass_cap=16, qp_refill_min=32)
+run("cap 24 refill 24 again", qp_pass_cap=24, qp_refill_min=24)
+run("wave only", qp_mode=1)
 ctx.close()
