@@ -23,26 +23,24 @@ namespace aa {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- helpers
-template <int KP, int NV>
+template <int KP, int NV, int NT = 256>
 __device__ __forceinline__ void block_col_combine(const double (&v)[NV], unsigned max_mask,
                                                   double *sm, double *dst)
 {
-    constexpr int RS = 256 / KP;
+    constexpr int RS = NT / KP;
     const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
 #pragma unroll
-    for (int a = 0; a < NV; ++a) sm[a * 256 + t] = v[a];
+    for (int a = 0; a < NV; ++a) sm[a * NT + t] = v[a];
     __syncthreads();
-    if (rsub == 0) {
-#pragma unroll
-        for (int a = 0; a < NV; ++a) {
-            double s = sm[a * 256 + comp];
-            if ((max_mask >> a) & 1u) {
-                for (int q = 1; q < RS; ++q) s = fmax(s, sm[a * 256 + q * KP + comp]);
-            } else {
-                for (int q = 1; q < RS; ++q) s += sm[a * 256 + q * KP + comp];
-            }
-            dst[a * KP + comp] = s;
+    if (rsub < NV) {                       // value a = rsub is combined by row-subgroup a
+        const int a = rsub;
+        double s = sm[a * NT + comp];
+        if ((max_mask >> a) & 1u) {
+            for (int q = 1; q < RS; ++q) s = fmax(s, sm[a * NT + q * KP + comp]);
+        } else {
+            for (int q = 1; q < RS; ++q) s += sm[a * NT + q * KP + comp];
         }
+        dst[a * KP + comp] = s;
     }
     __syncthreads();
 }
@@ -51,6 +49,8 @@ __device__ __forceinline__ double load_a(double a_const, const double *scal, int
 {
     return a_slot >= 0 ? scal[a_slot] : a_const;
 }
+
+#define PROJ_NT 1024       // threads per block of the first / finish passes of a projection
 
 // ---------------------------------------------------------------- projection passes
 // w[r][i] = x[r][i] - a * g[r][i]   (g == nullptr => w = x)
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_proj_pass(const double *__restrict__ x,
 //       PROJ_DIR   out = d = max(w-t,0) - x; v0 = <d,g>, v1 = <d,d>, v2 = <d, H alpha>
 //       PROJ_RES   v0 = sum res^2, v3 = max |res|                        (spg.py:250-263)
 template <int KP>
-__global__ __launch_bounds__(256) void k_proj_finish(int mode, const double *__restrict__ x,
+__global__ __launch_bounds__(PROJ_NT) void k_proj_finish(int mode, const double *__restrict__ x,
                                                      const double *__restrict__ g, double a_const,
                                                      const double *__restrict__ scal, int a_slot,
                                                      const double *__restrict__ H,
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256) void k_proj_finish(int mode, const double *__r
                                                      double *__restrict__ out,
                                                      double *__restrict__ partial)
 {
-    __shared__ double sm[4 * 256];
-    constexpr int RS = 256 / KP;
+    __shared__ double sm[4 * PROJ_NT];
+    constexpr int RS = PROJ_NT / KP;
     const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
     const double a = load_a(a_const, scal, a_slot);
     const long rb = (long)blockIdx.x * rows_pb;
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void k_proj_finish(int mode, const double *__r
     if (comp < k) {
         const double th = ps->t[comp];
         const double al = alpha ? alpha[comp] : 1.0;
+#pragma unroll 4
         for (long r = rb + rsub; r < re; r += RS) {
             const long e = r * KP + comp;
             const double xe = x[e];
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void k_proj_finish(int mode, const double *__r
             }
         }
     }
-    block_col_combine<KP, 4>(v, 8u, sm, partial + (size_t)blockIdx.x * 4 * KP);
+    block_col_combine<KP, 4, PROJ_NT>(v, 8u, sm, partial + (size_t)blockIdx.x * 4 * KP);
 }
 
 // ---------------------------------------------------------------- candidate-list projection
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void k_proj_finish(int mode, const double *__r
 //
 // first pass: w = x - a*g (written once), v0 = max w, v1/v2 = sum / count of {w > warm t}
 template <int KP>
-__global__ __launch_bounds__(256) void k_proj_first(const double *__restrict__ x,
+__global__ __launch_bounds__(PROJ_NT) void k_proj_first(const double *__restrict__ x,
                                                     const double *__restrict__ g, double a_const,
                                                     const double *__restrict__ scal, int a_slot,
                                                     long n, long rows_pb, int k, int warm_slot,
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(256) void k_proj_first(const double *__restrict__ x
                                                     double *__restrict__ wout,
                                                     double *__restrict__ partial)
 {
-    __shared__ double sm[3 * 256];
-    constexpr int RS = 256 / KP;
+    __shared__ double sm[3 * PROJ_NT];
+    constexpr int RS = PROJ_NT / KP;
     const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
     const double a = load_a(a_const, scal, a_slot);
     const long rb = (long)blockIdx.x * rows_pb;
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256) void k_proj_first(const double *__restrict__ x
     double v[3] = {-INFINITY, 0.0, 0.0};
     if (comp < k) {
         const double th = warm_slot > 0 ? ps->warm[warm_slot][comp] : INFINITY;
+#pragma unroll 4
         for (long r = rb + rsub; r < re; r += RS) {
             const double w = g ? x[r * KP + comp] - a * g[r * KP + comp] : x[r * KP + comp];
             if (wout) wout[r * KP + comp] = w;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void k_proj_first(const double *__restrict__ x
             }
         }
     }
-    block_col_combine<KP, 3>(v, 1u, sm, partial + (size_t)blockIdx.x * 3 * KP);
+    block_col_combine<KP, 3, PROJ_NT>(v, 1u, sm, partial + (size_t)blockIdx.x * 3 * KP);
 }
 
 // candidates {w > t_lower}: thread (rsub, comp) of block b appends its own rows, in row
@@ -238,13 +240,35 @@ __global__ __launch_bounds__(256) void k_proj_collect(const double *__restrict__
 // one block per column: Michelot's fixed point on the candidate list, started from the
 // lower bound.  Lists of <= PROJ_LDS_CAP candidates are gathered into LDS first.
 #define PROJ_LDS_CAP 2048
+#define PROJ_SPT 8          // segments per thread the register-blocked gather handles
+
+// fixed-order block sum of (s, m) over 256 threads: xor-shuffle tree inside each wave, then
+// the four wave totals in order => deterministic, two barriers
+__device__ __forceinline__ void block_sum_sm(double &s, int &m, double *rs, int *rm)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        m += __shfl_xor(m, o, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        rs[w] = s;
+        rm[w] = m;
+    }
+    __syncthreads();
+    s = ((rs[0] + rs[1]) + rs[2]) + rs[3];
+    m = rm[0] + rm[1] + rm[2] + rm[3];
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ list,
                                                     const int *__restrict__ segcnt, long nseg,
                                                     long segcap, ProjState *__restrict__ ps)
 {
     __shared__ double u[PROJ_LDS_CAP];
-    __shared__ double rs[256];
-    __shared__ int rm[256];
+    __shared__ double rs[4];
+    __shared__ int rm[4];
     __shared__ int scan[256];
     const int comp = blockIdx.x, t = threadIdx.x;
     const int spt = (int)((nseg + 255) / 256);          // consecutive segments per thread
@@ -252,9 +276,19 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
     const int *mycnt = segcnt + (long)comp * nseg;
     const double *mylist = list + (long)comp * nseg * segcap;
 
+    // counts of this thread's segments (all loads in flight together)
+    int cq[PROJ_SPT];
     int mine = 0;
-    for (int q = 0; q < spt; ++q)
-        if (s0 + q < nseg) mine += mycnt[s0 + q];
+    const bool blocked = spt <= PROJ_SPT;
+    if (blocked) {
+#pragma unroll
+        for (int q = 0; q < PROJ_SPT; ++q) cq[q] = (q < spt && s0 + q < nseg) ? mycnt[s0 + q] : 0;
+#pragma unroll
+        for (int q = 0; q < PROJ_SPT; ++q) mine += cq[q];
+    } else {
+        for (int q = 0; q < spt; ++q)
+            if (s0 + q < nseg) mine += mycnt[s0 + q];
+    }
     scan[t] = mine;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {            // inclusive Hillis-Steele scan
@@ -267,12 +301,34 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
     const bool in_lds = total <= PROJ_LDS_CAP;
     if (in_lds) {
         int pos = scan[t] - mine;
-        for (int q = 0; q < spt; ++q)
-            if (s0 + q < nseg) {
-                const int c = mycnt[s0 + q];
-                const double *src = mylist + (s0 + q) * segcap;
-                for (int i = 0; i < c; ++i) u[pos++] = src[i];
+        if (blocked) {
+            // level i copies the i-th candidate of each of the thread's segments: the
+            // PROJ_SPT loads of a level are independent, so one memory latency per level
+            // (segments hold a handful of candidates) instead of one per candidate
+            int base[PROJ_SPT], maxc = 0;
+#pragma unroll
+            for (int q = 0; q < PROJ_SPT; ++q) {
+                base[q] = pos;
+                pos += cq[q];
+                maxc = cq[q] > maxc ? cq[q] : maxc;
             }
+            for (int i = 0; i < maxc; ++i) {
+                double v[PROJ_SPT];
+#pragma unroll
+                for (int q = 0; q < PROJ_SPT; ++q)
+                    v[q] = i < cq[q] ? mylist[(s0 + q) * segcap + i] : 0.0;
+#pragma unroll
+                for (int q = 0; q < PROJ_SPT; ++q)
+                    if (i < cq[q]) u[base[q] + i] = v[q];
+            }
+        } else {
+            for (int q = 0; q < spt; ++q)
+                if (s0 + q < nseg) {
+                    const int c = mycnt[s0 + q];
+                    const double *src = mylist + (s0 + q) * segcap;
+                    for (int i = 0; i < c; ++i) u[pos++] = src[i];
+                }
+        }
     }
     __syncthreads();
 
@@ -300,24 +356,12 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
                         }
                     }
             }
-            rs[t] = s;
-            rm[t] = m;
-            __syncthreads();
-            for (int off = 128; off > 0; off >>= 1) {    // fixed tree => deterministic
-                if (t < off) {
-                    rs[t] += rs[t + off];
-                    rm[t] += rm[t + off];
-                }
-                __syncthreads();
-            }
-            const double S = rs[0];
-            const int M = rm[0];
-            __syncthreads();
+            block_sum_sm(s, m, rs, rm);
             // supports shrink monotonically from a lower bound; a repeat (or a last-bit
             // regrowth) is the fixed point
-            if (M == prev || (prev > 0 && M > prev) || M == 0) conv = 1;
-            if (M > 0 && M != prev) th = (S - 1.0) / (double)M;
-            if (M > 0) prev = M;
+            if (m == prev || (prev > 0 && m > prev) || m == 0) conv = 1;
+            if (m > 0 && m != prev) th = (s - 1.0) / (double)m;
+            if (m > 0) prev = m;
         }
     }
     if (t == 0) {
@@ -1068,6 +1112,16 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
     return AA_OK;
 }
 
+#define TALL_DISPATCH_NT(NTHREADS, KERNEL, ...)                                             \
+    do {                                                                                    \
+        if (c->KP == 32)                                                                    \
+            hipLaunchKernelGGL(KERNEL<32>, dim3(c->tallBlocks), dim3(NTHREADS), 0,          \
+                               c->stream, __VA_ARGS__);                                     \
+        else                                                                                \
+            hipLaunchKernelGGL(KERNEL<64>, dim3(c->tallBlocks), dim3(NTHREADS), 0,          \
+                               c->stream, __VA_ARGS__);                                     \
+    } while (0)
+
 #define TALL_DISPATCH(KERNEL, ...)                                                          \
     do {                                                                                    \
         if (c->KP == 32)                                                                    \
@@ -1097,7 +1151,7 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     if (lists) {
         const int RS = 256 / c->KP;
         const long nseg = (long)c->tallBlocks * RS, segcap = rpb / RS;
-        TALL_DISPATCH(k_proj_first, x, g, a_const, scal, a_slot, c->n, rpb, c->k,
+        TALL_DISPATCH_NT(PROJ_NT, k_proj_first, x, g, a_const, scal, a_slot, c->n, rpb, c->k,
                       c->projWarm[mode] ? mode : 0, (const ProjState *)ps, wbuf, part);
         AA_CHECK(finalize_and_post(c, 3, 1u, POST_FIRST, 0, 0, false));
         TALL_DISPATCH(k_proj_collect, wsrc, c->n, rpb, c->k, (const ProjState *)ps,
@@ -1128,7 +1182,7 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     double *out = nullptr;
     if (mode == PROJ_FEAS) out = const_cast<double *>(x);
     if (mode == PROJ_DIR) out = c->Dt.as<double>();
-    TALL_DISPATCH(k_proj_finish, mode, x, g, a_const, scal, a_slot, c->H.as<double>(),
+    TALL_DISPATCH_NT(PROJ_NT, k_proj_finish, mode, x, g, a_const, scal, a_slot, c->H.as<double>(),
                   c->alphaDev.as<double>(), c->n, rpb, c->k, (const ProjState *)ps, out, part);
     AA_CHECK(finalize_and_post(c, 4, 8u, POST_FIN, mode, 0, false));
     if (mode > 0) c->projWarm[mode] = true;
@@ -1196,17 +1250,28 @@ __global__ __launch_bounds__(256) void k_scale_gram(double *__restrict__ dst,
 }
 
 // 0.5 (tr K - 2 tr(D C K Z) + tr(D Z'Z D C K C')) / n   (archetypal_analysis.py:553-556),
-// one thread, fixed order; state = [Z'Z | C K C' | C K Z]
-__global__ void k_aa_cost(const double *__restrict__ state, const double *__restrict__ alpha, int k,
-                          int KP, double trace, double n_global, double *__restrict__ out)
+// one block, fixed summation tree; state = [Z'Z | C K C' | C K Z]
+__global__ __launch_bounds__(256) void k_aa_cost(const double *__restrict__ state,
+                                                 const double *__restrict__ alpha, int k, int KP,
+                                                 double trace, double n_global,
+                                                 double *__restrict__ out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ double sm[256];
     const double *ZtZ = state, *CKCt = state + KP * KP, *CKZ = state + 2 * KP * KP;
-    double t1 = 0.0, t2 = 0.0;
-    for (int i = 0; i < k; ++i) t1 += alpha[i] * CKZ[i * KP + i];
-    for (int i = 0; i < k; ++i)
-        for (int j = 0; j < k; ++j) t2 += alpha[i] * ZtZ[i * KP + j] * alpha[j] * CKCt[j * KP + i];
-    *out = 0.5 * (trace - 2.0 * t1 + t2) / n_global;
+    const int t = threadIdx.x;
+    double acc = 0.0;
+    for (int e = t; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        acc += alpha[i] * ZtZ[i * KP + j] * alpha[j] * CKCt[j * KP + i];
+    }
+    if (t < k) acc -= 2.0 * (alpha[t] * CKZ[t * KP + t]);
+    sm[t] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) sm[t] += sm[t + o];
+        __syncthreads();
+    }
+    if (t == 0) *out = 0.5 * (trace + sm[0]) / n_global;
 }
 
 __global__ void k_set_scalars(double *__restrict__ sc, double trace, double fnorm)
@@ -1228,7 +1293,7 @@ int launch_scale_gram(Ctx *c, double *dst, const double *src)
 
 int launch_aa_cost(Ctx *c, double *out_dev)
 {
-    hipLaunchKernelGGL(k_aa_cost, dim3(1), dim3(64), 0, c->stream,
+    hipLaunchKernelGGL(k_aa_cost, dim3(1), dim3(256), 0, c->stream,
                        (const double *)c->gramState.as<double>(),
                        (const double *)c->alphaDev.as<double>(), c->k, c->KP, c->trace,
                        (double)c->n_global, out_dev);

@@ -1,0 +1,24 @@
+#!/bin/bash
+# scratch: SQ-level counters of the GEMM kernels (one --pmc pass per counter group)
+mkdir -p gpurun_out
+cd /tmp && export TMPDIR=/tmp
+i=0
+for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM"; do
+  i=$((i+1))
+  timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcsq_$i -- python3 $GRAFT_REPO_ROOT/tools/sweep_row_local.py > $GRAFT_REPO_ROOT/gpurun_out/pmcsq_$i.log 2>&1
+  echo "pmc group $i ($C) exit=$?"
+done
+cd $GRAFT_REPO_ROOT
+python3 - <<'PY'
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmcsq_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][-40:]
+        if "row_local" in k or "reduce_rows" in k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in agg.items():
+    print("==", k)
+    for c, v in sorted(d.items()):
+        print("   %-34s n=%3d mean=%16.1f" % (c, len(v), sum(v) / len(v)))
+PY

@@ -9,7 +9,7 @@ X = bench.synthetic_rows(0, n); C0, Z0 = bench.start_factors(n, k)
 ctx = _backend.Context(dtype="float32")
 ctx.set_data(X); ctx.set_state(C0, Z0, np.ones(k)); ctx.prepare()
 ref = None
-for v, w in ((4, 0), (8, 0), (8, 14), (8, 16), (2, 0), (8, 13), (4, 0)):
+for v, w in ((4, 0), (8, 0), (8, 16)):
     _backend.set_option("row_local_variant", v); _backend.set_option("row_local_waves", w)
     ctx.time_kernel(1, 5)
     ms = ctx.time_kernel(1, 40)
@@ -18,15 +18,5 @@ for v, w in ((4, 0), (8, 0), (8, 14), (8, 16), (2, 0), (8, 13), (4, 0)):
     if ref is None: ref = g
     print("variant %d waves %d: %.4f ms  %.2f TB/s   max|dCKZ| %.2e" % (v, w, ms, n * p * 4 / ms / 1e9, np.abs(g - ref).max()), flush=True)
 print("reduce_rows: %.4f ms" % ctx.time_kernel(0, 40))
-_backend.set_option("row_local_variant", 4); _backend.set_option("row_local_waves", 0)
-import time
-for mode in (1, 0, 1, 0):
-    _backend.set_option("proj_mode", mode)
-    ctx.set_state(C0, Z0, np.ones(k)); ctx.prepare()
-    ctx.outer_iterations(6, dict(max_iterations=1), {})
-    t0 = time.perf_counter(); ts = []
-    for it in range(10):
-        t1 = time.perf_counter(); st = ctx.dictionary_update(max_iterations=1); ts.append(time.perf_counter() - t1); ctx.weights_update()
-    print("proj_mode %d: dictionary_update ms %s  f=%.10f" % (mode, " ".join("%.2f" % (1e3 * x) for x in ts), st.f), flush=True)
-_backend.set_option("proj_mode", 0)
+_backend.set_option("row_local_variant", -1); _backend.set_option("row_local_waves", 0)
 ctx.close()
