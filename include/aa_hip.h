@@ -104,6 +104,10 @@ int aa_device_count(int *count);
  *   "qp_refill_min"     1..64  idle lanes of a wave that trigger pulling new samples
  *   "qp_waves"          >= 1   most waves (64 samples each) the lane-per-sample kernel runs
  *                               at once; samples beyond that are pulled in as lanes free up
+ *   "qp_overlap_tail"   0|1    1: the wave-per-sample kernel of the stragglers runs on a side
+ *                               stream while Z'X is accumulated (float32 data); the rows it
+ *                               changes enter Z'X as a rank-m correction.  Default 0: measured
+ *                               neutral, the stragglers run 2x slower next to the GEMM
  *   "qp_mode"           0|1    0: lane-per-sample kernel then wave-per-sample kernel;
  *                               1: wave-per-sample kernel for every sample */
 int aa_set_option(const char *name, int value);
@@ -226,7 +230,8 @@ int aa_gpnh_residual_cost(aa_ctx *ctx, double *cost);
 /* ------------------------------------------------------------ measurement */
 /* Time `reps` launches of one hot-path GEMM kernel with HIP events on the
  * context's stream.  which: 0 = reduce-over-rows (C X, X'Z; k x p out),
- * 1 = row-local (CX X', X X'Z; n x k out), 2 = QP weights kernel on current state.
+ * 1 = row-local (CX X', X X'Z; n x k out), 2 = a plain streaming read of X (the read
+ * bandwidth the memory system delivers; reference point for the roofline).
  * ms_avg = average duration of one launch in milliseconds. */
 int aa_time_kernel(aa_ctx *ctx, int which, int reps, double *ms_avg);
 

@@ -127,6 +127,11 @@ def load_library():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # tuning knobs from the environment: AA_HIP_OPTIONS="name=value,name=value" (aa_set_option)
+    for item in filter(None, os.environ.get("AA_HIP_OPTIONS", "").split(",")):
+        name, _, value = item.partition("=")
+        if lib.aa_set_option(name.strip().encode(), int(value)) != 0:
+            raise RuntimeError("AA_HIP_OPTIONS: bad option %r" % item)
     return lib
 
 

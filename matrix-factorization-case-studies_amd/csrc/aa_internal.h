@@ -128,6 +128,11 @@ struct Ctx {
     int device = 0;
     int dtype = AA_F64;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;             // side stream: the QP's straggler kernel
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    bool qp_tail_pending = false;              // stragglers run on stream2, results in tmpTall by slot
+    const int *qp_tail_rows = nullptr;         // device: overflow slot -> row
+    const unsigned int *qp_tail_count = nullptr;   // device: number of overflow slots
     Comm *comm = nullptr;
     int rank = 0, world = 1;
     bool force_comm = false;                   // AA_FORCE_RCCL=1: use RCCL even with one rank
@@ -182,8 +187,15 @@ struct Ctx {
 // Also refreshes the T-typed operand copy outT (may alias out when T == double).
 int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *outT,
                        bool main_only = false);
+// second stage of the split-row reduction (after a main_only launch): sums the slab partials
+// plus `extra_slabs` further slabs appended by launch_reduce_rows_fixup
+int launch_reduce_rows_finish(Ctx *c, double *out_wide, void *outT, int extra_slabs);
+// appends sum_s (znew[s] - Z[rows[s]]) x_{rows[s]}' as QP_FIX_SLABS slabs of partials
+int launch_reduce_rows_fixup(Ctx *c, const unsigned int *count_dev, const int *rows_dev,
+                             const double *zslot, const double *Ztall);
 // out[n_pad][KP] (double) = sum_c X[r][c] * B[i][c];  B wide, T-typed.
 int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall);
+int launch_stream_probe(Ctx *c);   // measurement: one streaming read of X
 
 // ------------------------------------------------------------------ kernels_tall.hip
 int tall_setup(Ctx *c);
@@ -217,17 +229,28 @@ int launch_residual_cost(Ctx *c, const double *Ztall, const double *Wwide, const
 int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, long stride_t,
               const double *bscale_host /*k or null*/, double *Ztall, int ldz, long n, int k,
               const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats,
-              const double *gram_dev = nullptr);
+              const double *gram_dev = nullptr, bool defer_tail = false);
+// defer_tail: the wave-per-sample kernel of the stragglers runs on the side stream and leaves
+// its results in tmpTall, indexed by overflow slot (c->qp_tail_pending); the caller overlaps
+// the reduce-over-rows pass of Z'X with it, then calls launch_qp_tail_fixup: it waits for
+// the stragglers, adds sum_s (z_new - z_old)_s x_s' as QP_FIX_SLABS extra slabs of the
+// split-row partials (device-side count, no host synchronisation) and commits z_new to Z.
+#define QP_FIX_SLABS 32
+int launch_qp_tail_fixup(Ctx *c, double *Ztall);
 int launch_simplex_rows_generic(hipStream_t s, const double *in, double *out, long rows, long cols);
 
 extern int g_proj_mode;           // kernels_tall.hip
 extern int g_row_local_variant;   // kernels_gemm.hip
 extern int g_row_local_waves;     // kernels_gemm.hip
 extern int g_row_local_stagger;   // kernels_gemm.hip
+extern int g_reduce_rows_unroll;  // kernels_gemm.hip
+extern int g_reduce_rows_blocks;  // kernels_gemm.hip
 extern int g_qp_pass_cap;         // kernels_qp.hip
 extern int g_qp_mode;             // kernels_qp.hip
 extern int g_qp_refill_min;       // kernels_qp.hip
 extern int g_qp_waves;            // kernels_qp.hip
+extern int g_qp_profile;          // kernels_qp.hip
+extern int g_qp_overlap_tail;     // kernels_qp.hip
 
 // ------------------------------------------------------------------ comm.hip
 int comm_unique_id(void *id128);

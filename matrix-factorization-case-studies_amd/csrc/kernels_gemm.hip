@@ -33,14 +33,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // B-operand lane l = X[row r0+2u+(l>>5)][c0 + 4*(l&31) + m]  (one dwordx4 load feeds
 // the four MFMAs m = 0..3, whose output columns are c0 + 4*j + m).
 // ---------------------------------------------------------------------------
-template <int NCT>
+template <int NCT, int U>
 __global__ __launch_bounds__(256) void k_reduce_rows_f32(const float *__restrict__ X, long ldx,
                                                          const double *__restrict__ A,
                                                          long rows_per_slab, long n_pad, int p_pad,
                                                          float *__restrict__ partial)
 {
     constexpr int KP = 32 * NCT;
-    constexpr int U = 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c0 = (blockIdx.x * 4 + wave) * 128;
     if (c0 >= p_pad) return;   // wave-uniform; the kernel has no barriers
@@ -555,26 +554,113 @@ __global__ __launch_bounds__(256) void k_row_local_f64(const double *__restrict_
     for (int i = 0; i < KQ; ++i) out[(r0 + row) * KP + q * KQ + i] = acc[i];
 }
 
+// rank-m correction of a reduce-over-rows result whose tall operand changed in m rows after
+// the pass had read it (the QP's stragglers finish while Z'X is being accumulated):
+//   extra[g][i][c] = sum over the slots s of slab g of (znew[s][i] - Z[rows[s]][i]) * X[rows[s]][c]
+// written as G = gridDim.y further slabs of the split-row partials.  The slot count lives on
+// the device; slab g takes the contiguous slot range [g*chunk, (g+1)*chunk).  Same MFMA
+// mapping as k_reduce_rows_f32 (a wave owns a 128-column strip), with the rows gathered: a
+// wave reads 64 row indices at a time (one coalesced load) and hands them out with
+// ds_bpermute, so a step of 2*U slots costs one memory latency (X rows and z rows together).
+__global__ __launch_bounds__(256) void k_reduce_rows_fixup_f32(const float *__restrict__ X, long ldx,
+                                                               const unsigned int *__restrict__ count_dev,
+                                                               const int *__restrict__ rows,
+                                                               const double *__restrict__ zslot,
+                                                               const double *__restrict__ Ztall,
+                                                               int p_pad, float *__restrict__ extra)
+{
+    constexpr int KP = 32, U = 8;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = (blockIdx.x * 4 + wave) * 128;
+    if (c0 >= p_pad) return;   // wave-uniform; the kernel has no barriers
+    const int h = lane >> 5, j = lane & 31;
+    const long count = (long)*count_dev, G = gridDim.y;
+    long chunk = (count + G - 1) / G;
+    chunk = (chunk + 2 * U - 1) / (2 * U) * (2 * U);
+    const long s_begin = (long)blockIdx.y * chunk;
+    long s_end = s_begin + chunk;
+    if (s_end > count) s_end = count;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+    for (long b = s_begin; b < s_end; b += 64) {
+        const int mine = (b + lane < s_end) ? rows[b + lane] : 0;
+        for (int q = 0; q < 64 && b + q < s_end; q += 2 * U) {
+            f32x4 xv[U];
+            float av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int sl = q + 2 * u + h;                 // slot of this lane's half
+                const long slot = b + sl;
+                const bool valid = slot < s_end;
+                const long row = __shfl(mine, sl & 63, 64);   // 0 for slots past the end
+                xv[u] = *reinterpret_cast<const f32x4 *>(X + row * ldx + c0 + 4 * j);
+                av[u] = valid ? (float)(zslot[slot * KP + j] - Ztall[row * KP + j]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], xv[u][m], acc[m], 0, 0, 0);
+        }
+    }
+    float *out = extra + (size_t)blockIdx.y * KP * p_pad;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int comp = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        f32x4 v = {acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]};
+        *reinterpret_cast<f32x4 *>(out + (size_t)comp * p_pad + c0 + 4 * j) = v;
+    }
+}
+
+// measurement only: stream X once with 16-byte loads, no arithmetic to speak of -- the
+// read bandwidth the memory system delivers to a kernel of this shape (aa_time_kernel 2)
+__global__ __launch_bounds__(256) void k_stream_probe(const f32x4 *__restrict__ x, long n16,
+                                                      float *__restrict__ sink)
+{
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const f32x4 a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
+        acc += (a + b) + (c + d);
+    }
+    for (; i < n16; i += stride) acc += x[i];
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = 1.f;   // keeps the loads alive
+}
+
+int launch_stream_probe(Ctx *c)
+{
+    const long bytes = (long)c->n_pad * c->p_pad * (c->dtype == AA_F32 ? 4 : 8);
+    hipLaunchKernelGGL(k_stream_probe, dim3(4096), dim3(256), 0, c->stream,
+                       reinterpret_cast<const f32x4 *>(c->X.p), bytes / 16, c->partial.as<float>());
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
 // ---------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------
 int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *outT, bool main_only)
 {
-    const long elems = (long)c->KP * c->p_pad;
     dim3 block(256);
     if (c->dtype == AA_F32) {
         dim3 grid((unsigned)((c->p_pad + 511) / 512), (unsigned)c->nslab);
         float *part = c->partial.as<float>();
-        if (c->KP == 32)
-            hipLaunchKernelGGL(k_reduce_rows_f32<1>, grid, block, 0, c->stream, c->X.as<float>(),
-                               c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
-        else
-            hipLaunchKernelGGL(k_reduce_rows_f32<2>, grid, block, 0, c->stream, c->X.as<float>(),
-                               c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
-        float *oT = ((c->world > 1 || c->force_comm)) ? nullptr : reinterpret_cast<float *>(outT);
-        if (!main_only)
-            hipLaunchKernelGGL((k_reduce_partials<float, float>), dim3((unsigned)((elems + 255) / 256)),
-                           block, 0, c->stream, part, c->nslab, elems, out_wide, oT);
+#define RRL(NCTV, UV)                                                                         \
+    hipLaunchKernelGGL((k_reduce_rows_f32<NCTV, UV>), grid, block, 0, c->stream, c->X.as<float>(), \
+                       c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part)
+        if (c->KP == 32) {
+            if (g_reduce_rows_unroll == 8) RRL(1, 8);
+            else RRL(1, 4);
+        } else {
+            RRL(2, 4);
+        }
+#undef RRL
     } else {
         dim3 grid((unsigned)((c->p_pad + 255) / 256), (unsigned)c->nslab);
         double *part = c->partial.as<double>();
@@ -584,19 +670,45 @@ int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *out
         else
             hipLaunchKernelGGL(k_reduce_rows_f64<64>, grid, block, 0, c->stream, c->X.as<double>(),
                                c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
-        double *oT = ((c->world > 1 || c->force_comm) || outT == (void *)out_wide) ? nullptr
-                                                                : reinterpret_cast<double *>(outT);
-        if (!main_only)
-            hipLaunchKernelGGL((k_reduce_partials<double, double>),
-                           dim3((unsigned)((elems + 255) / 256)), block, 0, c->stream, part,
-                           c->nslab, elems, out_wide, oT);
     }
     AA_CHECK_HIP(hipGetLastError());
     if (main_only) return AA_OK;
+    return launch_reduce_rows_finish(c, out_wide, outT, 0);
+}
+
+int launch_reduce_rows_finish(Ctx *c, double *out_wide, void *outT, int extra_slabs)
+{
+    const long elems = (long)c->KP * c->p_pad;
+    const long slabs = c->nslab + extra_slabs;
+    dim3 block(256), grid((unsigned)((elems + 255) / 256));
+    if (c->dtype == AA_F32) {
+        float *oT = ((c->world > 1 || c->force_comm)) ? nullptr : reinterpret_cast<float *>(outT);
+        hipLaunchKernelGGL((k_reduce_partials<float, float>), grid, block, 0, c->stream,
+                           (const float *)c->partial.as<float>(), slabs, elems, out_wide, oT);
+    } else {
+        double *oT = ((c->world > 1 || c->force_comm) || outT == (void *)out_wide) ? nullptr
+                                                                : reinterpret_cast<double *>(outT);
+        hipLaunchKernelGGL((k_reduce_partials<double, double>), grid, block, 0, c->stream,
+                           (const double *)c->partial.as<double>(), slabs, elems, out_wide, oT);
+    }
+    AA_CHECK_HIP(hipGetLastError());
     if ((c->world > 1 || c->force_comm)) {
         AA_CHECK(comm_allreduce(c, out_wide, elems, 0));
         if (outT && outT != (void *)out_wide) AA_CHECK(launch_wide_to_T(c, out_wide, outT));
     }
+    return AA_OK;
+}
+
+int launch_reduce_rows_fixup(Ctx *c, const unsigned int *count_dev, const int *rows_dev,
+                             const double *zslot, const double *Ztall)
+{
+    AA_REQUIRE(c->KP == 32 && c->dtype == AA_F32, AA_ERR_STATE, "tail fix-up: float32 data, k <= 32");
+    const size_t slab_elems = (size_t)c->KP * c->p_pad;
+    dim3 grid((unsigned)((c->p_pad + 511) / 512), QP_FIX_SLABS), block(256);
+    hipLaunchKernelGGL(k_reduce_rows_fixup_f32, grid, block, 0, c->stream, c->X.as<float>(), c->p_pad,
+                       count_dev, rows_dev, zslot, Ztall, (int)c->p_pad,
+                       c->partial.as<float>() + (size_t)c->nslab * slab_elems);
+    AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
 
@@ -605,6 +717,8 @@ int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *out
 // 4 (default) = 128, 5 = 32 double-buffered, 6 = 128 double-buffered, 7 = 32;
 // 8: wave-streaming (wave-private X tiles, B slabs shared per block).  aa_set_option.
 int g_row_local_variant = -1;   // -1: by size (8 from 32768 rows per GPU, else 4)
+int g_reduce_rows_unroll = 4;  // row pairs per software-pipeline half step (4 or 8; k <= 32)
+int g_reduce_rows_blocks = 512; // target block count of the reduce-over-rows kernel
 int g_row_local_stagger = 0;   // variant 8: column-slab offset between consecutive blocks
 int g_row_local_waves = 0;     // variant 8: waves per block (0 = one block per CU)
 static int row_local_variant(const Ctx *c)

@@ -109,6 +109,12 @@ struct QpHeader {
     unsigned int pad;
 };
 
+// Optional cycle accounting of the lane-per-sample kernel (aa_set_option("qp_profile", 1));
+// lives at byte 64 of the scratch buffer, printed by the host after the update.
+struct QpDebug {
+    unsigned long long trips, refills, cyc_total, cyc_proj, cyc_matvec, waves, cyc_step, cyc_fin;
+};
+
 // ---------------------------------------------------------------------------
 // phase 1: one lane per sample, A broadcast from LDS.
 // ---------------------------------------------------------------------------
@@ -236,20 +242,36 @@ __device__ __forceinline__ void qp_matvec_mfma(const double (&Breg)[KQ / 16][KQ 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // two sample tiles x NT component tiles = 2*NT independent accumulators in flight: a
+    // single accumulator would serialise the MFMAs on their result latency
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        double a[NS];
+    for (int mp = 0; mp < 2; ++mp) {
+        double a0[NS], a1[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) a[s] = vbuf[(4 * s + lr) * QP_VS + 16 * mt + lc];
+        for (int s = 0; s < NS; ++s) {
+            a0[s] = vbuf[(4 * s + lr) * QP_VS + 32 * mp + lc];
+            a1[s] = vbuf[(4 * s + lr) * QP_VS + 32 * mp + 16 + lc];
+        }
+        f64x4 acc0[NT], acc1[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], Breg[nt][s], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) abuf[(16 * nt + lc) * QP_AS + 16 * mt + lr + 4 * r] = acc[r];
+            acc0[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+            acc1[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
         }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc0[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], Breg[nt][s], acc0[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], Breg[nt][s], acc1[nt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                abuf[(16 * nt + lc) * QP_AS + 32 * mp + lr + 4 * r] = acc0[nt][r];
+                abuf[(16 * nt + lc) * QP_AS + 32 * mp + 16 + lr + 4 * r] = acc1[nt][r];
+            }
     }
     // one wave per block: LDS executes a wave's operations in order; the barrier only
     // keeps the compiler from moving the column reads above the tile writes
@@ -268,7 +290,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                                            aa_qp_params p, int pass_cap, int *__restrict__ iters,
                                            QpHeader *__restrict__ hdr,
                                            int *__restrict__ ovf_rows, QpCarry *__restrict__ ovf,
-                                           int g_refill)
+                                           int g_refill, QpDebug *__restrict__ dbg)
 {
     constexpr bool MFMA = KQ >= 16;
     constexpr int VS = MFMA ? QP_VS : 64;              // row stride of the direction buffer
@@ -293,11 +315,13 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
     double x[KQ], g[KQ], Ad[KQ];
     const int refill_min = g_refill;
     double f = 0.0, alpha = 1.0, fmem[QP_MAXMEM];
-    double delta = 0.0, dd = 0.0;
+    double delta = 0.0, dd = 0.0, td = 0.0, alpha_d = 0.0;   // direction: d = P(x - alpha_d g) - x
     int n_iter = 0, n_feval = 0;
     long row = -1;
     bool active = false, exhausted = false;
-    typename QpMask<KQ>::type support = 0;   // support of this sample's latest projection
+    // supports of this sample's latest direction / residual projection (the two differ by
+    // the step: x - alpha g against x - g), each the warm start of the next one of its kind
+    typename QpMask<KQ>::type support = 0, support_r = 0;
     const int mem = p.memory < 1 ? 1 : (p.memory > QP_MAXMEM ? QP_MAXMEM : p.memory);
 #pragma unroll
     for (int i = 0; i < KQ; ++i) vl[i * VS] = 0.0;
@@ -307,8 +331,13 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
         else qp_matvec<KQ>(AsT, vl, k, out);
     };
 
+    long long pc_proj = 0, pc_mv = 0, pc_refills = 0, pc_trips = 0, pc_step = 0, pc_fin = 0;
+    const long long pc_start = dbg ? clock64() : 0;
+#define QP_TIC(var) const long long var = dbg ? clock64() : 0
+#define QP_TOC(acc, var) if (dbg) acc += clock64() - var
     // the trip bound is a watchdog only (each sample needs <= max_iterations trips)
     for (long trip = 0; trip < (1L << 24); ++trip) {
+        pc_trips = trip;
         // Refill idle lanes in batches: the start-up of a sample (strided loads, a
         // projection and a mat-vec) is executed by the whole wave, so it is only entered
         // when enough lanes are waiting (or nothing else is left to do).
@@ -328,6 +357,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                 }
                 support = 0;
                 const double t0 = qp_project_threshold<KQ>(x, g, 0.0, k, support);
+                support_r = support;
 #pragma unroll
                 for (int i = 0; i < KQ; ++i) x[i] = (i < k) ? fmax(x[i] - t0, 0.0) : 0.0;
 #pragma unroll
@@ -337,7 +367,10 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             }
         }
         if (__any(starting)) {                         // wave-uniform: the mat-vec is collective
+            pc_refills += 1;
+            QP_TIC(tm0);
             matvec(Ad);
+            QP_TOC(pc_mv, tm0);
             if (starting) {
                 double xg = 0.0, xb = 0.0;
 #pragma unroll
@@ -357,13 +390,14 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             }
         }
         if (!__any(active)) break;
+        QP_TIC(tp0);
         if (active) {
             // ---- one pass of the loop at spg.py:318-396, up to the search direction
             if (n_iter == 0) {
                 if (p.alpha_min <= p.alpha0 && p.alpha0 <= p.alpha_max) {
                     alpha = p.alpha0;
                 } else {
-                    const double t1 = qp_project_threshold<KQ>(x, g, 1.0, k, support);
+                    const double t1 = qp_project_threshold<KQ>(x, g, 1.0, k, support_r);
                     double ainv = 0.0;
 #pragma unroll
                     for (int i = 0; i < KQ; ++i)
@@ -372,22 +406,32 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                     alpha = fmin(fmax(p.alpha_min, 1.0 / ainv), p.alpha_max);
                 }
             }
-            const double td = qp_project_threshold<KQ>(x, g, alpha, k, support);
+            td = qp_project_threshold<KQ>(x, g, alpha, k, support);
+            alpha_d = alpha;
             delta = 0.0;
             dd = 0.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
-                const double di = (i < k) ? fmax(x[i] - alpha * g[i] - td, 0.0) - x[i] : 0.0;
-                vl[i * VS] = di;                 // the direction lives in LDS only
+                const double di = (i < k) ? fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i] : 0.0;
+                vl[i * VS] = di;                 // to LDS for the mat-vec; recomputed below
                 delta = fma(di, g[i], delta);
                 dd = fma(di, di, dd);
             }
         }
+        QP_TOC(pc_proj, tp0);
+        QP_TIC(tm1);
         matvec(Ad);                                    // collective (idle lanes: stale columns)
+        QP_TOC(pc_mv, tm1);
+        QP_TIC(ts0);
         if (active) {
+            // d is recomputed from (x, g, alpha_d, td) -- the same three operations, so the same
+            // bits -- instead of read back from LDS (32 dependent-latency reads per use)
             double dAd = 0.0;
 #pragma unroll
-            for (int i = 0; i < KQ; ++i) dAd = fma(vl[i * VS], Ad[i], dAd);
+            for (int i = 0; i < KQ; ++i) {
+                const double di = (i < k) ? fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i] : 0.0;
+                dAd = fma(di, Ad[i], dAd);
+            }
             // non-monotone reference value (spg.py:341-344): roll, store, nanmax
 #pragma unroll
             for (int i = QP_MAXMEM - 1; i > 0; --i)
@@ -412,7 +456,8 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             }
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
-                x[i] = fma(lam, vl[i * VS], x[i]);
+                const double di = (i < k) ? fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i] : 0.0;
+                x[i] = fma(lam, di, x[i]);
                 g[i] = fma(lam, Ad[i], g[i]);
             }
             const double sksk = lam * lam * dd;
@@ -421,7 +466,11 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             f = f_new;
             n_feval += 1;
 
-            const double tr = qp_project_threshold<KQ>(x, g, 1.0, k, support);
+            QP_TOC(pc_step, ts0);
+            QP_TIC(tp1);
+            const double tr = qp_project_threshold<KQ>(x, g, 1.0, k, support_r);
+            QP_TOC(pc_proj, tp1);
+            QP_TIC(tf0);
             double r2 = 0.0, rinf = 0.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i)
@@ -454,8 +503,21 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                 }
                 active = false;
             }
+            QP_TOC(pc_fin, tf0);
         }
     }
+    if (dbg && threadIdx.x == 0) {
+        atomicAdd(&dbg->cyc_step, (unsigned long long)pc_step);
+        atomicAdd(&dbg->cyc_fin, (unsigned long long)pc_fin);
+        atomicAdd(&dbg->trips, (unsigned long long)(pc_trips + 1));
+        atomicAdd(&dbg->refills, (unsigned long long)pc_refills);
+        atomicAdd(&dbg->cyc_total, (unsigned long long)(clock64() - pc_start));
+        atomicAdd(&dbg->cyc_proj, (unsigned long long)pc_proj);
+        atomicAdd(&dbg->cyc_matvec, (unsigned long long)pc_mv);
+        atomicAdd(&dbg->waves, 1ull);
+    }
+#undef QP_TIC
+#undef QP_TOC
 }
 
 // ---------------------------------------------------------------------------
@@ -475,6 +537,14 @@ __device__ __forceinline__ double qw_dpp(double old, double v)
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// row shift with zero fill (bound_ctrl): no `old` operand to materialise
+template <int CTRL>
+__device__ __forceinline__ double qw_dpp_z(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double qw_readlane(double v, int l)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
@@ -484,13 +554,18 @@ __device__ __forceinline__ double qw_readlane(double v, int l)
 // HALF (k <= 32): lanes 32..63 MIRROR lanes 0..31 (lane l+32 holds component l too), the
 // total of a half needs one step less (lane 31 / lane 63), and two different quantities
 // -- one per half -- are reduced by the same five instructions.
+__device__ __forceinline__ double qw_scan_rows(double v)      // inclusive scan inside rows of 16
+{
+    v += qw_dpp_z<0x111>(v);   // row_shr:1
+    v += qw_dpp_z<0x112>(v);   // row_shr:2
+    v += qw_dpp_z<0x114>(v);   // row_shr:4
+    v += qw_dpp_z<0x118>(v);   // row_shr:8
+    return v;
+}
 template <bool HALF>
 __device__ __forceinline__ double qw_sum(double v)
 {
-    v += qw_dpp<0x111, 0xf>(0.0, v);   // row_shr:1
-    v += qw_dpp<0x112, 0xf>(0.0, v);   // row_shr:2
-    v += qw_dpp<0x114, 0xf>(0.0, v);   // row_shr:4
-    v += qw_dpp<0x118, 0xf>(0.0, v);   // row_shr:8
+    v = qw_scan_rows(v);
     v += qw_dpp<0x142, 0xa>(0.0, v);   // row_bcast:15 -> rows 1, 3
     if constexpr (HALF) return qw_readlane(v, 31);
     v += qw_dpp<0x143, 0xc>(0.0, v);   // row_bcast:31 -> rows 2, 3
@@ -501,11 +576,7 @@ template <bool HALF>
 __device__ __forceinline__ void qw_sum2(double a, double b, int lane, double &sa, double &sb)
 {
     if constexpr (HALF) {
-        double v = lane < 32 ? a : b;
-        v += qw_dpp<0x111, 0xf>(0.0, v);
-        v += qw_dpp<0x112, 0xf>(0.0, v);
-        v += qw_dpp<0x114, 0xf>(0.0, v);
-        v += qw_dpp<0x118, 0xf>(0.0, v);
+        double v = qw_scan_rows(lane < 32 ? a : b);
         v += qw_dpp<0x142, 0xa>(0.0, v);
         sa = qw_readlane(v, 31);
         sb = qw_readlane(v, 63);
@@ -514,16 +585,17 @@ __device__ __forceinline__ void qw_sum2(double a, double b, int lane, double &sa
         sb = qw_sum<false>(b);
     }
 }
+// maxima: lanes without a source keep their own value (old = v), which is neutral for max
 template <bool HALF>
 __device__ __forceinline__ double qw_max(double v)
 {
-    v = fmax(v, qw_dpp<0x111, 0xf>(-INFINITY, v));
-    v = fmax(v, qw_dpp<0x112, 0xf>(-INFINITY, v));
-    v = fmax(v, qw_dpp<0x114, 0xf>(-INFINITY, v));
-    v = fmax(v, qw_dpp<0x118, 0xf>(-INFINITY, v));
-    v = fmax(v, qw_dpp<0x142, 0xa>(-INFINITY, v));
+    v = fmax(v, qw_dpp<0x111, 0xf>(v, v));
+    v = fmax(v, qw_dpp<0x112, 0xf>(v, v));
+    v = fmax(v, qw_dpp<0x114, 0xf>(v, v));
+    v = fmax(v, qw_dpp<0x118, 0xf>(v, v));
+    v = fmax(v, qw_dpp<0x142, 0xa>(v, v));
     if constexpr (HALF) return qw_readlane(v, 31);
-    v = fmax(v, qw_dpp<0x143, 0xc>(-INFINITY, v));
+    v = fmax(v, qw_dpp<0x143, 0xc>(v, v));
     return qw_readlane(v, 63);
 }
 // Threshold of the projection of the wave-distributed vector w (w = -inf on lanes without
@@ -581,9 +653,13 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
                                                  int k, aa_qp_params p, int *__restrict__ iters,
                                                  QpHeader *__restrict__ hdr,
                                                  const int *__restrict__ ovf_rows,
-                                                 const QpCarry *__restrict__ ovf)
+                                                 const QpCarry *__restrict__ ovf,
+                                                 double *__restrict__ zslot /*[slot][KQ] or null*/)
 {
     constexpr bool HALF = KQ == 32;
+    // latency-bound waves: take issue priority over the bandwidth-bound GEMM waves they may
+    // share a SIMD with (the stragglers run concurrently with the Z'X pass)
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int comp = HALF ? (lane & 31) : lane;     // HALF: the upper half mirrors the lower
     const bool live = comp < k;
@@ -606,12 +682,13 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
         const double b = live ? -B[comp * stride_j + row * stride_t] * (bscale ? bscale[comp] : 1.0) : 0.0;
         double f, alpha = 1.0, fmem[QP_MAXMEM];
         int n_iter, n_feval;
-        unsigned long long support = 0ull;      // support of the latest projection
+        unsigned long long support = 0ull, support_r = 0ull;   // latest direction / residual supports
 #pragma unroll
         for (int i = 0; i < QP_MAXMEM; ++i) fmem[i] = NAN;
         if (fresh) {
             const double t0 = qw_threshold<HALF>(live ? x : -INFINITY, comp, support);
             x = live ? fmax(x - t0, 0.0) : 0.0;
+            support_r = support;
         }
         double g = qw_matvec<KQ>(Arow, x) + b;
         if (fresh) {
@@ -634,7 +711,7 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
                 if (p.alpha_min <= p.alpha0 && p.alpha0 <= p.alpha_max) {
                     alpha = p.alpha0;
                 } else {
-                    const double t1 = qw_threshold<HALF>(live ? x - g : -INFINITY, comp, support);
+                    const double t1 = qw_threshold<HALF>(live ? x - g : -INFINITY, comp, support_r);
                     double ainv = qw_max<HALF>(live ? fabs(fmax(x - g - t1, 0.0) - x) : 0.0);
                     if (fabs(ainv) < 1e-12) ainv = 1.0;
                     alpha = fmin(fmax(p.alpha_min, 1.0 / ainv), p.alpha_max);
@@ -676,7 +753,7 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             f = f_new;
             n_feval += 1;
 
-            const double tr = qw_threshold<HALF>(live ? x - g : -INFINITY, comp, support);
+            const double tr = qw_threshold<HALF>(live ? x - g : -INFINITY, comp, support_r);
             const double r = live ? fmax(x - g - tr, 0.0) - x : 0.0;
             const double r2 = qw_sum<HALF>(r * r);
             // max |r| < epsilon_one  <=>  no lane has |r| >= epsilon_one (no reduction)
@@ -685,7 +762,10 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             const bool conv = (sqrt(r2) < p.epsilon_two) || rinf_small;
             if (conv || n_feval > p.max_feval || n_iter >= p.max_iterations) break;
         }
-        if (live && lane == comp) Z[row * ldz + comp] = x;
+        if (live && lane == comp) {
+            if (zslot) zslot[(size_t)slot * KQ + comp] = x;     // deferred commit (launch_qp_tail_fixup)
+            else Z[row * ldz + comp] = x;
+        }
         if (lane == 0) {
             if (iters) iters[row] = n_iter;
             atomicAdd(&hdr->total_passes, (unsigned long long)n_iter);
@@ -720,6 +800,8 @@ __global__ __launch_bounds__(256) void k_qp_project_only(const double *__restric
 int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
 int g_qp_refill_min = 24;      // idle lanes of a wave that trigger a refill (1..64)
 int g_qp_mode = 0;             // 0: lane-per-sample then wave-per-sample; 1: wave-per-sample only
+int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
+int g_qp_profile = 0;          // cycle accounting of k_qp (printed when stats are requested)
 int g_qp_waves = 1024;         // most waves the lane-per-sample kernel is launched with
 static int qp_pass_cap() { return g_qp_pass_cap < 1 ? 1 : g_qp_pass_cap; }
 
@@ -753,7 +835,8 @@ __global__ __launch_bounds__(256) void k_qp_setup(QpHeader *__restrict__ hdr, do
 
 int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, long stride_t,
               const double *bscale_host, double *Ztall, int ldz, long n, int k,
-              const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats, const double *gram_dev)
+              const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats, const double *gram_dev,
+              bool defer_tail)
 {
     int KQ = 4;
     while (KQ < k) KQ *= 2;
@@ -762,7 +845,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     const bool wave_only = KQ > 32 || g_qp_mode == 1;
     const int KW = KQ > 32 ? 64 : 32;              // A padding of the wave kernel
     // scratch layout: QpHeader | A[KQ*KQ] | A2[KW*KW] | bscale[64] | ovf_rows[n] | ovf[n]
-    const size_t off_A = 64;
+    const size_t off_A = 128;             // QpHeader at 0, QpDebug at 64
     const size_t off_A2 = off_A + (size_t)KQ * KQ * sizeof(double);
     const size_t off_bs = off_A2 + (size_t)KW * KW * sizeof(double);
     const size_t off_rows = off_bs + 64 * sizeof(double);
@@ -810,11 +893,11 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         if (KW == 64)
             hipLaunchKernelGGL(k_qp_wave<64>, dim3((unsigned)blocks), dim3(256), 0, c->stream, A2d, Btall,
                                stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr,
-                               (const int *)ovf_rows, (const QpCarry *)ovf);
+                               (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr);
         else
             hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)blocks), dim3(256), 0, c->stream, A2d, Btall,
                                stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr,
-                               (const int *)ovf_rows, (const QpCarry *)ovf);
+                               (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr);
     } else {
         // phase 1: every sample gets up to pass_cap passes in a lane
         int cap = qp_pass_cap();
@@ -824,16 +907,35 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         long waves = (n + 63) / 64;
         if (waves > g_qp_waves) waves = g_qp_waves;
         dim3 grid((unsigned)waves);
-#define QPL(KQV) hipLaunchKernelGGL(k_qp<KQV>, grid, dim3(64), 0, c->stream, Ad, Btall, stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf, g_qp_refill_min)
+        QpDebug *dbgp = g_qp_profile ? reinterpret_cast<QpDebug *>(base + 64) : (QpDebug *)nullptr;
+        if (dbgp) AA_CHECK_HIP(hipMemsetAsync(dbgp, 0, sizeof(QpDebug), c->stream));
+#define QPL(KQV) hipLaunchKernelGGL(k_qp<KQV>, grid, dim3(64), 0, c->stream, Ad, Btall, stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf, g_qp_refill_min, dbgp)
         switch (KQ) { case 4: QPL(4); break; case 8: QPL(8); break; case 16: QPL(16); break;
                       default: QPL(32); break; }
 #undef QPL
         if (cap < p->max_iterations) {
             // phase 2: the stragglers, one wave each (grid is fixed; the count is read on
             // the device, so no host synchronisation between the phases)
-            hipLaunchKernelGGL(k_qp_wave<32>, dim3(1024), dim3(256), 0, c->stream, A2d, Btall, stride_j,
+            const bool defer = defer_tail && !stats && c->stream2 && ldz == c->KP && KW == 32 &&
+                               c->dtype == AA_F32 &&
+                               c->tmpTall.bytes >= (size_t)n * 32 * sizeof(double);
+            hipStream_t s2 = c->stream;
+            double *zslot = nullptr;
+            if (defer) {
+                AA_CHECK_HIP(hipEventRecord(c->evFork, c->stream));
+                AA_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->evFork, 0));
+                s2 = c->stream2;
+                zslot = c->tmpTall.as<double>();
+            }
+            hipLaunchKernelGGL(k_qp_wave<32>, dim3(1024), dim3(256), 0, s2, A2d, Btall, stride_j,
                                stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
-                               (const int *)ovf_rows, (const QpCarry *)ovf);
+                               (const int *)ovf_rows, (const QpCarry *)ovf, zslot);
+            if (defer) {
+                AA_CHECK_HIP(hipEventRecord(c->evJoin, c->stream2));
+                c->qp_tail_pending = true;
+                c->qp_tail_rows = ovf_rows;
+                c->qp_tail_count = &hdr->n_overflow;
+            }
         }
     }
     AA_CHECK_HIP(hipGetLastError());
@@ -844,7 +946,43 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         stats->total_passes = (long)h.total_passes;
         stats->max_passes = (int)h.max_passes;
         stats->reserved = (int)h.n_overflow;
+        if (g_qp_profile) {
+            QpDebug d;
+            AA_CHECK_HIP(hipMemcpy(&d, base + 64, sizeof(d), hipMemcpyDeviceToHost));
+            if (d.waves)
+                fprintf(stderr, "[qp_profile] waves %llu trips/wave %.1f refills/wave %.1f cycles/wave %.0f "
+                        "(projection part %.1f%%, mat-vec %.1f%%, step %.1f%%, residual+finish %.1f%%) cycles/trip %.0f\n",
+                        d.waves, (double)d.trips / d.waves, (double)d.refills / d.waves,
+                        (double)d.cyc_total / d.waves, 100.0 * d.cyc_proj / d.cyc_total,
+                        100.0 * d.cyc_matvec / d.cyc_total, 100.0 * d.cyc_step / d.cyc_total,
+                        100.0 * d.cyc_fin / d.cyc_total, (double)d.cyc_total / d.trips);
+        }
     }
+    return AA_OK;
+}
+
+// commit of the deferred stragglers: Z[row_s] = z_new[s]
+__global__ __launch_bounds__(256) void k_qp_commit_tail(const QpHeader *__restrict__ hdr,
+                                                        const int *__restrict__ rows,
+                                                        const double *__restrict__ zslot,
+                                                        double *__restrict__ Z, int KP, int k)
+{
+    const unsigned int count = hdr->n_overflow;
+    const int comp = threadIdx.x % KP;
+    for (unsigned int s = blockIdx.x * (256 / KP) + threadIdx.x / KP; s < count; s += gridDim.x * (256 / KP))
+        if (comp < k) Z[(size_t)rows[s] * KP + comp] = zslot[(size_t)s * KP + comp];
+}
+
+int launch_qp_tail_fixup(Ctx *c, double *Ztall)
+{
+    if (!c->qp_tail_pending) return AA_OK;
+    c->qp_tail_pending = false;
+    AA_CHECK_HIP(hipStreamWaitEvent(c->stream, c->evJoin, 0));
+    const QpHeader *hdr = reinterpret_cast<const QpHeader *>(c->qpStats.p);
+    AA_CHECK(launch_reduce_rows_fixup(c, c->qp_tail_count, c->qp_tail_rows, c->tmpTall.as<double>(), Ztall));
+    hipLaunchKernelGGL(k_qp_commit_tail, dim3(64), dim3(256), 0, c->stream, hdr, c->qp_tail_rows,
+                       (const double *)c->tmpTall.as<double>(), Ztall, c->KP, c->k);
+    AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
 

@@ -345,6 +345,21 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
                     const double v = u[i];
                     if (v > th) { s += v; m += 1; }
                 }
+            } else if (blocked) {
+                // long lists (cold start / dense columns) stay in global memory: level i
+                // reads the i-th candidate of the thread's segments, loads independent
+                int maxc = 0;
+#pragma unroll
+                for (int q = 0; q < PROJ_SPT; ++q) maxc = cq[q] > maxc ? cq[q] : maxc;
+                for (int i = 0; i < maxc; ++i) {
+                    double v[PROJ_SPT];
+#pragma unroll
+                    for (int q = 0; q < PROJ_SPT; ++q)
+                        v[q] = i < cq[q] ? mylist[(s0 + q) * segcap + i] : -INFINITY;
+#pragma unroll
+                    for (int q = 0; q < PROJ_SPT; ++q)
+                        if (v[q] > th) { s += v[q]; m += 1; }
+                }
             } else {
                 for (int q = 0; q < spt; ++q)
                     if (s0 + q < nseg) {
@@ -441,72 +456,83 @@ __device__ void post_step(int kind, int mode, const double *__restrict__ red, in
         }
     } else if (kind == POST_FIN) {
         if (i < k && mode > 0 && mode < 4) ps->warm[mode][i] = ps->t[i];
-        if (i == 0) {
-            if (ps->passes < 0) {
-                int all = 1;
-                for (int c = 0; c < k; ++c) all &= ps->shrunk[c];
-                ps->done = all;
+        if (i < 64) {                       // wave 0: the k column results -> scalars (xor tree)
+            const bool col = i < k;
+            double s0 = col ? red[i] : 0.0, s1 = col ? red[KP + i] : 0.0;
+            double s2 = col ? red[2 * KP + i] : 0.0, m3 = col ? red[3 * KP + i] : 0.0;
+            const bool conv_all = __ballot(col && !ps->shrunk[i]) == 0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                s0 += __shfl_xor(s0, o, 64);
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+                m3 = fmax(m3, __shfl_xor(m3, o, 64));
             }
-            double s0 = 0, s1 = 0, s2 = 0, m3 = 0;
-            for (int c = 0; c < k; ++c) {
-                s0 += red[c];
-                s1 += red[KP + c];
-                s2 += red[2 * KP + c];
-                m3 = fmax(m3, red[3 * KP + c]);
+            if (i == 0) {
+                if (ps->passes < 0) ps->done = conv_all ? 1 : 0;
+                if (mode == PROJ_DIR) {
+                    scal[SC_DELTA] = s0;
+                    scal[SC_DD] = s1;
+                    scal[SC_S1D] = s2;
+                } else if (mode == PROJ_RES) {
+                    scal[SC_RES2] = s0;
+                    scal[SC_RESINF] = m3;
+                } else if (mode == PROJ_ALPHA) {
+                    scal[SC_AINV] = m3;
+                }
+                const bool done = ps->passes < 0 ? conv_all : (ps->done != 0);
+                if (!done)
+                    scal[SC_FLAGS] = (double)((int)scal[SC_FLAGS] | AA_SPG_FLAG_PROJ_UNCONV);
             }
-            if (mode == PROJ_DIR) {
-                scal[SC_DELTA] = s0;
-                scal[SC_DD] = s1;
-                scal[SC_S1D] = s2;
-            } else if (mode == PROJ_RES) {
-                scal[SC_RES2] = s0;
-                scal[SC_RESINF] = m3;
-            } else if (mode == PROJ_ALPHA) {
-                scal[SC_AINV] = m3;
-            }
-            if (!ps->done)
-                scal[SC_FLAGS] = (double)((int)scal[SC_FLAGS] | AA_SPG_FLAG_PROJ_UNCONV);
         }
     } else if (kind == POST_SCALAR_SUM) {
-        if (i == 0) {
-            double s = 0;
-            for (int c = 0; c < k; ++c) s += red[c];
-            scal[slot] = s;
+        if (i < 64) {
+            double s = i < k ? red[i] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (i == 0) scal[slot] = s;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_finalize_sum(const double *__restrict__ partial, int nb,
-                                                      int NV, int KP, unsigned max_mask,
-                                                      double *__restrict__ red,
-                                                      const ProjState *__restrict__ ps_gate,
-                                                      int kind, int mode, int k,
-                                                      ProjState *__restrict__ ps,
-                                                      double *__restrict__ scal, int slot)
+#define FIN_NT 1024
+__global__ __launch_bounds__(FIN_NT) void k_finalize_sum(const double *__restrict__ partial, int nb,
+                                                         int NV, int KP, unsigned max_mask,
+                                                         double *__restrict__ red,
+                                                         const ProjState *__restrict__ ps_gate,
+                                                         int kind, int mode, int k,
+                                                         ProjState *__restrict__ ps,
+                                                         double *__restrict__ scal, int slot)
 {
     if (ps_gate && ps_gate->done) return;
-    __shared__ double sm[256];
-    const int RS = 256 / KP;
+    __shared__ double sm[4 * FIN_NT];
+    const int RS = FIN_NT / KP;                 // 32 or 16 partial groups, all NV values at once
     const int t = threadIdx.x, comp = t % KP, part = t / KP;
-    for (int a = 0; a < NV; ++a) {
+    double acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = ((max_mask >> a) & 1u) ? -INFINITY : 0.0;
+    for (int b = part; b < nb; b += RS) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (a < NV) {
+                const double val = partial[((size_t)b * NV + a) * KP + comp];
+                acc[a] = ((max_mask >> a) & 1u) ? fmax(acc[a], val) : acc[a] + val;
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sm[a * FIN_NT + t] = acc[a];
+    __syncthreads();
+    if (part < NV) {                            // group a finishes value a (fixed order)
+        const int a = part;
         const bool is_max = (max_mask >> a) & 1u;
-        double s = is_max ? -INFINITY : 0.0;
-#pragma unroll 8
-        for (int b = part; b < nb; b += RS) {
-            const double val = partial[((size_t)b * NV + a) * KP + comp];
+        double s = sm[a * FIN_NT + comp];
+        for (int q = 1; q < RS; ++q) {
+            const double val = sm[a * FIN_NT + q * KP + comp];
             s = is_max ? fmax(s, val) : s + val;
         }
-        sm[t] = s;
-        __syncthreads();
-        if (part == 0) {
-            for (int q = 1; q < RS; ++q) {
-                const double val = sm[q * KP + comp];
-                s = is_max ? fmax(s, val) : s + val;
-            }
-            red[a * KP + comp] = s;
-        }
-        __syncthreads();
+        red[a * KP + comp] = s;
     }
+    __syncthreads();
     if (kind != POST_NONE) post_step(kind, mode, red, KP, k, ps, scal, slot);
 }
 
@@ -754,12 +780,19 @@ __global__ __launch_bounds__(256) void k_gram_wide(const double *__restrict__ A,
 __global__ __launch_bounds__(256) void k_gram_finalize(const double *__restrict__ partial, int nb,
                                                        int elems, double *__restrict__ out)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= elems) return;
+    // block = 64 elements x 4 partial groups (group g sums b = g, g+4, ...), combined in a
+    // fixed order
+    __shared__ double sm[256];
+    const int t = threadIdx.x, g = t >> 6;
+    const int e = blockIdx.x * 64 + (t & 63);
     double s = 0.0;
+    if (e < elems) {
 #pragma unroll 8
-    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * elems + e];
-    out[e] = s;
+        for (int b = g; b < nb; b += 4) s += partial[(size_t)b * elems + e];
+    }
+    sm[t] = s;
+    __syncthreads();
+    if (g == 0 && e < elems) out[e] = ((sm[t] + sm[t + 64]) + sm[t + 128]) + sm[t + 192];
 }
 
 // ---------------------------------------------------------------- transposes (kernel form)
@@ -1055,7 +1088,7 @@ int tall_setup(Ctx *c)
     c->tallBlocks = (int)nb;
     // gram partials: tall grams use tallBlocks blocks, wide grams p_pad/128 blocks
     long gb = nb > c->p_pad / 128 ? nb : c->p_pad / 128;
-    if (gb < 128) gb = 128;          // tall Grams use up to 128 blocks whatever n is
+    if (gb < 256) gb = 256;          // tall Grams use up to 256 blocks whatever n is
     size_t need = (size_t)gb * c->KP * c->KP * sizeof(double);
     size_t need2 = (size_t)nb * 4 * c->KP * sizeof(double) + 4 * c->KP * sizeof(double);
     // residual / distance partials: one per 4 rows
@@ -1081,18 +1114,19 @@ int tall_setup(Ctx *c)
 static inline double *red_buf(Ctx *c) { return c->redOut.as<double>(); }
 
 static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mode, int slot,
-                             bool gated)
+                             bool gated, int nb = 0)
 {
+    if (nb <= 0) nb = c->tallBlocks;
     double *part = c->redPartial.as<double>();
     double *red = red_buf(c);
     ProjState *ps = c->proj.as<ProjState>();
     const ProjState *gate = gated ? ps : (const ProjState *)nullptr;
     if ((c->world <= 1 && !c->force_comm)) {
-        hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(256), 0, c->stream, part, c->tallBlocks, NV,
+        hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(FIN_NT), 0, c->stream, part, nb, NV,
                            c->KP, max_mask, red, gate, kind, mode, c->k, ps, c->scalars.as<double>(),
                            slot);
     } else {
-        hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(256), 0, c->stream, part, c->tallBlocks, NV,
+        hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(FIN_NT), 0, c->stream, part, nb, NV,
                            c->KP, max_mask, red, gate, (int)POST_NONE, mode, c->k, ps,
                            c->scalars.as<double>(), slot);
         // sums and maxima are reduced separately; layout red[a][KP].  (When a gated pass
@@ -1192,12 +1226,24 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
 int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, double scale,
                 const double *d_for_dot, int dot_slot)
 {
-    const long rpb = round_up((c->n + c->tallBlocks - 1) / c->tallBlocks, 64);
+    // 16 rows per wave and step with nothing in flight across steps: ~4 blocks per CU
+    long gb = (c->n + 63) / 64;
+    if (gb > 1024) gb = 1024;
+    if (gb < 1) gb = 1;
+    const long rpb = round_up((c->n + gb - 1) / gb, 64);
+    const int nb = (int)((c->n + rpb - 1) / rpb);
     double *part = c->redPartial.as<double>();
-    TALL_DISPATCH(k_grad, Graw, H, c->Mdev.as<double>(), c->alphaDev.as<double>(), scale, c->n,
-                  rpb, c->k, gout, d_for_dot, d_for_dot ? part : (double *)nullptr);
+    double *pdot = d_for_dot ? part : (double *)nullptr;
+    if (c->KP == 32)
+        hipLaunchKernelGGL(k_grad<32>, dim3(nb), dim3(256), 0, c->stream, Graw, H,
+                           (const double *)c->Mdev.as<double>(), (const double *)c->alphaDev.as<double>(),
+                           scale, c->n, rpb, c->k, gout, d_for_dot, pdot);
+    else
+        hipLaunchKernelGGL(k_grad<64>, dim3(nb), dim3(256), 0, c->stream, Graw, H,
+                           (const double *)c->Mdev.as<double>(), (const double *)c->alphaDev.as<double>(),
+                           scale, c->n, rpb, c->k, gout, d_for_dot, pdot);
     AA_CHECK_HIP(hipGetLastError());
-    if (d_for_dot) AA_CHECK(finalize_and_post(c, 1, 0u, POST_SCALAR_SUM, 0, dot_slot, false));
+    if (d_for_dot) AA_CHECK(finalize_and_post(c, 1, 0u, POST_SCALAR_SUM, 0, dot_slot, false, nb));
     return AA_OK;
 }
 
@@ -1221,7 +1267,7 @@ int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const doubl
 
 int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev)
 {
-    const int want = c->KP == 32 ? 64 : 128;
+    const int want = 256;                                      // one block per CU
     long rpb = round_up((c->n_pad + want - 1) / want, 64);     // 4 row groups per step
     const int nb = (int)((c->n_pad + rpb - 1) / rpb);
     double *part = c->redPartial.as<double>();
@@ -1230,7 +1276,7 @@ int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev)
         hipLaunchKernelGGL(k_gram_tall<32>, dim3(nb), dim3(256), 0, c->stream, A, B, c->n_pad, rpb, part);
     else
         hipLaunchKernelGGL(k_gram_tall<64>, dim3(nb), dim3(256), 0, c->stream, A, B, c->n_pad, rpb, part);
-    hipLaunchKernelGGL(k_gram_finalize, dim3((elems + 255) / 256), dim3(256), 0, c->stream, part,
+    hipLaunchKernelGGL(k_gram_finalize, dim3((elems + 63) / 64), dim3(256), 0, c->stream, part,
                        nb, elems, out_dev);
     AA_CHECK_HIP(hipGetLastError());
     if ((c->world > 1 || c->force_comm)) AA_CHECK(comm_allreduce(c, out_dev, elems, 0));
@@ -1317,7 +1363,7 @@ int launch_gram_wide(Ctx *c, const double *A, const double *B, double *out_dev)
         hipLaunchKernelGGL(k_gram_wide<32>, dim3(nb), dim3(256), 0, c->stream, A, B, (int)c->p_pad, part);
     else
         hipLaunchKernelGGL(k_gram_wide<64>, dim3(nb), dim3(256), 0, c->stream, A, B, (int)c->p_pad, part);
-    hipLaunchKernelGGL(k_gram_finalize, dim3((elems + 255) / 256), dim3(256), 0, c->stream, part,
+    hipLaunchKernelGGL(k_gram_finalize, dim3((elems + 63) / 64), dim3(256), 0, c->stream, part,
                        nb, elems, out_dev);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;   // wide operands are already replicated across ranks

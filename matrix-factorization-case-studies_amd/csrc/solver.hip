@@ -68,15 +68,15 @@ static int ensure_problem(Ctx *c, int k)
     }
     // split-row decomposition of the reduce-over-rows GEMM
     const long colgroups = c->dtype == AA_F32 ? (c->p_pad + 511) / 512 : (c->p_pad + 255) / 256;
-    long nslab = (512 + colgroups - 1) / colgroups;     // ~2 blocks per CU; 64 slabs at p = 4096
-    if (nslab > 128) nslab = 128;
+    long nslab = (g_reduce_rows_blocks + colgroups - 1) / colgroups;   // 2 blocks per CU: 64 slabs at p = 4096
+    if (nslab > 256) nslab = 256;
     if (nslab < 1) nslab = 1;
-    long rps = round_up((c->n_pad + nslab - 1) / nslab, 16);
+    long rps = round_up((c->n_pad + nslab - 1) / nslab, 32);
     nslab = (c->n_pad + rps - 1) / rps;
     c->nslab = nslab;
     c->rows_per_slab = rps;
     c->partial.release();
-    AA_CHECK(c->partial.alloc((size_t)nslab * KP * c->p_pad * esize(c)));
+    AA_CHECK(c->partial.alloc((size_t)(nslab + QP_FIX_SLABS) * KP * c->p_pad * esize(c)));
     AA_CHECK(tall_setup(c));
     c->alpha.assign(k, 1.0);
     c->ZtZ.assign((size_t)k * k, 0.0);
@@ -196,11 +196,21 @@ static int refresh_after_dictionary(Ctx *c, bool recompute_products)
 
 static int refresh_after_weights(Ctx *c)
 {
-    AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
     if (c->form == AA_FORM_DATA) {
-        AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), operandT(c, c->ZtX, c->Qw)));
+        // Z'X.  When the QP's stragglers are still running on the side stream, the pass
+        // over X starts with the Z of the lane kernel and the rows that change afterwards
+        // enter as a rank-m correction (launch_qp_tail_fixup), so the latency-bound tail of
+        // the weights update hides behind an HBM-bound pass.
+        const bool tail = c->qp_tail_pending;
+        AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), operandT(c, c->ZtX, c->Qw), true));
+        if (tail) AA_CHECK(launch_qp_tail_fixup(c, c->Zt.as<double>()));
+        AA_CHECK(launch_reduce_rows_finish(c, c->ZtX.as<double>(), operandT(c, c->ZtX, c->Qw),
+                                           tail ? QP_FIX_SLABS : 0));
+        AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
         AA_CHECK(launch_row_local(c, operandT(c, c->ZtX, c->Qw), c->H.as<double>()));
     } else {
+        if (c->qp_tail_pending) AA_CHECK(launch_qp_tail_fixup(c, c->Zt.as<double>()));   // not used
+        AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
         AA_CHECK(launch_transpose_tall_to_wide(c, c->Zt.as<double>(), c->ZtX.as<double>(),
                                                operandT(c, c->ZtX, c->Qw)));
         AA_CHECK(launch_row_local(c, operandT(c, c->ZtX, c->Qw), c->H.as<double>()));
@@ -340,8 +350,9 @@ static int weights_update(Ctx *c, const aa_qp_params *qp, aa_qp_stats *stats)
 {
     AA_REQUIRE(c->have_state && c->grams_valid, AA_ERR_STATE, "weights_update needs prepare() first");
     // Hessian D C K C' D (archetypal_analysis.py:387) and b-scale D are set up on the device
+    const bool defer = g_qp_overlap_tail && c->form == AA_FORM_DATA;
     AA_CHECK(launch_qp(c, nullptr, c->Gr.as<double>(), 1, c->KP, nullptr, c->Zt.as<double>(), c->KP, c->n,
-                       c->k, qp, nullptr, stats, dev_CKCt(c)));
+                       c->k, qp, nullptr, stats, dev_CKCt(c), defer));
     AA_CHECK(refresh_after_weights(c));
     return AA_OK;
 }
@@ -377,12 +388,22 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "row_local_waves")) {
         AA_REQUIRE(value == 0 || (value >= 8 && value <= 16), AA_ERR_ARG, "row_local_waves must be 0 or 8..16");
         g_row_local_waves = value;
+    } else if (!strcmp(name, "reduce_rows_unroll")) {
+        AA_REQUIRE(value == 4 || value == 8, AA_ERR_ARG, "reduce_rows_unroll must be 4 or 8");
+        g_reduce_rows_unroll = value;
+    } else if (!strcmp(name, "reduce_rows_blocks")) {
+        AA_REQUIRE(value >= 1, AA_ERR_ARG, "reduce_rows_blocks must be >= 1");
+        g_reduce_rows_blocks = value;      // takes effect at the next aa_set_state
     } else if (!strcmp(name, "row_local_stagger")) {
         AA_REQUIRE(value >= 0, AA_ERR_ARG, "row_local_stagger must be >= 0");
         g_row_local_stagger = value;
     } else if (!strcmp(name, "proj_mode")) {
         AA_REQUIRE(value == 0 || value == 1, AA_ERR_ARG, "proj_mode must be 0 or 1");
         g_proj_mode = value;
+    } else if (!strcmp(name, "qp_overlap_tail")) {
+        g_qp_overlap_tail = value != 0;
+    } else if (!strcmp(name, "qp_profile")) {
+        g_qp_profile = value != 0;
     } else if (!strcmp(name, "qp_waves")) {
         AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_waves must be >= 1");
         g_qp_waves = value;
@@ -417,6 +438,13 @@ int aa_ctx_create(aa_ctx **out, int device, int dtype)
     h->c.device = device;
     h->c.dtype = dtype;
     hipError_t e = hipStreamCreate(&h->c.stream);
+    if (e == hipSuccess) {
+        int lo = 0, hi = 0;                       // numerically lower = higher priority
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipStreamCreateWithPriority(&h->c.stream2, hipStreamDefault, hi);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->c.evFork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->c.evJoin, hipEventDisableTiming);
     if (e != hipSuccess) {
         set_error("hipStreamCreate: %s", hipGetErrorString(e));
         delete h;
@@ -431,6 +459,7 @@ int aa_ctx_destroy(aa_ctx *h)
     if (!h) return AA_OK;
     Ctx *c = &h->c;
     (void)hipSetDevice(c->device);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     comm_destroy(c);
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
@@ -438,6 +467,9 @@ int aa_ctx_destroy(aa_ctx *h)
                      &c->gramOut, &c->gramState, &c->costDev, &c->redOut, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters,
                      &c->qpStats};
     for (DevBuf *b : all) b->release();
+    if (c->evFork) (void)hipEventDestroy(c->evFork);
+    if (c->evJoin) (void)hipEventDestroy(c->evJoin);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete h;
     return AA_OK;
@@ -929,6 +961,8 @@ int aa_time_kernel(aa_ctx *h, int which, int reps, double *ms_avg)
                 rc = launch_reduce_rows(c, c->Ct.as<double>(), c->Q.as<double>(), nullptr, true);
             else if (which == 1)
                 rc = launch_row_local(c, operandT(c, c->P, c->Pw), c->Gn.as<double>());
+            else if (which == 2)
+                rc = launch_stream_probe(c);
             else {
                 set_error("aa_time_kernel: unknown kernel %d", which);
                 rc = AA_ERR_ARG;

@@ -597,3 +597,39 @@ def test_projection_modes_agree(cdr, orc, n, k, dense):
     assert np.abs(res[0][0] - res[1][0]).max() < 1e-13
     assert np.array_equal(res[0][0] > 0, res[1][0] > 0) or \
         np.abs(res[0][0] - res[1][0])[(res[0][0] > 0) != (res[1][0] > 0)].max() < 1e-15
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-11), ("float32", 2e-5)])
+def test_qp_tail_overlap_agrees(cdr, orc, dtype, tol):
+    """Stragglers of the weights QP finishing on a side stream while Z'X is accumulated (their
+    rows enter as a rank-m correction) give the same factors as the serial order.  A pass
+    cap of 3 sends most samples down that path."""
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(5)
+    n, p, k = 2500, 300, 9
+    X = rng.standard_normal((n, p))
+    if dtype == "float32":
+        X = X.astype(np.float32)
+    C = orc.right_stochastic_matrix((k, n), rng)
+    Z = orc.right_stochastic_matrix((n, k), rng)
+    out = []
+    _backend.set_option("qp_pass_cap", 3)
+    try:
+        for overlap in (0, 1):
+            _backend.set_option("qp_overlap_tail", overlap)
+            with _backend.Context(dtype=dtype) as ctx:
+                ctx.set_data(X)
+                ctx.set_state(C, Z, np.ones(k))
+                ctx.prepare()
+                costs = ctx.outer_iterations(4, dict(max_iterations=1), {})
+                Cf, Zf, _ = ctx.get_state()
+                out.append((np.asarray(costs), Cf, Zf, ctx.grams()))
+    finally:
+        _backend.set_option("qp_pass_cap", 24)
+        _backend.set_option("qp_overlap_tail", 0)
+    a, b = out
+    assert np.abs(a[0] - b[0]).max() <= tol * np.abs(a[0]).max()
+    assert np.abs(a[1] - b[1]).max() <= tol and np.abs(a[2] - b[2]).max() <= 10 * tol
+    for ga, gb in zip(a[3][:3], b[3][:3]):
+        assert np.abs(ga - gb).max() <= tol * max(1.0, np.abs(ga).max())
+    assert np.abs(b[2].sum(axis=1) - 1).max() < 1e-12 and b[2].min() >= 0

@@ -10,6 +10,8 @@ ctx = _backend.Context(dtype="float32")
 ctx.set_data(X)
 ctx.set_state(C0, Z0, np.ones(k)); ctx.prepare()
 ctx.outer_iterations(30, dict(max_iterations=1), {})
+print('stream probe: %.4f ms -> %.2f TB/s' % (ctx.time_kernel(2, 20), n * p * 4 / ctx.time_kernel(2, 20) / 1e9), flush=True)
+if os.environ.get('QP_PROFILE'): _backend.set_option('qp_profile', 1)
 for it in range(6):
     t0 = time.perf_counter(); ctx.dictionary_update(max_iterations=1); t1 = time.perf_counter()
     st = ctx.weights_update(); t2 = time.perf_counter()

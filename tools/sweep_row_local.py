@@ -9,14 +9,14 @@ X = bench.synthetic_rows(0, n); C0, Z0 = bench.start_factors(n, k)
 ctx = _backend.Context(dtype="float32")
 ctx.set_data(X); ctx.set_state(C0, Z0, np.ones(k)); ctx.prepare()
 ref = None
-for v, w in ((4, 0), (8, 0), (8, 16)):
-    _backend.set_option("row_local_variant", v); _backend.set_option("row_local_waves", w)
+for v, w, sg in ((8, 0, 0), (8, 0, 1), (8, 0, 3), (8, 0, 5), (8, 0, 7), (8, 0, 11), (8, 0, 16), (8, 0, 0)):
+    _backend.set_option("row_local_variant", v); _backend.set_option("row_local_waves", w); _backend.set_option("row_local_stagger", sg)
     ctx.time_kernel(1, 5)
     ms = ctx.time_kernel(1, 40)
     ctx.set_state(C0, Z0, np.ones(k)); ctx.prepare()
     g = ctx.grams()[2]
     if ref is None: ref = g
-    print("variant %d waves %d: %.4f ms  %.2f TB/s   max|dCKZ| %.2e" % (v, w, ms, n * p * 4 / ms / 1e9, np.abs(g - ref).max()), flush=True)
+    print("variant %d waves %d stagger %d: %.4f ms  %.2f TB/s   max|dCKZ| %.2e" % (v, w, sg, ms, n * p * 4 / ms / 1e9, np.abs(g - ref).max()), flush=True)
 print("reduce_rows: %.4f ms" % ctx.time_kernel(0, 40))
-_backend.set_option("row_local_variant", -1); _backend.set_option("row_local_waves", 0)
+_backend.set_option("row_local_variant", -1); _backend.set_option("row_local_waves", 0); _backend.set_option("row_local_stagger", 0)
 ctx.close()
