@@ -97,8 +97,10 @@ int aa_device_count(int *count);
  *                               4: 128, 5: 32 double-buffered, 6: 128 double-buffered, 7: 32),
  *                               8 wave-streaming (wave-private X tiles, shared B slabs)
  *   "row_local_waves"   0..16  waves per block of variant 8 (0: one block per CU)
- *   "proj_mode"         0|1    column simplex projection: 0 candidate lists (single rank),
- *                               1 iterative full passes (always used with > 1 rank)
+ *   "proj_mode"         0|1    column simplex projection: 0 candidate lists, 1 iterative full
+ *                               passes (also the fallback of a rank whose list overflows)
+ *   "proj_list_cap"     1..2048 multi-rank: candidates per rank and column that travel in the
+ *                               single list all-reduce of a projection
  *   "qp_pass_cap"       >= 1   SPG passes a sample spends in the lane-per-sample QP kernel
  *                               before it moves to the wave-per-sample kernel
  *   "qp_refill_min"     1..64  idle lanes of a wave that trigger pulling new samples

@@ -165,6 +165,8 @@ struct Ctx {
     DevBuf costDev;                            // costs recorded by aa_outer_iterations
     bool host_grams_valid = false;             // the host copies below match gramState
     DevBuf redOut;                             // finalized [NV][KP] reduction results
+    DevBuf redGather;                          // multi-rank: [world][NV][KP] per-rank results
+    DevBuf listGather;                         // multi-rank: [world][KP][cap + 1] candidate lists
     DevBuf scalars;                            // SC_COUNT doubles
     DevBuf proj;                               // ProjState
     DevBuf projList, projSegCnt;               // candidate lists of the column projection
@@ -240,6 +242,7 @@ int launch_qp_tail_fixup(Ctx *c, double *Ztall);
 int launch_simplex_rows_generic(hipStream_t s, const double *in, double *out, long rows, long cols);
 
 extern int g_proj_mode;           // kernels_tall.hip
+extern int g_proj_list_cap;       // kernels_tall.hip
 extern int g_row_local_variant;   // kernels_gemm.hip
 extern int g_row_local_waves;     // kernels_gemm.hip
 extern int g_row_local_stagger;   // kernels_gemm.hip

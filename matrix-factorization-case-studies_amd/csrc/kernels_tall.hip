@@ -262,9 +262,38 @@ __device__ __forceinline__ void block_sum_sm(double &s, int &m, double *rs, int 
     __syncthreads();
 }
 
+// Michelot's fixed point from the lower bound `th` on the `total` candidates in LDS (u);
+// all 256 threads; returns the threshold, the support size and whether it converged
+__device__ __forceinline__ void proj_solve_lds(const double *u, int total, double &th, int &prev,
+                                               int &conv, double *rs, int *rm)
+{
+    const int t = threadIdx.x;
+    for (int it = 0; it < 200 && !conv; ++it) {
+        double s = 0.0;
+        int m = 0;
+        for (int i = t; i < total; i += 256) {
+            const double v = u[i];
+            if (v > th) { s += v; m += 1; }
+        }
+        block_sum_sm(s, m, rs, rm);
+        // supports shrink monotonically from a lower bound; a repeat (or a last-bit
+        // regrowth) is the fixed point
+        if (m == prev || (prev > 0 && m > prev) || m == 0) conv = 1;
+        if (m > 0 && m != prev) th = (s - 1.0) / (double)m;
+        if (m > 0) prev = m;
+    }
+}
+
+// PACK = false: one block per column finishes the projection on this rank's candidate
+// list.  PACK = true (multi-rank): the block only copies the list, in its fixed order, into
+// this rank's slot of the gather buffer ([world][KP][cap + 1], element cap = the count, -1
+// when the list does not fit); k_proj_solve_gathered continues after the all-reduce.
+template <bool PACK>
 __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ list,
                                                     const int *__restrict__ segcnt, long nseg,
-                                                    long segcap, ProjState *__restrict__ ps)
+                                                    long segcap, ProjState *__restrict__ ps,
+                                                    double *__restrict__ pack_slot, int pack_cap,
+                                                    int pack_stride)
 {
     __shared__ double u[PROJ_LDS_CAP];
     __shared__ double rs[4];
@@ -298,7 +327,8 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
         __syncthreads();
     }
     const int total = scan[255];
-    const bool in_lds = total <= PROJ_LDS_CAP;
+    const bool in_lds = total <= (PACK ? pack_cap : PROJ_LDS_CAP);
+    double *dst = PACK ? pack_slot + (size_t)comp * pack_stride : u;
     if (in_lds) {
         int pos = scan[t] - mine;
         if (blocked) {
@@ -319,16 +349,20 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
                     v[q] = i < cq[q] ? mylist[(s0 + q) * segcap + i] : 0.0;
 #pragma unroll
                 for (int q = 0; q < PROJ_SPT; ++q)
-                    if (i < cq[q]) u[base[q] + i] = v[q];
+                    if (i < cq[q]) dst[base[q] + i] = v[q];
             }
         } else {
             for (int q = 0; q < spt; ++q)
                 if (s0 + q < nseg) {
                     const int c = mycnt[s0 + q];
                     const double *src = mylist + (s0 + q) * segcap;
-                    for (int i = 0; i < c; ++i) u[pos++] = src[i];
+                    for (int i = 0; i < c; ++i) dst[pos++] = src[i];
                 }
         }
+    }
+    if constexpr (PACK) {
+        if (t == 0) dst[pack_cap] = in_lds ? (double)total : -1.0;
+        return;
     }
     __syncthreads();
 
@@ -336,16 +370,13 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
     int prev = -1, conv = 0;
     if (total == 0) {
         conv = 1;                                        // cannot happen (max w > t_lower)
+    } else if (in_lds) {
+        proj_solve_lds(u, total, th, prev, conv, rs, rm);
     } else {
         for (int it = 0; it < 200 && !conv; ++it) {
             double s = 0.0;
             int m = 0;
-            if (in_lds) {
-                for (int i = t; i < total; i += 256) {
-                    const double v = u[i];
-                    if (v > th) { s += v; m += 1; }
-                }
-            } else if (blocked) {
+            if (blocked) {
                 // long lists (cold start / dense columns) stay in global memory: level i
                 // reads the i-th candidate of the thread's segments, loads independent
                 int maxc = 0;
@@ -372,8 +403,6 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
                     }
             }
             block_sum_sm(s, m, rs, rm);
-            // supports shrink monotonically from a lower bound; a repeat (or a last-bit
-            // regrowth) is the fixed point
             if (m == prev || (prev > 0 && m > prev) || m == 0) conv = 1;
             if (m > 0 && m != prev) th = (s - 1.0) / (double)m;
             if (m > 0) prev = m;
@@ -383,6 +412,62 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
         ps->t[comp] = th;
         ps->cnt[comp] = (double)prev;
         ps->shrunk[comp] = conv;                         // list mode: "column converged"
+    }
+}
+
+// multi-rank: the ranks' candidate lists side by side (gathered [world][KP][cap + 1], summed
+// all-reduce of per-rank slots) -> the same fixed point on every rank, lists concatenated in
+// rank order.  A rank whose list did not fit (count -1) leaves the column unconverged; the
+// host then falls back to the iterative passes from the lower bound.
+__global__ __launch_bounds__(256) void k_proj_solve_gathered(const double *__restrict__ gathered,
+                                                             int world, int cap, int KP,
+                                                             ProjState *__restrict__ ps)
+{
+    __shared__ double u[PROJ_LDS_CAP];
+    __shared__ double rs[4];
+    __shared__ int rm[4];
+    const int comp = blockIdx.x, t = threadIdx.x;
+    const size_t stride = (size_t)cap + 1;
+    int total = 0;
+    bool overflow = false;
+    for (int r = 0; r < world; ++r) {                    // uniform: every thread reads the counts
+        const double c = gathered[((size_t)r * KP + comp) * stride + cap];
+        if (c < 0.0) overflow = true;
+        else total += (int)c;
+    }
+    if (total > PROJ_LDS_CAP) overflow = true;
+    double th = ps->t[comp];
+    int prev = -1, conv = 0;
+    if (!overflow) {
+        int pos = 0;
+        for (int r = 0; r < world; ++r) {
+            const double *src = gathered + ((size_t)r * KP + comp) * stride;
+            const int c = (int)src[cap];
+            for (int i = t; i < c; i += 256) u[pos + i] = src[i];
+            pos += c;
+        }
+        __syncthreads();
+        if (total == 0) conv = 1;
+        else proj_solve_lds(u, total, th, prev, conv, rs, rm);
+    }
+    if (t == 0) {
+        ps->t[comp] = th;
+        ps->cnt[comp] = (double)prev;
+        ps->shrunk[comp] = conv;
+    }
+}
+
+// fallback after an overflowing list: continue with iterative passes from the lower bounds
+__global__ void k_proj_fallback_init(ProjState *__restrict__ ps, int k)
+{
+    const int i = threadIdx.x;
+    if (i < k) {
+        ps->cnt[i] = 0.0;
+        ps->shrunk[i] = 0;
+    }
+    if (i == 0) {
+        ps->done = 0;
+        ps->passes = 0;
     }
 }
 
@@ -502,7 +587,9 @@ __global__ __launch_bounds__(FIN_NT) void k_finalize_sum(const double *__restric
                                                          const ProjState *__restrict__ ps_gate,
                                                          int kind, int mode, int k,
                                                          ProjState *__restrict__ ps,
-                                                         double *__restrict__ scal, int slot)
+                                                         double *__restrict__ scal, int slot,
+                                                         double *__restrict__ gather, int rank,
+                                                         int world)
 {
     if (ps_gate && ps_gate->done) return;
     __shared__ double sm[4 * FIN_NT];
@@ -531,6 +618,10 @@ __global__ __launch_bounds__(FIN_NT) void k_finalize_sum(const double *__restric
             s = is_max ? fmax(s, val) : s + val;
         }
         red[a * KP + comp] = s;
+        // multi-rank: this rank's slot of the gather buffer, zeros in the other slots; a sum
+        // all-reduce then leaves every rank's values side by side on every rank
+        if (gather)
+            for (int r = 0; r < world; ++r) gather[((size_t)r * NV + a) * KP + comp] = r == rank ? s : 0.0;
     }
     __syncthreads();
     if (kind != POST_NONE) post_step(kind, mode, red, KP, k, ps, scal, slot);
@@ -538,11 +629,27 @@ __global__ __launch_bounds__(FIN_NT) void k_finalize_sum(const double *__restric
 
 // red [NV][KP] -> projection state / scalars, as its own launch (multi-rank: runs after
 // the all-reduce of `red`).  One block of 256 threads.
-__global__ __launch_bounds__(256) void k_post(int kind, int mode, const double *__restrict__ red,
+__global__ __launch_bounds__(256) void k_post(int kind, int mode, double *__restrict__ red,
                                               int KP, int k, ProjState *__restrict__ ps,
-                                              double *__restrict__ scal, int slot, int gated)
+                                              double *__restrict__ scal, int slot, int gated,
+                                              const double *__restrict__ gather, int world, int NV,
+                                              unsigned max_mask)
 {
     if (gated && ps->done) return;
+    // gathered [world][NV][KP] -> red [NV][KP], ranks combined in rank order on every rank
+    // (identical bits everywhere, whatever the all-reduce algorithm)
+    const int t = threadIdx.x;
+    if (t < NV * KP) {
+        const int a = t / KP;
+        const bool is_max = (max_mask >> a) & 1u;
+        double s = gather[t];
+        for (int r = 1; r < world; ++r) {
+            const double v = gather[(size_t)r * NV * KP + t];
+            s = is_max ? fmax(s, v) : s + v;
+        }
+        red[t] = s;
+    }
+    __syncthreads();
     post_step(kind, mode, red, KP, k, ps, scal, slot);
 }
 
@@ -1124,23 +1231,21 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
     if ((c->world <= 1 && !c->force_comm)) {
         hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(FIN_NT), 0, c->stream, part, nb, NV,
                            c->KP, max_mask, red, gate, kind, mode, c->k, ps, c->scalars.as<double>(),
-                           slot);
+                           slot, (double *)nullptr, 0, 1);
     } else {
+        // one sum all-reduce of a [world][NV][KP] buffer in which every rank fills its own
+        // slot, whatever mix of sums and maxima the NV values are; the ranks' values are
+        // combined in rank order by k_post.  (When a gated pass has already converged the
+        // reduced values are stale but unused: k_post exits.)
+        AA_CHECK(c->redGather.alloc((size_t)c->world * 4 * c->KP * sizeof(double)));
+        double *gather = c->redGather.as<double>();
         hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(FIN_NT), 0, c->stream, part, nb, NV,
                            c->KP, max_mask, red, gate, (int)POST_NONE, mode, c->k, ps,
-                           c->scalars.as<double>(), slot);
-        // sums and maxima are reduced separately; layout red[a][KP].  (When a gated pass
-        // has already converged the reduced values are stale but unused: k_post exits.)
-        // one all-reduce per run of consecutive values with the same operation
-        for (int a = 0; a < NV;) {
-            const int op = (max_mask >> a) & 1u;
-            int b = a + 1;
-            while (b < NV && (int)((max_mask >> b) & 1u) == op) ++b;
-            AA_CHECK(comm_allreduce(c, red + (size_t)a * c->KP, (long)(b - a) * c->KP, op));
-            a = b;
-        }
+                           c->scalars.as<double>(), slot, gather, c->rank, c->world);
+        AA_CHECK(comm_allreduce(c, gather, (long)c->world * NV * c->KP, 0));
         hipLaunchKernelGGL(k_post, dim3(1), dim3(256), 0, c->stream, kind, mode, red, c->KP, c->k, ps,
-                           c->scalars.as<double>(), slot, gated ? 1 : 0);
+                           c->scalars.as<double>(), slot, gated ? 1 : 0, (const double *)gather,
+                           c->world, NV, max_mask);
     }
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
@@ -1171,7 +1276,32 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
 // synchronisation, cheaper than enqueuing a dozen passes that exit immediately).
 static int g_proj_hard_cap = 200;
 
-int g_proj_mode = 0;   // 0: candidate lists (single rank), 1: iterative full passes
+int g_proj_mode = 0;        // 0: candidate lists, 1: iterative full passes
+int g_proj_list_cap = 256;  // multi-rank: candidates per rank and column that travel in one all-reduce
+
+static int proj_iterative_passes(Ctx *c, const double *wsrc, int mode, long rpb, int first_batch)
+{
+    double *part = c->redPartial.as<double>();
+    const double *scal = c->scalars.as<double>();
+    ProjState *ps = c->proj.as<ProjState>();
+    int batch = first_batch;
+    int total = 0;
+    int hdr[2] = {0, 0};
+    while (true) {
+        for (int it = 0; it < batch; ++it) {
+            TALL_DISPATCH(k_proj_pass, wsrc, (const double *)nullptr, 0.0, scal, -1, c->n, rpb,
+                          c->k, (const ProjState *)ps, part);
+            AA_CHECK(finalize_and_post(c, 2, 0u, POST_MICHELOT, 0, 0, true));
+        }
+        total += batch;
+        AA_CHECK_HIP(hipMemcpyAsync(hdr, &ps->done, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
+        AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+        if (hdr[0] || total >= g_proj_hard_cap) break;
+        batch = 3;
+    }
+    c->projPassHint[mode] = hdr[1];
+    return AA_OK;
+}
 
 int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode)
 {
@@ -1181,8 +1311,8 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     ProjState *ps = c->proj.as<ProjState>();
     double *wbuf = g ? c->tmpTall.as<double>() : (double *)nullptr;
     const double *wsrc = g ? (const double *)wbuf : x;
-    const bool lists = g_proj_mode == 0 && c->world <= 1 && !c->force_comm;
-    if (lists) {
+    const bool multi = c->world > 1 || c->force_comm;
+    if (g_proj_mode == 0) {
         const int RS = 256 / c->KP;
         const long nseg = (long)c->tallBlocks * RS, segcap = rpb / RS;
         TALL_DISPATCH_NT(PROJ_NT, k_proj_first, x, g, a_const, scal, a_slot, c->n, rpb, c->k,
@@ -1190,28 +1320,46 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
         AA_CHECK(finalize_and_post(c, 3, 1u, POST_FIRST, 0, 0, false));
         TALL_DISPATCH(k_proj_collect, wsrc, c->n, rpb, c->k, (const ProjState *)ps,
                       c->projList.as<double>(), c->projSegCnt.as<int>());
-        hipLaunchKernelGGL(k_proj_solve, dim3(c->k), dim3(256), 0, c->stream,
-                           (const double *)c->projList.as<double>(),
-                           (const int *)c->projSegCnt.as<int>(), nseg, segcap, ps);
+        if (!multi) {
+            hipLaunchKernelGGL(k_proj_solve<false>, dim3(c->k), dim3(256), 0, c->stream,
+                               (const double *)c->projList.as<double>(),
+                               (const int *)c->projSegCnt.as<int>(), nseg, segcap, ps,
+                               (double *)nullptr, 0, 0);
+        } else {
+            // every rank packs its candidates into its slot of [world][KP][cap + 1]; one sum
+            // all-reduce puts all lists on all ranks; each rank solves the union (same bits)
+            int cap = g_proj_list_cap;
+            if (cap * c->world > PROJ_LDS_CAP) cap = PROJ_LDS_CAP / c->world;
+            if (cap < 1) cap = 1;
+            const size_t stride = (size_t)cap + 1, slot = (size_t)c->KP * stride;
+            AA_CHECK(c->listGather.alloc((size_t)c->world * slot * sizeof(double)));
+            double *gl = c->listGather.as<double>();
+            AA_CHECK_HIP(hipMemsetAsync(gl, 0, (size_t)c->world * slot * sizeof(double), c->stream));
+            hipLaunchKernelGGL(k_proj_solve<true>, dim3(c->k), dim3(256), 0, c->stream,
+                               (const double *)c->projList.as<double>(),
+                               (const int *)c->projSegCnt.as<int>(), nseg, segcap, ps,
+                               gl + (size_t)c->rank * slot, cap, (int)stride);
+            AA_CHECK(comm_allreduce(c, gl, (long)c->world * (long)slot, 0));
+            hipLaunchKernelGGL(k_proj_solve_gathered, dim3(c->k), dim3(256), 0, c->stream,
+                               (const double *)gl, c->world, cap, c->KP, ps);
+            // did every column fit and converge?  (identical on all ranks)
+            int conv[AA_MAX_K];
+            AA_CHECK_HIP(hipMemcpyAsync(conv, ps->shrunk, (size_t)c->k * sizeof(int),
+                                        hipMemcpyDeviceToHost, c->stream));
+            AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+            bool all = true;
+            for (int i = 0; i < c->k; ++i) all = all && conv[i] != 0;
+            if (!all) {
+                hipLaunchKernelGGL(k_proj_fallback_init, dim3(1), dim3(64), 0, c->stream, ps, c->k);
+                AA_CHECK(proj_iterative_passes(c, wsrc, mode, rpb, 6));
+            }
+        }
+        AA_CHECK_HIP(hipGetLastError());
     } else {
         TALL_DISPATCH(k_proj_colmax, x, g, a_const, scal, a_slot, c->n, rpb, c->k, wbuf, part);
         AA_CHECK(finalize_and_post(c, 1, 1u, POST_COLMAX, 0, c->projWarm[mode] ? mode : 0, false));
-        int batch = c->projPassHint[mode] > 0 ? c->projPassHint[mode] + 1 : 12;
-        int total = 0;
-        int hdr[2] = {0, 0};
-        while (true) {
-            for (int it = 0; it < batch; ++it) {
-                TALL_DISPATCH(k_proj_pass, wsrc, (const double *)nullptr, 0.0, scal, -1, c->n, rpb,
-                              c->k, (const ProjState *)ps, part);
-                AA_CHECK(finalize_and_post(c, 2, 0u, POST_MICHELOT, 0, 0, true));
-            }
-            total += batch;
-            AA_CHECK_HIP(hipMemcpyAsync(hdr, &ps->done, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
-            AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-            if (hdr[0] || total >= g_proj_hard_cap) break;
-            batch = 3;
-        }
-        c->projPassHint[mode] = hdr[1];
+        AA_CHECK(proj_iterative_passes(c, wsrc, mode, rpb,
+                                       c->projPassHint[mode] > 0 ? c->projPassHint[mode] + 1 : 12));
     }
     double *out = nullptr;
     if (mode == PROJ_FEAS) out = const_cast<double *>(x);

@@ -397,6 +397,9 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "row_local_stagger")) {
         AA_REQUIRE(value >= 0, AA_ERR_ARG, "row_local_stagger must be >= 0");
         g_row_local_stagger = value;
+    } else if (!strcmp(name, "proj_list_cap")) {
+        AA_REQUIRE(value >= 1 && value <= 2048, AA_ERR_ARG, "proj_list_cap must be in 1..2048");
+        g_proj_list_cap = value;
     } else if (!strcmp(name, "proj_mode")) {
         AA_REQUIRE(value == 0 || value == 1, AA_ERR_ARG, "proj_mode must be 0 or 1");
         g_proj_mode = value;
@@ -464,7 +467,7 @@ int aa_ctx_destroy(aa_ctx *h)
     comm_destroy(c);
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->redPartial,
-                     &c->gramOut, &c->gramState, &c->costDev, &c->redOut, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters,
+                     &c->gramOut, &c->gramState, &c->costDev, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters,
                      &c->qpStats};
     for (DevBuf *b : all) b->release();
     if (c->evFork) (void)hipEventDestroy(c->evFork);

@@ -10,7 +10,9 @@ Per outer iteration the collectives are (all float64, sum unless noted):
   P = C X, Q = D X, Z'X            k x p
   Z'Z, C XX'Z, Grams of CX / DX    k x k           (the latter from replicated operands)
   packed scalars                   <d,g>, <d,d>, tr(D H), ||res||^2, (max) |res|_inf, alpha^-1
-  projection passes                k x (sum, count) per Michelot pass, k maxima once
+  projection                       one gathered k x (max, sum, count), then the ranks'
+                                   candidate lists in ONE buffer (sum all-reduce of per-rank
+                                   slots); fallback: k x (sum, count) per Michelot pass
 Everything else (C XX' rows, X X'Z rows, the n/G per-sample QPs, the row-local part of
 every projection) needs no communication.
 """
@@ -42,12 +44,22 @@ class TorchComm(object):
         return t.numpy()
 
 
-def project_columns(W, comm, max_passes=64):
-    """Column-wise simplex projection of a tall [n_local, k] array whose rows are
-    sharded: Michelot fixed point with one all-reduce of k x (sum, count) per pass."""
+def gather_by_sum(local, comm, rank):
+    """What csrc does instead of an all-gather: every rank fills its own slot of a
+    [world, ...] buffer (zeros elsewhere) and the buffer is sum-all-reduced."""
+    buf = np.zeros((comm.world,) + np.shape(local))
+    buf[rank] = local
+    return comm.allreduce(buf, "sum").reshape(buf.shape)
+
+
+def comm_rank(comm):
+    return comm.dist.get_rank() if hasattr(comm, "dist") else 0
+
+
+def project_columns_passes(W, comm, t, max_passes=64):
+    """Michelot fixed point from the thresholds t with one all-reduce of k x (sum, count)
+    per pass (csrc: k_proj_pass + finalize; also the fallback of the list form)."""
     k = W.shape[1]
-    local_max = W.max(axis=0) if W.shape[0] else np.full(k, -np.inf)
-    t = comm.allreduce(local_max, "max") - 1.0
     prev = np.zeros(k)
     done = np.zeros(k, dtype=bool)
     for _ in range(max_passes):
@@ -61,7 +73,54 @@ def project_columns(W, comm, max_passes=64):
         done |= conv
         if done.all():
             break
-    return np.fmax(W - t, 0.0)
+    return t
+
+
+def project_columns(W, comm, warm=None, cap=256):
+    """Column-wise simplex projection of a tall [n_local, k] array whose rows are sharded,
+    as csrc/kernels_tall.hip: launch_proj runs it on several ranks:
+      1. per rank (max, sum and count above the warm threshold) -> gathered -> lower bound
+         t_lo = max(max - 1, Newton step from the warm threshold)          (k_proj_first)
+      2. per rank the candidates {w > t_lo}, at most `cap` per column, gathered in one
+         buffer -> every rank runs the fixed point on the union           (k_proj_solve*)
+      3. a rank whose list does not fit -> iterative passes from t_lo      (fallback)
+    Returns (projection, thresholds)."""
+    k = W.shape[1]
+    rank = comm_rank(comm)
+    tw = np.full(k, np.inf) if warm is None else warm
+    above = W > tw
+    first = np.stack([W.max(axis=0) if W.shape[0] else np.full(k, -np.inf),
+                      np.where(above, W, 0.0).sum(axis=0), above.sum(axis=0).astype(float)])
+    allr = gather_by_sum(first, comm, rank)                       # [world, 3, k]
+    mx = allr[:, 0].max(axis=0)
+    s, cnt = allr[:, 1].sum(axis=0), allr[:, 2].sum(axis=0)
+    t = mx - 1.0
+    newton = np.where(cnt > 0, (s - 1.0) / np.maximum(cnt, 1.0), -np.inf)
+    t = np.where((newton > t) & (newton < mx), newton, t)
+    lists = np.full((k, cap + 1), 0.0)
+    for i in range(k):
+        cand = W[W[:, i] > t[i], i]
+        if cand.size <= cap:
+            lists[i, :cand.size] = cand
+            lists[i, cap] = cand.size
+        else:
+            lists[i, cap] = -1.0
+    allists = gather_by_sum(lists, comm, rank)                    # [world, k, cap + 1]
+    if (allists[:, :, cap] < 0).any():
+        t = project_columns_passes(W, comm, t)
+    else:
+        for i in range(k):
+            u = np.concatenate([allists[r, i, :int(allists[r, i, cap])] for r in range(comm.world)])
+            th, prev = t[i], -1
+            for _ in range(200):
+                m = u > th
+                c = int(m.sum())
+                if c == prev or (prev > 0 and c > prev) or c == 0:
+                    break
+                th = (u[m].sum() - 1.0) / c
+                prev = c
+            t[i] = th
+    return np.fmax(W - t, 0.0), t
 
 
 def dictionary_update(Xg, Ct, H, ZtZ, alpha, trace, n_global, comm, max_iterations=1,
@@ -71,7 +130,8 @@ def dictionary_update(Xg, Ct, H, ZtZ, alpha, trace, n_global, comm, max_iteratio
     Returns (Ct, P, G, f) with P = C X (replicated), G = (C XX')' rows of this shard."""
     k = Ct.shape[1]
     M = alpha[:, None] * ZtZ * alpha[None, :]
-    x = project_columns(Ct, comm)
+    warm = {}
+    x, _ = project_columns(Ct, comm)
     P = comm.allreduce(x.T.dot(Xg))
     s1 = comm.allreduce([np.sum(x * H * alpha)])[0]
     a0 = np.trace(M.dot(P.dot(P.T)))
@@ -81,9 +141,11 @@ def dictionary_update(Xg, Ct, H, ZtZ, alpha, trace, n_global, comm, max_iteratio
     step = None
     for it in range(max_iterations):
         if step is None:
-            reach = comm.allreduce([np.abs(project_columns(x - g, comm) - x).max()], "max")[0]
+            pa, warm["alpha"] = project_columns(x - g, comm, warm.get("alpha"))
+            reach = comm.allreduce([np.abs(pa - x).max()], "max")[0]
             step = 1.0 / reach if abs(reach) > 1e-12 else 1.0
-        d = project_columns(x - step * g, comm) - x
+        pd, warm["dir"] = project_columns(x - step * g, comm, warm.get("dir"))
+        d = pd - x
         delta, dd, s1d = comm.allreduce([np.sum(d * g), np.sum(d * d), np.sum(d * H * alpha)])
         Q = comm.allreduce(d.T.dot(Xg))
         a1 = np.trace(M.dot(P.dot(Q.T))) + np.trace(M.dot(Q.dot(P.T)))
@@ -106,7 +168,8 @@ def dictionary_update(Xg, Ct, H, ZtZ, alpha, trace, n_global, comm, max_iteratio
         step = orc.cauchy_step_size(lam * (dgn - delta), lam * lam * dd, alpha_min, alpha_max)
         f_old = f_new
         g = g_new
-        res = project_columns(x - g, comm) - x
+        pr, warm["res"] = project_columns(x - g, comm, warm.get("res"))
+        res = pr - x
         r2 = comm.allreduce([np.sum(res * res)])[0]
         rinf = comm.allreduce([np.abs(res).max() if res.size else 0.0], "max")[0]
         if np.sqrt(r2) < epsilon_two or rinf < epsilon_one:

@@ -519,8 +519,10 @@ def test_qp_pass_cap_invariance(cdr, orc, cap):
 
 def test_rccl_path_single_rank(cdr, orc):
     """The multi-rank code path (RCCL all-reduce at every splice point: split-row GEMM
-    result, projection passes, Grams, packed scalars, FurthestSum row broadcast) run on one
-    GPU with a 1-rank communicator (AA_FORCE_RCCL=1): identical results to the direct path."""
+    result, gathered per-rank reductions, gathered candidate lists of the projection, Grams,
+    FurthestSum row broadcast) run on one GPU with a 1-rank communicator (AA_FORCE_RCCL=1):
+    identical results to the direct path, for the list projection and for the iterative one;
+    a list cap of 1 forces the overflow fallback (lists -> iterative passes)."""
     import os
     from convex_dim_red import _backend
     rng = np.random.RandomState(17)
@@ -529,11 +531,11 @@ def test_rccl_path_single_rank(cdr, orc):
     C = orc.right_stochastic_matrix((k, n), rng)
     Z = orc.right_stochastic_matrix((n, k), rng)
 
-    def run(force):
+    def run(force, **opts):
         if force:
             os.environ["AA_FORCE_RCCL"] = "1"
-        # multi-rank contexts always use the iterative projection; compare like with like
-        _backend.set_option("proj_mode", 1)
+        for name, value in opts.items():
+            _backend.set_option(name, value)
         try:
             with _backend.Context(dtype="float32") as ctx:
                 if force:
@@ -549,12 +551,17 @@ def test_rccl_path_single_rank(cdr, orc):
         finally:
             os.environ.pop("AA_FORCE_RCCL", None)
             _backend.set_option("proj_mode", 0)
+            _backend.set_option("proj_list_cap", 256)
 
-    a, b = run(False), run(True)
-    assert a[0] == b[0] and np.array_equal(a[1], b[1])
-    assert np.allclose(a[2], b[2], rtol=1e-6, atol=1e-6)   # the row travels through float64
-    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
-    assert np.array_equal(b[5], [1.5, 2.5])
+    for opts in (dict(), dict(proj_mode=1)):
+        a, b = run(False, **opts), run(True, **opts)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1])
+        assert np.allclose(a[2], b[2], rtol=1e-6, atol=1e-6)   # the row travels through float64
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+        assert np.array_equal(b[5], [1.5, 2.5])
+    a, c = run(False), run(True, proj_list_cap=1)
+    assert np.abs(np.asarray(a[1]) - np.asarray(c[1])).max() < 1e-9 * abs(a[0])
+    assert np.abs(a[3] - c[3]).max() < 1e-12 and np.abs(a[4] - c[4]).max() < 1e-9
 
 
 @pytest.mark.parametrize("n,k,dense", [(900, 6, False), (7000, 5, True), (7000, 40, True),
