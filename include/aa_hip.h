@@ -99,8 +99,12 @@ int aa_device_count(int *count);
  *   "row_local_waves"   0..16  waves per block of variant 8 (0: one block per CU)
  *   "proj_mode"         0|1    column simplex projection: 0 candidate lists, 1 iterative full
  *                               passes (also the fallback of a rank whose list overflows)
- *   "proj_list_cap"     1..2048 multi-rank: candidates per rank and column that travel in the
- *                               single list all-reduce of a projection
+ *   "proj_list_cap"     1..2048 multi-rank: most candidates per rank and column that travel in
+ *                               the list all-reduce of a projection (effective: min(this,
+ *                               2048 / ranks), so that the union fits the solver's LDS)
+ *   "use_graph"         0|1    1 (default): aa_outer_iterations captures two outer iterations
+ *                               in a hipGraph and replays it (single rank, data form, one SPG
+ *                               iteration per dictionary update, >= 8 iterations)
  *   "qp_pass_cap"       >= 1   SPG passes a sample spends in the lane-per-sample QP kernel
  *                               before it moves to the wave-per-sample kernel
  *   "qp_refill_min"     1..64  idle lanes of a wave that trigger pulling new samples
@@ -110,8 +114,9 @@ int aa_device_count(int *count);
  *                               stream while Z'X is accumulated (float32 data); the rows it
  *                               changes enter Z'X as a rank-m correction.  Default 0: measured
  *                               neutral, the stragglers run 2x slower next to the GEMM
- *   "qp_mode"           0|1    0: lane-per-sample kernel then wave-per-sample kernel;
- *                               1: wave-per-sample kernel for every sample */
+ *   "qp_mode"           0|1|2  0 (default): by size -- up to 16384 samples per GPU one wave per
+ *                               sample, above that the lane-per-sample kernel followed by the
+ *                               wave-per-sample kernel for the stragglers; 1 / 2 force either */
 int aa_set_option(const char *name, int value);
 
 /* -------------------------------------------- stateless ops (unit-test surface) */

@@ -163,6 +163,7 @@ struct Ctx {
     DevBuf gramOut;                            // up to 4 KPxKP results
     DevBuf gramState;                          // [3][KP*KP] on the device: Z'Z | C K C' | C K Z
     DevBuf costDev;                            // costs recorded by aa_outer_iterations
+    DevBuf costSlot;                           // device counter: next free slot of costDev
     bool host_grams_valid = false;             // the host copies below match gramState
     DevBuf redOut;                             // finalized [NV][KP] reduction results
     DevBuf redGather;                          // multi-rank: [world][NV][KP] per-rank results
@@ -211,7 +212,8 @@ int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const doubl
 int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev); // A'B  (KPxKP)
 int launch_gram_wide(Ctx *c, const double *A, const double *B, double *out_dev); // A B' (KPxKP)
 int launch_scale_gram(Ctx *c, double *dst, const double *src);      // dst = D src D
-int launch_aa_cost(Ctx *c, double *out_dev);                        // cost from gramState
+int launch_aa_cost(Ctx *c, double *out_dev, int *slot_counter_dev = nullptr);   // cost from gramState;
+                                              // with a counter: out_dev[(*counter)++]
 int launch_set_scalars(Ctx *c, double trace, double fnorm);          // SC_TRACE, SC_FNORM
 int launch_wide_axpy_lambda(Ctx *c, double *P, const double *Q, void *PT);   // P += lambda*Q; PT = T(P)
 int launch_wide_to_T(Ctx *c, const double *src, void *dstT);
@@ -241,6 +243,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
 int launch_qp_tail_fixup(Ctx *c, double *Ztall);
 int launch_simplex_rows_generic(hipStream_t s, const double *in, double *out, long rows, long cols);
 
+extern int g_use_graph;           // solver.hip
 extern int g_proj_mode;           // kernels_tall.hip
 extern int g_proj_list_cap;       // kernels_tall.hip
 extern int g_row_local_variant;   // kernels_gemm.hip

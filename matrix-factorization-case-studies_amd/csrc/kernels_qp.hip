@@ -799,7 +799,7 @@ __global__ __launch_bounds__(256) void k_qp_project_only(const double *__restric
 // wave-per-sample kernel.
 int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
 int g_qp_refill_min = 24;      // idle lanes of a wave that trigger a refill (1..64)
-int g_qp_mode = 0;             // 0: lane-per-sample then wave-per-sample; 1: wave-per-sample only
+int g_qp_mode = 0;             // 0: by size, 1: wave-per-sample only, 2: lane-per-sample then wave-per-sample
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
 int g_qp_profile = 0;          // cycle accounting of k_qp (printed when stats are requested)
 int g_qp_waves = 1024;         // most waves the lane-per-sample kernel is launched with
@@ -842,7 +842,9 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     while (KQ < k) KQ *= 2;
     AA_REQUIRE(KQ <= 64, AA_ERR_ARG, "QP: k = %d > 64 unsupported", k);
     AA_REQUIRE(n < (1L << 31), AA_ERR_ARG, "QP: too many samples");
-    const bool wave_only = KQ > 32 || g_qp_mode == 1;
+    // few samples (small shards of a multi-GPU run): the chip has more wave slots than
+    // samples, so one wave per sample beats the >= pass-cap trips of the lane kernel
+    const bool wave_only = KQ > 32 || g_qp_mode == 1 || (g_qp_mode == 0 && n <= 16384);
     const int KW = KQ > 32 ? 64 : 32;              // A padding of the wave kernel
     // scratch layout: QpHeader | A[KQ*KQ] | A2[KW*KW] | bscale[64] | ovf_rows[n] | ovf[n]
     const size_t off_A = 128;             // QpHeader at 0, QpDebug at 64

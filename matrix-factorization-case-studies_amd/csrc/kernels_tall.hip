@@ -1277,7 +1277,8 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
 static int g_proj_hard_cap = 200;
 
 int g_proj_mode = 0;        // 0: candidate lists, 1: iterative full passes
-int g_proj_list_cap = 256;  // multi-rank: candidates per rank and column that travel in one all-reduce
+int g_proj_list_cap = 2048; // multi-rank: most candidates per rank and column in the list all-reduce
+                            // (the union must fit the solver's LDS: effective cap = min(this, 2048 / world))
 
 static int proj_iterative_passes(Ctx *c, const double *wsrc, int mode, long rpb, int first_batch)
 {
@@ -1448,7 +1449,8 @@ __global__ __launch_bounds__(256) void k_scale_gram(double *__restrict__ dst,
 __global__ __launch_bounds__(256) void k_aa_cost(const double *__restrict__ state,
                                                  const double *__restrict__ alpha, int k, int KP,
                                                  double trace, double n_global,
-                                                 double *__restrict__ out)
+                                                 double *__restrict__ out,
+                                                 int *__restrict__ slot_counter)
 {
     __shared__ double sm[256];
     const double *ZtZ = state, *CKCt = state + KP * KP, *CKZ = state + 2 * KP * KP;
@@ -1465,7 +1467,12 @@ __global__ __launch_bounds__(256) void k_aa_cost(const double *__restrict__ stat
         if (t < o) sm[t] += sm[t + o];
         __syncthreads();
     }
-    if (t == 0) *out = 0.5 * (trace + sm[0]) / n_global;
+    // slot_counter: consecutive calls fill consecutive slots (the launch arguments stay
+    // constant, so the call can sit in a captured graph)
+    if (t == 0) {
+        const int idx = slot_counter ? (*slot_counter)++ : 0;
+        out[idx] = 0.5 * (trace + sm[0]) / n_global;
+    }
 }
 
 __global__ void k_set_scalars(double *__restrict__ sc, double trace, double fnorm)
@@ -1485,12 +1492,12 @@ int launch_scale_gram(Ctx *c, double *dst, const double *src)
     return AA_OK;
 }
 
-int launch_aa_cost(Ctx *c, double *out_dev)
+int launch_aa_cost(Ctx *c, double *out_dev, int *slot_counter_dev)
 {
     hipLaunchKernelGGL(k_aa_cost, dim3(1), dim3(256), 0, c->stream,
                        (const double *)c->gramState.as<double>(),
                        (const double *)c->alphaDev.as<double>(), c->k, c->KP, c->trace,
-                       (double)c->n_global, out_dev);
+                       (double)c->n_global, out_dev, slot_counter_dev);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }

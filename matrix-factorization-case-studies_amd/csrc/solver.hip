@@ -19,6 +19,8 @@
 
 namespace aa {
 
+int g_use_graph = 1;     // aa_outer_iterations replays a captured pair of iterations
+
 static thread_local std::string g_err;
 
 void set_error(const char *fmt, ...)
@@ -405,13 +407,15 @@ int aa_set_option(const char *name, int value)
         g_proj_mode = value;
     } else if (!strcmp(name, "qp_overlap_tail")) {
         g_qp_overlap_tail = value != 0;
+    } else if (!strcmp(name, "use_graph")) {
+        g_use_graph = value != 0;
     } else if (!strcmp(name, "qp_profile")) {
         g_qp_profile = value != 0;
     } else if (!strcmp(name, "qp_waves")) {
         AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_waves must be >= 1");
         g_qp_waves = value;
     } else if (!strcmp(name, "qp_mode")) {
-        AA_REQUIRE(value == 0 || value == 1, AA_ERR_ARG, "qp_mode must be 0 or 1");
+        AA_REQUIRE(value >= 0 && value <= 2, AA_ERR_ARG, "qp_mode must be 0, 1 or 2");
         g_qp_mode = value;
     } else {
         set_error("unknown option '%s'", name);
@@ -467,7 +471,7 @@ int aa_ctx_destroy(aa_ctx *h)
     comm_destroy(c);
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->redPartial,
-                     &c->gramOut, &c->gramState, &c->costDev, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters,
+                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters,
                      &c->qpStats};
     for (DevBuf *b : all) b->release();
     if (c->evFork) (void)hipEventDestroy(c->evFork);
@@ -698,12 +702,51 @@ int aa_outer_iterations(aa_ctx *h, int n_outer, const aa_spg_params *spg, const 
     Ctx *c = &h->c;
     AA_CHECK_HIP(hipSetDevice(c->device));
     // costs are evaluated and kept on the device; the host waits once, at the end
-    if (costs && n_outer > 0) AA_CHECK(c->costDev.alloc((size_t)(2 * n_outer + 64) * sizeof(double)));
-    for (int i = 0; i < n_outer; ++i) {
+    AA_CHECK(c->costDev.alloc((size_t)(2 * n_outer + 64) * sizeof(double)));
+    AA_CHECK(c->costSlot.alloc(64));
+    int *slot = c->costSlot.as<int>();
+    double *cd = c->costDev.as<double>();
+    AA_CHECK_HIP(hipMemsetAsync(slot, 0, sizeof(int), c->stream));
+    auto one_iteration = [&]() -> int {
         AA_CHECK(dictionary_update(c, spg, nullptr, true));
-        if (costs) AA_CHECK(launch_aa_cost(c, c->costDev.as<double>() + 2 * i));
+        if (costs) AA_CHECK(launch_aa_cost(c, cd, slot));
         AA_CHECK(weights_update(c, qp, nullptr));
-        if (costs) AA_CHECK(launch_aa_cost(c, c->costDev.as<double>() + 2 * i + 1));
+        if (costs) AA_CHECK(launch_aa_cost(c, cd, slot));
+        return AA_OK;
+    };
+    // An outer iteration with one SPG iteration per dictionary update is a fixed sequence
+    // of ~56 launches without host decisions, two thirds of them small dependent kernels:
+    // after two eager iterations (warm state, every lazy allocation done) TWO iterations --
+    // the gradient / Gram buffer pairs swap once per iteration -- are captured into a
+    // hipGraph and replayed.  Single rank only (RCCL stays outside graphs).
+    const bool graph = g_use_graph && c->world <= 1 && !c->force_comm && c->form == AA_FORM_DATA &&
+                       spg->max_iterations == 1 && n_outer >= 8 && !g_qp_overlap_tail;
+    int i = 0;
+    const int eager = graph ? 2 : n_outer;
+    for (; i < eager; ++i) AA_CHECK(one_iteration());
+    if (graph) {
+        const int pairs = (n_outer - i) / 2;
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        AA_CHECK_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int rc = one_iteration();
+        if (rc == AA_OK) rc = one_iteration();
+        hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc != AA_OK || e != hipSuccess || !g) {
+            if (rc == AA_OK) set_error("hipStreamEndCapture: %s (set option use_graph=0)", hipGetErrorString(e));
+            if (g) (void)hipGraphDestroy(g);
+            return rc != AA_OK ? rc : AA_ERR_HIP;   // host state has advanced: not recoverable
+        }
+        e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        for (int p = 0; p < pairs && e == hipSuccess; ++p) e = hipGraphLaunch(ge, c->stream);
+        if (ge) (void)hipGraphExecDestroy(ge);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) {
+            set_error("hipGraph: %s (set option use_graph=0)", hipGetErrorString(e));
+            return AA_ERR_HIP;
+        }
+        i += 2 * pairs;
+        for (; i < n_outer; ++i) AA_CHECK(one_iteration());
     }
     if (costs && n_outer > 0)
         AA_CHECK_HIP(hipMemcpyAsync(costs, c->costDev.p, (size_t)2 * n_outer * sizeof(double),
