@@ -102,9 +102,10 @@ int aa_device_count(int *count);
  *   "proj_list_cap"     1..2048 multi-rank: most candidates per rank and column that travel in
  *                               the list all-reduce of a projection (effective: min(this,
  *                               2048 / ranks), so that the union fits the solver's LDS)
- *   "use_graph"         0|1    1 (default): aa_outer_iterations captures two outer iterations
- *                               in a hipGraph and replays it (single rank, data form, one SPG
- *                               iteration per dictionary update, >= 8 iterations)
+ *   "use_graph"         0|1    1: aa_outer_iterations captures two outer iterations in a
+ *                               hipGraph and replays it (single rank, data form, one SPG
+ *                               iteration per dictionary update, >= 8 iterations).  Default 0:
+ *                               bit-identical and measured neutral on ROCm 7.2
  *   "qp_pass_cap"       >= 1   SPG passes a sample spends in the lane-per-sample QP kernel
  *                               before it moves to the wave-per-sample kernel
  *   "qp_refill_min"     1..64  idle lanes of a wave that trigger pulling new samples
@@ -237,10 +238,17 @@ int aa_gpnh_residual_cost(aa_ctx *ctx, double *cost);
 /* ------------------------------------------------------------ measurement */
 /* Time `reps` launches of one hot-path GEMM kernel with HIP events on the
  * context's stream.  which: 0 = reduce-over-rows (C X, X'Z; k x p out),
- * 1 = row-local (CX X', X X'Z; n x k out), 2 = a plain streaming read of X (the read
- * bandwidth the memory system delivers; reference point for the roofline).
+ * 1 = row-local (CX X', X X'Z; n x k out), 2..5 = a plain streaming read of X (the read
+ * bandwidth the memory system delivers; reference point for the roofline) with 4 / 8 / 16 / 8
+ * loads in flight per thread on 4096 / 2048 / 1024 / 8192 blocks.
  * ms_avg = average duration of one launch in milliseconds. */
 int aa_time_kernel(aa_ctx *ctx, int which, int reps, double *ms_avg);
+/* In-context timing of the two pass kernels: while enabled, every launch of the
+ * reduce-over-rows / row-local GEMM kernel is bracketed by a HIP event pair on the
+ * context's stream.  Each call returns the average duration (ms) and the number of
+ * launches recorded since the previous call, clears them, and sets the mode to `enable`. */
+int aa_gemm_timing(aa_ctx *ctx, int enable, double *ms_reduce_rows, int *n_reduce_rows,
+                   double *ms_row_local, int *n_row_local);
 
 #ifdef __cplusplus
 }

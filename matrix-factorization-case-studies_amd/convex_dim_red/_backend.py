@@ -99,6 +99,8 @@ _SIGNATURES = {
     "aa_gpnh_weights_update": (ctypes.c_int, [_vp, _dp, ctypes.POINTER(QPParams), ctypes.POINTER(QPStats)]),
     "aa_gpnh_residual_cost": (ctypes.c_int, [_vp, _dp]),
     "aa_time_kernel": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp]),
+    "aa_gemm_timing": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_int), _dp,
+                                      ctypes.POINTER(ctypes.c_int)]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
@@ -422,6 +424,15 @@ class Context(object):
         c = ctypes.c_double(0)
         _check(self.lib.aa_gpnh_residual_cost(self.h, ctypes.byref(c)))
         return c.value
+
+    def gemm_timing(self, enable):
+        """Switch the in-context event timing of the two pass kernels on/off; returns
+        (ms_reduce_rows, launches, ms_row_local, launches) recorded since the last call."""
+        a, b = ctypes.c_double(0), ctypes.c_double(0)
+        na, nb = ctypes.c_int(0), ctypes.c_int(0)
+        _check(self.lib.aa_gemm_timing(self.h, int(bool(enable)), ctypes.byref(a), ctypes.byref(na),
+                                       ctypes.byref(b), ctypes.byref(nb)))
+        return a.value, na.value, b.value, nb.value
 
     def time_kernel(self, which, reps):
         ms = ctypes.c_double(0)

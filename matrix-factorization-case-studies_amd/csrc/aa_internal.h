@@ -131,6 +131,9 @@ struct Ctx {
     hipStream_t stream2 = nullptr;             // side stream: the QP's straggler kernel
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     bool qp_tail_pending = false;              // stragglers run on stream2, results in tmpTall by slot
+    // measurement (aa_gemm_timing): HIP event pairs around every launch of the two pass kernels
+    bool time_gemm = false;
+    std::vector<hipEvent_t> gemmEvents[2];     // [0] reduce-over-rows, [1] row-local: start, stop, ...
     const int *qp_tail_rows = nullptr;         // device: overflow slot -> row
     const unsigned int *qp_tail_count = nullptr;   // device: number of overflow slots
     Comm *comm = nullptr;
@@ -198,7 +201,7 @@ int launch_reduce_rows_fixup(Ctx *c, const unsigned int *count_dev, const int *r
                              const double *zslot, const double *Ztall);
 // out[n_pad][KP] (double) = sum_c X[r][c] * B[i][c];  B wide, T-typed.
 int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall);
-int launch_stream_probe(Ctx *c);   // measurement: one streaming read of X
+int launch_stream_probe(Ctx *c, int variant);   // measurement: one streaming read of X
 
 // ------------------------------------------------------------------ kernels_tall.hip
 int tall_setup(Ctx *c);

@@ -619,25 +619,36 @@ __global__ __launch_bounds__(256) void k_reduce_rows_fixup_f32(const float *__re
 
 // measurement only: stream X once with 16-byte loads, no arithmetic to speak of -- the
 // read bandwidth the memory system delivers to a kernel of this shape (aa_time_kernel 2)
+template <int UNROLL>
 __global__ __launch_bounds__(256) void k_stream_probe(const f32x4 *__restrict__ x, long n16,
                                                       float *__restrict__ sink)
 {
     const long stride = (long)gridDim.x * 256;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const f32x4 a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
-        acc += (a + b) + (c + d);
+    for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+        f32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = x[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc += v[u];
     }
     for (; i < n16; i += stride) acc += x[i];
     if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = 1.f;   // keeps the loads alive
 }
 
-int launch_stream_probe(Ctx *c)
+// variant: 0 = 4 loads in flight per thread x 4096 blocks; 1 = 8 x 2048; 2 = 16 x 1024; 3 = 8 x 8192
+int launch_stream_probe(Ctx *c, int variant)
 {
     const long bytes = (long)c->n_pad * c->p_pad * (c->dtype == AA_F32 ? 4 : 8);
-    hipLaunchKernelGGL(k_stream_probe, dim3(4096), dim3(256), 0, c->stream,
-                       reinterpret_cast<const f32x4 *>(c->X.p), bytes / 16, c->partial.as<float>());
+    const f32x4 *x = reinterpret_cast<const f32x4 *>(c->X.p);
+    float *sink = c->partial.as<float>();
+    switch (variant) {
+        case 1: hipLaunchKernelGGL(k_stream_probe<8>, dim3(2048), dim3(256), 0, c->stream, x, bytes / 16, sink); break;
+        case 2: hipLaunchKernelGGL(k_stream_probe<16>, dim3(1024), dim3(256), 0, c->stream, x, bytes / 16, sink); break;
+        case 3: hipLaunchKernelGGL(k_stream_probe<8>, dim3(8192), dim3(256), 0, c->stream, x, bytes / 16, sink); break;
+        default: hipLaunchKernelGGL(k_stream_probe<4>, dim3(4096), dim3(256), 0, c->stream, x, bytes / 16, sink); break;
+    }
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
@@ -645,9 +656,20 @@ int launch_stream_probe(Ctx *c)
 // ---------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------
+static void gemm_event(Ctx *c, int which)
+{
+    if (!c->time_gemm) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) == hipSuccess) {
+        (void)hipEventRecord(e, c->stream);
+        c->gemmEvents[which].push_back(e);
+    }
+}
+
 int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *outT, bool main_only)
 {
     dim3 block(256);
+    gemm_event(c, 0);
     if (c->dtype == AA_F32) {
         dim3 grid((unsigned)((c->p_pad + 511) / 512), (unsigned)c->nslab);
         float *part = c->partial.as<float>();
@@ -672,6 +694,7 @@ int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *out
                                c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
     }
     AA_CHECK_HIP(hipGetLastError());
+    gemm_event(c, 0);
     if (main_only) return AA_OK;
     return launch_reduce_rows_finish(c, out_wide, outT, 0);
 }
@@ -730,6 +753,7 @@ static int row_local_variant(const Ctx *c)
 int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
 {
     dim3 block(256);
+    gemm_event(c, 1);
     if (c->dtype == AA_F32 && row_local_variant(c) == 8) {
         // wave-streaming kernel: W waves per block, one block per CU where possible
         const float *B = reinterpret_cast<const float *>(B_wideT);
@@ -811,6 +835,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
                                c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
     }
     AA_CHECK_HIP(hipGetLastError());
+    gemm_event(c, 1);
     return AA_OK;
 }
 

@@ -366,30 +366,10 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                 exhausted = true;   // queue drained: this lane idles
             }
         }
-        if (__any(starting)) {                         // wave-uniform: the mat-vec is collective
-            pc_refills += 1;
-            QP_TIC(tm0);
-            matvec(Ad);
-            QP_TOC(pc_mv, tm0);
-            if (starting) {
-                double xg = 0.0, xb = 0.0;
-#pragma unroll
-                for (int i = 0; i < KQ; ++i) {
-                    const double bi =
-                        (i < k) ? -B[i * stride_j + row * stride_t] * (bscale ? bscale[i] : 1.0) : 0.0;
-                    g[i] = Ad[i] + bi;
-                    xg = fma(x[i], g[i], xg);
-                    xb = fma(x[i], bi, xb);
-                }
-                f = 0.5 * (xg + xb);
-                n_feval = 1;
-                n_iter = 0;
-#pragma unroll
-                for (int i = 0; i < QP_MAXMEM; ++i) fmem[i] = NAN;
-                active = true;
-            }
-        }
-        if (!__any(active)) break;
+        // A starting lane has put x into its LDS column, an active lane will put its search
+        // direction there: ONE collective mat-vec per trip serves both (g = A x + b for the
+        // former, A d for the latter), so pulling in new samples costs no extra mat-vec.
+        if (!__any(active || starting)) break;
         QP_TIC(tp0);
         if (active) {
             // ---- one pass of the loop at spg.py:318-396, up to the search direction
@@ -423,7 +403,25 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
         matvec(Ad);                                    // collective (idle lanes: stale columns)
         QP_TOC(pc_mv, tm1);
         QP_TIC(ts0);
-        if (active) {
+        if (starting) {
+            // ---- rest of the start-up: g = A x + b; f = x'(g + b)/2      (spg.py:298-315)
+            pc_refills += 1;
+            double xg = 0.0, xb = 0.0;
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) {
+                const double bi =
+                    (i < k) ? -B[i * stride_j + row * stride_t] * (bscale ? bscale[i] : 1.0) : 0.0;
+                g[i] = Ad[i] + bi;
+                xg = fma(x[i], g[i], xg);
+                xb = fma(x[i], bi, xb);
+            }
+            f = 0.5 * (xg + xb);
+            n_feval = 1;
+            n_iter = 0;
+#pragma unroll
+            for (int i = 0; i < QP_MAXMEM; ++i) fmem[i] = NAN;
+            active = true;                             // its first pass runs in the next trip
+        } else if (active) {
             // d is recomputed from (x, g, alpha_d, td) -- the same three operations, so the same
             // bits -- instead of read back from LDS (32 dependent-latency reads per use)
             double dAd = 0.0;

@@ -598,13 +598,25 @@ __global__ __launch_bounds__(FIN_NT) void k_finalize_sum(const double *__restric
     double acc[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[a] = ((max_mask >> a) & 1u) ? -INFINITY : 0.0;
-    for (int b = part; b < nb; b += RS) {
+    // batches of 8 partial rows per thread with all their loads issued before the first use
+    // (a rolled loop waits one memory latency per row)
+    for (int b0 = part; b0 < nb; b0 += 8 * RS) {
+        double val[8][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-            if (a < NV) {
-                const double val = partial[((size_t)b * NV + a) * KP + comp];
-                acc[a] = ((max_mask >> a) & 1u) ? fmax(acc[a], val) : acc[a] + val;
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + u * RS;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const bool is_max = (max_mask >> a) & 1u;
+                val[u][a] = (a < NV && b < nb) ? partial[((size_t)b * NV + a) * KP + comp]
+                                               : (is_max ? -INFINITY : 0.0);
             }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                acc[a] = ((max_mask >> a) & 1u) ? fmax(acc[a], val[u][a]) : acc[a] + val[u][a];
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) sm[a * FIN_NT + t] = acc[a];

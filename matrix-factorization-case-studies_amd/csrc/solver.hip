@@ -19,7 +19,7 @@
 
 namespace aa {
 
-int g_use_graph = 1;     // aa_outer_iterations replays a captured pair of iterations
+int g_use_graph = 0;     // 1: aa_outer_iterations replays a captured pair of iterations (measured neutral)
 
 static thread_local std::string g_err;
 
@@ -474,6 +474,8 @@ int aa_ctx_destroy(aa_ctx *h)
                      &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters,
                      &c->qpStats};
     for (DevBuf *b : all) b->release();
+    for (int w = 0; w < 2; ++w)
+        for (hipEvent_t e : c->gemmEvents[w]) (void)hipEventDestroy(e);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
     if (c->evJoin) (void)hipEventDestroy(c->evJoin);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -988,6 +990,35 @@ int aa_quad_simplex_spg_batch(int device, const double *A, const double *B, long
 }
 
 // ------------------------------------------------------------------ measurement
+int aa_gemm_timing(aa_ctx *h, int enable, double *ms_reduce_rows, int *n_reduce_rows,
+                   double *ms_row_local, int *n_row_local)
+{
+    AA_REQUIRE(h, AA_ERR_ARG, "null ctx");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    double *ms_out[2] = {ms_reduce_rows, ms_row_local};
+    int *n_out[2] = {n_reduce_rows, n_row_local};
+    for (int w = 0; w < 2; ++w) {
+        std::vector<hipEvent_t> &ev = c->gemmEvents[w];
+        double total = 0.0;
+        int n = 0;
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) {
+                total += ms;
+                ++n;
+            }
+        }
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+        if (ms_out[w]) *ms_out[w] = n ? total / n : 0.0;
+        if (n_out[w]) *n_out[w] = n;
+    }
+    c->time_gemm = enable != 0;
+    return AA_OK;
+}
+
 int aa_time_kernel(aa_ctx *h, int which, int reps, double *ms_avg)
 {
     AA_REQUIRE(h && ms_avg && reps >= 1, AA_ERR_ARG, "bad arguments");
@@ -1007,8 +1038,8 @@ int aa_time_kernel(aa_ctx *h, int which, int reps, double *ms_avg)
                 rc = launch_reduce_rows(c, c->Ct.as<double>(), c->Q.as<double>(), nullptr, true);
             else if (which == 1)
                 rc = launch_row_local(c, operandT(c, c->P, c->Pw), c->Gn.as<double>());
-            else if (which == 2)
-                rc = launch_stream_probe(c);
+            else if (which >= 2 && which <= 5)
+                rc = launch_stream_probe(c, which - 2);
             else {
                 set_error("aa_time_kernel: unknown kernel %d", which);
                 rc = AA_ERR_ARG;

@@ -681,7 +681,7 @@ def test_graph_replay_is_bit_identical(cdr, orc, n_outer):
                 Cf, Zf, _ = ctx.get_state()
                 out.append((costs, more, Cf, Zf, ctx.cost()))
     finally:
-        _backend.set_option("use_graph", 1)
+        _backend.set_option("use_graph", 0)
     a, b = out
     assert a[0].size == 2 * n_outer
     for x, y in zip(a, b):
