@@ -44,10 +44,13 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 template <int KQ> struct QpMask { typedef unsigned int type; };
 template <> struct QpMask<64> { typedef unsigned long long type; };
 
-template <int KQ>
+// FULL: k == KQ, so the `component < k` tests -- otherwise KQ wave-uniform predicates that
+// hipcc keeps in SGPR pairs and spills -- vanish at compile time.
+template <int KQ, bool FULL = false>
 __device__ __forceinline__ double qp_project_threshold(const double (&x)[KQ], const double (&g)[KQ],
                                                        double a, int k,
-                                                       typename QpMask<KQ>::type &mask)
+                                                       typename QpMask<KQ>::type &mask,
+                                                       int *rounds = nullptr)
 {
     typedef typename QpMask<KQ>::type M;
     constexpr int NP = KQ >= 4 ? 4 : 1;
@@ -61,14 +64,14 @@ __device__ __forceinline__ double qp_project_threshold(const double (&x)[KQ], co
             for (int q = 0; q < NP; ++q) mxp[q] = -INFINITY;
 #pragma unroll
             for (int i = 0; i < KQ; ++i)
-                if (i < k) mxp[i % NP] = fmax(mxp[i % NP], x[i] - a * g[i]);
+                if ((FULL || i < k)) mxp[i % NP] = fmax(mxp[i % NP], x[i] - a * g[i]);
             double mx = mxp[0];
 #pragma unroll
             for (int q = 1; q < NP; ++q) mx = fmax(mx, mxp[q]);
             const double t0 = mx - 1.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i)
-                if (i < k && x[i] - a * g[i] > t0) m |= (M)1 << i;
+                if ((FULL || i < k) && x[i] - a * g[i] > t0) m |= (M)1 << i;
         }
         double sp[NP];
 #pragma unroll
@@ -86,7 +89,8 @@ __device__ __forceinline__ double qp_project_threshold(const double (&x)[KQ], co
         M nm = 0;
 #pragma unroll
         for (int i = 0; i < KQ; ++i)
-            if (i < k && (x[i] - a * g[i]) * cd > sm1) nm |= (M)1 << i;
+            if ((FULL || i < k) && (x[i] - a * g[i]) * cd > sm1) nm |= (M)1 << i;
+        if (rounds) *rounds += 1;
         if (nm == m || (pass >= 2 && __popcll((unsigned long long)nm) >= c)) break;
         m = nm;
     }
@@ -109,10 +113,21 @@ struct QpHeader {
     unsigned int pad;
 };
 
+__device__ __forceinline__ int qp_debug_wave_max(int v)   // maximum of v over the active lanes
+{
+    int m = 0;
+    for (int r = 1; r < 200; ++r) {
+        if (!__any(v >= r)) break;
+        m = r;
+    }
+    return m;
+}
+
 // Optional cycle accounting of the lane-per-sample kernel (aa_set_option("qp_profile", 1));
 // lives at byte 64 of the scratch buffer, printed by the host after the update.
 struct QpDebug {
     unsigned long long trips, refills, cyc_total, cyc_proj, cyc_matvec, waves, cyc_step, cyc_fin;
+    unsigned long long proj_calls, proj_rounds_wavemax, proj_rounds_lanesum, proj_lanes;
 };
 
 // ---------------------------------------------------------------------------
@@ -282,7 +297,9 @@ __device__ __forceinline__ void qp_matvec_mfma(const double (&Breg)[KQ / 16][KQ 
     for (int i = 0; i < KQ; ++i) out[i] = abuf[i * QP_AS + lane];
 }
 
-template <int KQ>
+// PROF: cycle accounting compiled in (aa_set_option("qp_profile", 1)); the counters cost
+// registers, so the production instantiation has none of it.
+template <int KQ, bool FULL, bool PROF>
 __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][KQ]*/,
                                            const double *__restrict__ B, long stride_j,
                                            long stride_t, const double *__restrict__ bscale,
@@ -332,12 +349,13 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
     };
 
     long long pc_proj = 0, pc_mv = 0, pc_refills = 0, pc_trips = 0, pc_step = 0, pc_fin = 0;
-    const long long pc_start = dbg ? clock64() : 0;
-#define QP_TIC(var) const long long var = dbg ? clock64() : 0
-#define QP_TOC(acc, var) if (dbg) acc += clock64() - var
+    long long pc_lane_rounds = 0, pc_lane_calls = 0, pc_wavemax = 0;
+    const long long pc_start = PROF ? clock64() : 0;
+#define QP_TIC(var) const long long var = PROF ? clock64() : 0
+#define QP_TOC(acc, var) if constexpr (PROF) acc += clock64() - var
     // the trip bound is a watchdog only (each sample needs <= max_iterations trips)
     for (long trip = 0; trip < (1L << 24); ++trip) {
-        pc_trips = trip;
+        if constexpr (PROF) pc_trips = trip;
         // Refill idle lanes in batches: the start-up of a sample (strided loads, a
         // projection and a mat-vec) is executed by the whole wave, so it is only entered
         // when enough lanes are waiting (or nothing else is left to do).
@@ -352,14 +370,14 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                 // ---- start-up: x = P(z0); g = A x + b; f = x'(g + b)/2      (spg.py:298-315)
 #pragma unroll
                 for (int i = 0; i < KQ; ++i) {
-                    x[i] = (i < k) ? Z[row * ldz + i] : 0.0;
+                    x[i] = (FULL || i < k) ? Z[row * ldz + i] : 0.0;
                     g[i] = 0.0;
                 }
                 support = 0;
-                const double t0 = qp_project_threshold<KQ>(x, g, 0.0, k, support);
+                const double t0 = qp_project_threshold<KQ, FULL>(x, g, 0.0, k, support);
                 support_r = support;
 #pragma unroll
-                for (int i = 0; i < KQ; ++i) x[i] = (i < k) ? fmax(x[i] - t0, 0.0) : 0.0;
+                for (int i = 0; i < KQ; ++i) x[i] = (FULL || i < k) ? fmax(x[i] - t0, 0.0) : 0.0;
 #pragma unroll
                 for (int i = 0; i < KQ; ++i) vl[i * VS] = x[i];
             } else {
@@ -377,22 +395,27 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                 if (p.alpha_min <= p.alpha0 && p.alpha0 <= p.alpha_max) {
                     alpha = p.alpha0;
                 } else {
-                    const double t1 = qp_project_threshold<KQ>(x, g, 1.0, k, support_r);
+                    const double t1 = qp_project_threshold<KQ, FULL>(x, g, 1.0, k, support_r);
                     double ainv = 0.0;
 #pragma unroll
                     for (int i = 0; i < KQ; ++i)
-                        if (i < k) ainv = fmax(ainv, fabs(fmax(x[i] - g[i] - t1, 0.0) - x[i]));
+                        if (FULL || i < k) ainv = fmax(ainv, fabs(fmax(x[i] - g[i] - t1, 0.0) - x[i]));
                     if (fabs(ainv) < 1e-12) ainv = 1.0;
                     alpha = fmin(fmax(p.alpha_min, 1.0 / ainv), p.alpha_max);
                 }
             }
-            td = qp_project_threshold<KQ>(x, g, alpha, k, support);
+            int rd_d = 0;
+            td = qp_project_threshold<KQ, FULL>(x, g, alpha, k, support, PROF ? &rd_d : nullptr);
+            if constexpr (PROF) {
+                pc_lane_rounds += rd_d;
+                pc_lane_calls += 1;
+            }
             alpha_d = alpha;
             delta = 0.0;
             dd = 0.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
-                const double di = (i < k) ? fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i] : 0.0;
+                const double di = (FULL || i < k) ? fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i] : 0.0;
                 vl[i * VS] = di;                 // to LDS for the mat-vec; recomputed below
                 delta = fma(di, g[i], delta);
                 dd = fma(di, di, dd);
@@ -405,12 +428,12 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
         QP_TIC(ts0);
         if (starting) {
             // ---- rest of the start-up: g = A x + b; f = x'(g + b)/2      (spg.py:298-315)
-            pc_refills += 1;
+            if constexpr (PROF) pc_refills += 1;
             double xg = 0.0, xb = 0.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
                 const double bi =
-                    (i < k) ? -B[i * stride_j + row * stride_t] * (bscale ? bscale[i] : 1.0) : 0.0;
+                    (FULL || i < k) ? -B[i * stride_j + row * stride_t] * (bscale ? bscale[i] : 1.0) : 0.0;
                 g[i] = Ad[i] + bi;
                 xg = fma(x[i], g[i], xg);
                 xb = fma(x[i], bi, xb);
@@ -427,7 +450,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             double dAd = 0.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
-                const double di = (i < k) ? fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i] : 0.0;
+                const double di = (FULL || i < k) ? fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i] : 0.0;
                 dAd = fma(di, Ad[i], dAd);
             }
             // non-monotone reference value (spg.py:341-344): roll, store, nanmax
@@ -454,7 +477,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             }
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
-                const double di = (i < k) ? fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i] : 0.0;
+                const double di = (FULL || i < k) ? fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i] : 0.0;
                 x[i] = fma(lam, di, x[i]);
                 g[i] = fma(lam, Ad[i], g[i]);
             }
@@ -466,13 +489,19 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
 
             QP_TOC(pc_step, ts0);
             QP_TIC(tp1);
-            const double tr = qp_project_threshold<KQ>(x, g, 1.0, k, support_r);
+            int rd_r = 0;
+            const double tr = qp_project_threshold<KQ, FULL>(x, g, 1.0, k, support_r, PROF ? &rd_r : nullptr);
+            if constexpr (PROF) {
+                pc_lane_rounds += rd_r;
+                pc_lane_calls += 1;
+                pc_wavemax += qp_debug_wave_max(rd_r);
+            }
             QP_TOC(pc_proj, tp1);
             QP_TIC(tf0);
             double r2 = 0.0, rinf = 0.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i)
-                if (i < k) {
+                if (FULL || i < k) {
                     const double r = fmax(x[i] - g[i] - tr, 0.0) - x[i];
                     r2 = fma(r, r, r2);
                     rinf = fmax(rinf, fabs(r));
@@ -483,7 +512,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             if (finished || n_iter >= pass_cap) {
 #pragma unroll
                 for (int i = 0; i < KQ; ++i)
-                    if (i < k) Z[row * ldz + i] = x[i];
+                    if (FULL || i < k) Z[row * ldz + i] = x[i];
                 if (finished) {
                     if (iters) iters[row] = n_iter;
                     atomicAdd(&hdr->total_passes, (unsigned long long)n_iter);
@@ -504,7 +533,13 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             QP_TOC(pc_fin, tf0);
         }
     }
-    if (dbg && threadIdx.x == 0) {
+    if constexpr (PROF) {
+        atomicAdd(&dbg->proj_rounds_lanesum, (unsigned long long)pc_lane_rounds);
+        atomicAdd(&dbg->proj_lanes, (unsigned long long)pc_lane_calls);
+    }
+    if (PROF && threadIdx.x == 0) {
+        atomicAdd(&dbg->proj_calls, (unsigned long long)pc_trips + 1);
+        atomicAdd(&dbg->proj_rounds_wavemax, (unsigned long long)pc_wavemax);
         atomicAdd(&dbg->cyc_step, (unsigned long long)pc_step);
         atomicAdd(&dbg->cyc_fin, (unsigned long long)pc_fin);
         atomicAdd(&dbg->trips, (unsigned long long)(pc_trips + 1));
@@ -845,7 +880,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     const bool wave_only = KQ > 32 || g_qp_mode == 1 || (g_qp_mode == 0 && n <= 16384);
     const int KW = KQ > 32 ? 64 : 32;              // A padding of the wave kernel
     // scratch layout: QpHeader | A[KQ*KQ] | A2[KW*KW] | bscale[64] | ovf_rows[n] | ovf[n]
-    const size_t off_A = 128;             // QpHeader at 0, QpDebug at 64
+    const size_t off_A = 192;             // QpHeader at 0, QpDebug at 64 (96 bytes)
     const size_t off_A2 = off_A + (size_t)KQ * KQ * sizeof(double);
     const size_t off_bs = off_A2 + (size_t)KW * KW * sizeof(double);
     const size_t off_rows = off_bs + 64 * sizeof(double);
@@ -909,9 +944,18 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         dim3 grid((unsigned)waves);
         QpDebug *dbgp = g_qp_profile ? reinterpret_cast<QpDebug *>(base + 64) : (QpDebug *)nullptr;
         if (dbgp) AA_CHECK_HIP(hipMemsetAsync(dbgp, 0, sizeof(QpDebug), c->stream));
-#define QPL(KQV) hipLaunchKernelGGL(k_qp<KQV>, grid, dim3(64), 0, c->stream, Ad, Btall, stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf, g_qp_refill_min, dbgp)
+#define QPL3(KQV, FULLV, PROFV)                                                               \
+    hipLaunchKernelGGL((k_qp<KQV, FULLV, PROFV>), grid, dim3(64), 0, c->stream, Ad, Btall, stride_j,  \
+                       stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf,  \
+                       g_qp_refill_min, dbgp)
+#define QPL(KQV)                                                                              \
+    do {                                                                                      \
+        if (dbgp) { if (k == KQV) QPL3(KQV, true, true); else QPL3(KQV, false, true); }       \
+        else      { if (k == KQV) QPL3(KQV, true, false); else QPL3(KQV, false, false); }     \
+    } while (0)
         switch (KQ) { case 4: QPL(4); break; case 8: QPL(8); break; case 16: QPL(16); break;
                       default: QPL(32); break; }
+#undef QPL3
 #undef QPL
         if (cap < p->max_iterations) {
             // phase 2: the stragglers, one wave each (grid is fixed; the count is read on
@@ -956,6 +1000,10 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                         (double)d.cyc_total / d.waves, 100.0 * d.cyc_proj / d.cyc_total,
                         100.0 * d.cyc_matvec / d.cyc_total, 100.0 * d.cyc_step / d.cyc_total,
                         100.0 * d.cyc_fin / d.cyc_total, (double)d.cyc_total / d.trips);
+            if (d.waves && d.proj_lanes)
+                fprintf(stderr, "[qp_profile] Michelot rounds per projection: lane mean %.2f, wave max (residual "
+                        "projection) %.2f\n", (double)d.proj_rounds_lanesum / d.proj_lanes,
+                        (double)d.proj_rounds_wavemax / d.proj_calls);
         }
     }
     return AA_OK;
