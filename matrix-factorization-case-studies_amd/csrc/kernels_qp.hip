@@ -299,6 +299,12 @@ __device__ __forceinline__ void qp_matvec_mfma(const double (&Breg)[KQ / 16][KQ 
 
 // PROF: cycle accounting compiled in (aa_set_option("qp_profile", 1)); the counters cost
 // registers, so the production instantiation has none of it.
+// Components k..KQ-1 are padding.  Their x is 0 and their gradient is held at QP_PAD = 1e300
+// (b_i = QP_PAD, the padded rows of A are zero), so x - a g is hugely negative for every step
+// a > 0, they never enter a support, their direction and residual are exactly 0, and the pass
+// loop needs no `component < k` predicate at all (32 wave-uniform predicates that hipcc kept
+// in SGPR pairs, spilled, and branched on).  Only the start-up and the final store test i < k.
+#define QP_PAD 1e300
 template <int KQ, bool FULL, bool PROF>
 __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][KQ]*/,
                                            const double *__restrict__ B, long stride_j,
@@ -370,11 +376,11 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                 // ---- start-up: x = P(z0); g = A x + b; f = x'(g + b)/2      (spg.py:298-315)
 #pragma unroll
                 for (int i = 0; i < KQ; ++i) {
-                    x[i] = (FULL || i < k) ? Z[row * ldz + i] : 0.0;
+                    x[i] = (FULL || i < k) ? Z[row * ldz + i] : -QP_PAD;   // padding: never in a support
                     g[i] = 0.0;
                 }
                 support = 0;
-                const double t0 = qp_project_threshold<KQ, FULL>(x, g, 0.0, k, support);
+                const double t0 = qp_project_threshold<KQ, true>(x, g, 0.0, k, support);
                 support_r = support;
 #pragma unroll
                 for (int i = 0; i < KQ; ++i) x[i] = (FULL || i < k) ? fmax(x[i] - t0, 0.0) : 0.0;
@@ -395,17 +401,17 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                 if (p.alpha_min <= p.alpha0 && p.alpha0 <= p.alpha_max) {
                     alpha = p.alpha0;
                 } else {
-                    const double t1 = qp_project_threshold<KQ, FULL>(x, g, 1.0, k, support_r);
+                    const double t1 = qp_project_threshold<KQ, true>(x, g, 1.0, k, support_r);
                     double ainv = 0.0;
 #pragma unroll
                     for (int i = 0; i < KQ; ++i)
-                        if (FULL || i < k) ainv = fmax(ainv, fabs(fmax(x[i] - g[i] - t1, 0.0) - x[i]));
+                        ainv = fmax(ainv, fabs(fmax(x[i] - g[i] - t1, 0.0) - x[i]));
                     if (fabs(ainv) < 1e-12) ainv = 1.0;
                     alpha = fmin(fmax(p.alpha_min, 1.0 / ainv), p.alpha_max);
                 }
             }
             int rd_d = 0;
-            td = qp_project_threshold<KQ, FULL>(x, g, alpha, k, support, PROF ? &rd_d : nullptr);
+            td = qp_project_threshold<KQ, true>(x, g, alpha, k, support, PROF ? &rd_d : nullptr);
             if constexpr (PROF) {
                 pc_lane_rounds += rd_d;
                 pc_lane_calls += 1;
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             dd = 0.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
-                const double di = (FULL || i < k) ? fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i] : 0.0;
+                const double di = fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i];
                 vl[i * VS] = di;                 // to LDS for the mat-vec; recomputed below
                 delta = fma(di, g[i], delta);
                 dd = fma(di, di, dd);
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
                 const double bi =
-                    (FULL || i < k) ? -B[i * stride_j + row * stride_t] * (bscale ? bscale[i] : 1.0) : 0.0;
+                    (FULL || i < k) ? -B[i * stride_j + row * stride_t] * (bscale ? bscale[i] : 1.0) : QP_PAD;
                 g[i] = Ad[i] + bi;
                 xg = fma(x[i], g[i], xg);
                 xb = fma(x[i], bi, xb);
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             double dAd = 0.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
-                const double di = (FULL || i < k) ? fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i] : 0.0;
+                const double di = fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i];
                 dAd = fma(di, Ad[i], dAd);
             }
             // non-monotone reference value (spg.py:341-344): roll, store, nanmax
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             }
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
-                const double di = (FULL || i < k) ? fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i] : 0.0;
+                const double di = fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i];
                 x[i] = fma(lam, di, x[i]);
                 g[i] = fma(lam, Ad[i], g[i]);
             }
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             QP_TOC(pc_step, ts0);
             QP_TIC(tp1);
             int rd_r = 0;
-            const double tr = qp_project_threshold<KQ, FULL>(x, g, 1.0, k, support_r, PROF ? &rd_r : nullptr);
+            const double tr = qp_project_threshold<KQ, true>(x, g, 1.0, k, support_r, PROF ? &rd_r : nullptr);
             if constexpr (PROF) {
                 pc_lane_rounds += rd_r;
                 pc_lane_calls += 1;
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
             double r2 = 0.0, rinf = 0.0;
 #pragma unroll
             for (int i = 0; i < KQ; ++i)
-                if (FULL || i < k) {
+                {
                     const double r = fmax(x[i] - g[i] - tr, 0.0) - x[i];
                     r2 = fma(r, r, r2);
                     rinf = fmax(rinf, fabs(r));
