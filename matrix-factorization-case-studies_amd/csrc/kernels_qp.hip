@@ -91,7 +91,7 @@ __device__ __forceinline__ double qp_project_threshold(const double (&x)[KQ], co
         for (int i = 0; i < KQ; ++i)
             if ((FULL || i < k) && (x[i] - a * g[i]) * cd > sm1) nm |= (M)1 << i;
         if (rounds) *rounds += 1;
-        if (nm == m || (pass >= 2 && __popcll((unsigned long long)nm) >= c)) break;
+        if (nm == m || (pass >= 2 && (int)__popcll((unsigned long long)nm) >= c)) break;
         m = nm;
     }
     mask = m;
@@ -657,7 +657,7 @@ __device__ __forceinline__ double qw_threshold(double w, int comp, unsigned long
         c = __popcll(m);
         s = qw_sum<HALF>(in ? w : 0.0);
         const unsigned long long nm = __ballot(w * (double)c > s - 1.0) & full;
-        if (nm == m || (pass >= 2 && __popcll(nm) >= c)) break;
+        if (nm == m || (pass >= 2 && (int)__popcll(nm) >= c)) break;
         m = nm;
     }
     mask = m;

@@ -13,9 +13,13 @@
 // and the finalize step is where the multi-GPU all-reduce is spliced in.
 //
 // The simplex projection does not sort: per column it runs Michelot's fixed point
-//   S <- {w > t},  t <- (sum_S w - 1)/|S|,   starting from t = max(w) - 1,
+//   S <- {w > t},  t <- (sum_S w - 1)/|S|,
 // which ends at exactly the support the reference's sorted scan finds and the same
-// closed form t = (sum of the m largest - 1)/m (simplex_projection.py:23).
+// closed form t = (sum of the m largest - 1)/m (simplex_projection.py:23).  Default form
+// ("candidate lists", below): one pass for a lower bound of t, one pass that copies the few
+// candidates above it, the fixed point on that short list, one pass that applies t.  The
+// iterative form (one full pass per Michelot round) is the fallback of the multi-rank path
+// and stays selectable (aa_set_option("proj_mode", 1)).
 #include "aa_internal.h"
 
 namespace aa {
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
         sm[threadIdx.x] = dot;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
-            if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+            if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
             __syncthreads();
         }
         if (threadIdx.x < KP) partial[(size_t)blockIdx.x * KP + threadIdx.x] = threadIdx.x == 0 ? sm[0] : 0.0;
@@ -967,7 +971,7 @@ __device__ double block_trace_MG(const double *__restrict__ M, const double *__r
     sm[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
         __syncthreads();
     }
     const double r = sm[0];
@@ -1078,7 +1082,7 @@ __global__ __launch_bounds__(256) void k_sqnorm(const T *__restrict__ X, long ld
     sm[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
         __syncthreads();
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
@@ -1095,7 +1099,7 @@ __global__ __launch_bounds__(256) void k_diag_sum(const T *__restrict__ K, long 
     sm[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
         __syncthreads();
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
@@ -1183,7 +1187,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__
     sm[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = sm[0];

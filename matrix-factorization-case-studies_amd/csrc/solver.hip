@@ -236,13 +236,6 @@ static int prepare(Ctx *c, double *cost)
 }
 
 // ----------------------------------------------------------------- dictionary SPG
-static int set_scalar(Ctx *c, int slot, double v)
-{
-    AA_CHECK_HIP(hipMemcpyAsync(c->scalars.as<double>() + slot, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
-    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-    return AA_OK;
-}
-
 static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, bool refresh)
 {
     AA_REQUIRE(c->have_state && (c->grams_valid || c->dict_inputs_overridden), AA_ERR_STATE,
