@@ -240,7 +240,8 @@ int aa_gpnh_residual_cost(aa_ctx *ctx, double *cost);
  * context's stream.  which: 0 = reduce-over-rows (C X, X'Z; k x p out),
  * 1 = row-local (CX X', X X'Z; n x k out), 2..5 = a plain streaming read of X (the read
  * bandwidth the memory system delivers; reference point for the roofline) with 4 / 8 / 16 / 8
- * loads in flight per thread on 4096 / 2048 / 1024 / 8192 blocks.
+ * loads in flight per thread on 4096 / 2048 / 1024 / 8192 blocks; 6 / 7 = the load pattern
+ * of the row-local kernel alone, from the row-major matrix / from a tiled view of the same bytes.
  * ms_avg = average duration of one launch in milliseconds. */
 int aa_time_kernel(aa_ctx *ctx, int which, int reps, double *ms_avg);
 /* In-context timing of the two pass kernels: while enabled, every launch of the

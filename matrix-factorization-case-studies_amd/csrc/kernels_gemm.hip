@@ -637,13 +637,45 @@ __global__ __launch_bounds__(256) void k_stream_probe(const f32x4 *__restrict__ 
     if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = 1.f;   // keeps the loads alive
 }
 
+// the load pattern of k_row_local_f32_ws without its LDS / MFMA work: a wave owns 32 rows and
+// walks the columns in 64-column tiles (TILED = false: 32 pieces of 256 B, 16 KB apart, per
+// tile, as in the row-major matrix; TILED = true: the same bytes as one contiguous 8 KB chunk,
+// i.e. what a [32 x 64]-tiled storage of X would give)
+template <bool TILED>
+__global__ __launch_bounds__(832) void k_stream_probe_rows(const float *__restrict__ X, long ldx,
+                                                           long n_pad, int p_pad,
+                                                           float *__restrict__ sink)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r0 = ((long)blockIdx.x * 13 + wave) * 32;
+    if (r0 >= n_pad) return;
+    const int xr = lane >> 4, xc = lane & 15;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < p_pad; c0 += 128) {
+        f32x4 v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int tile = e >> 3, ee = e & 7;
+            const long off = TILED ? (r0 * ldx + (long)(c0 / 64 + tile) * 2048 + (4 * ee + xr) * 64 + 4 * xc)
+                                   : ((r0 + 4 * ee + xr) * ldx + c0 + 64 * tile + 4 * xc);
+            v[e] = *reinterpret_cast<const f32x4 *>(X + off);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc += v[e];
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = 1.f;
+}
+
 // variant: 0 = 4 loads in flight per thread x 4096 blocks; 1 = 8 x 2048; 2 = 16 x 1024; 3 = 8 x 8192
 int launch_stream_probe(Ctx *c, int variant)
 {
     const long bytes = (long)c->n_pad * c->p_pad * (c->dtype == AA_F32 ? 4 : 8);
     const f32x4 *x = reinterpret_cast<const f32x4 *>(c->X.p);
     float *sink = c->partial.as<float>();
+    const long tiles = c->n_pad / 32;
     switch (variant) {
+        case 4: hipLaunchKernelGGL(k_stream_probe_rows<false>, dim3((unsigned)((tiles + 12) / 13)), dim3(832), 0, c->stream, c->X.as<float>(), c->p_pad, c->n_pad, (int)c->p_pad, sink); break;
+        case 5: hipLaunchKernelGGL(k_stream_probe_rows<true>, dim3((unsigned)((tiles + 12) / 13)), dim3(832), 0, c->stream, c->X.as<float>(), c->p_pad, c->n_pad, (int)c->p_pad, sink); break;
         case 1: hipLaunchKernelGGL(k_stream_probe<8>, dim3(2048), dim3(256), 0, c->stream, x, bytes / 16, sink); break;
         case 2: hipLaunchKernelGGL(k_stream_probe<16>, dim3(1024), dim3(256), 0, c->stream, x, bytes / 16, sink); break;
         case 3: hipLaunchKernelGGL(k_stream_probe<8>, dim3(8192), dim3(256), 0, c->stream, x, bytes / 16, sink); break;

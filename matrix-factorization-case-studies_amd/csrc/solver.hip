@@ -1031,7 +1031,7 @@ int aa_time_kernel(aa_ctx *h, int which, int reps, double *ms_avg)
                 rc = launch_reduce_rows(c, c->Ct.as<double>(), c->Q.as<double>(), nullptr, true);
             else if (which == 1)
                 rc = launch_row_local(c, operandT(c, c->P, c->Pw), c->Gn.as<double>());
-            else if (which >= 2 && which <= 5)
+            else if (which >= 2 && which <= 7)
                 rc = launch_stream_probe(c, which - 2);
             else {
                 set_error("aa_time_kernel: unknown kernel %d", which);

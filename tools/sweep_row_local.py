@@ -18,7 +18,7 @@ for v, w, sg in ((8, 0, 0), (4, 0, 0), (8, 0, 0)):
     if ref is None: ref = g
     print("variant %d waves %d stagger %d: %.4f ms  %.2f TB/s   max|dCKZ| %.2e" % (v, w, sg, ms, n * p * 4 / ms / 1e9, np.abs(g - ref).max()), flush=True)
 print("reduce_rows: %.4f ms" % ctx.time_kernel(0, 40))
-for w, label in ((2, "4 loads x 4096 blocks"), (3, "8 x 2048"), (4, "16 x 1024"), (5, "8 x 8192")):
+for w, label in ((2, "4 loads x 4096 blocks"), (5, "8 x 8192"), (6, "ws pattern, row-major"), (7, "ws pattern, tiled 8 KB"), (6, "ws pattern, row-major"), (7, "ws pattern, tiled 8 KB")):
     ctx.time_kernel(w, 3); ms = ctx.time_kernel(w, 20)
     print("stream probe %-22s %.4f ms  %.2f TB/s" % (label, ms, n * p * 4 / ms / 1e9), flush=True)
 _backend.set_option("row_local_variant", -1); _backend.set_option("row_local_waves", 0); _backend.set_option("row_local_stagger", 0)
