@@ -234,7 +234,18 @@ __global__ __launch_bounds__(256) void k_proj_collect(const double *__restrict__
     double *dst = list + ((long)comp * nseg + seg) * segcap;
     const double th = ps->t[comp];
     int cnt = 0;
-    for (long r = rb + rsub; r < re; r += RS) {
+    // eight rows per step with their loads issued together (the conditional store would
+    // otherwise serialise one memory latency per row)
+    long r = rb + rsub;
+    for (; r + 7 * RS < re; r += 8 * RS) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = w[(r + u * RS) * KP + comp];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v[u] > th) dst[cnt++] = v[u];
+    }
+    for (; r < re; r += RS) {
         const double v = w[r * KP + comp];
         if (v > th) dst[cnt++] = v;
     }

@@ -687,3 +687,31 @@ def test_graph_replay_is_bit_identical(cdr, orc, n_outer):
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     assert np.all(np.diff(np.asarray(a[0]).ravel()) < 1e-6)        # costs keep decreasing
+
+
+def test_gemm_timing_counts_launches(cdr, orc):
+    """aa_gemm_timing brackets every launch of the two pass kernels with HIP events: two of
+    each per outer iteration once the dictionary products are warm; the timing mode does
+    not change results."""
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(2)
+    n, p, k = 1200, 256, 5
+    X = rng.standard_normal((n, p)).astype(np.float32)
+    C = orc.right_stochastic_matrix((k, n), rng)
+    Z = orc.right_stochastic_matrix((n, k), rng)
+    outs = []
+    for timed in (False, True):
+        with _backend.Context(dtype="float32") as ctx:
+            ctx.set_data(X)
+            ctx.set_state(C, Z, np.ones(k))
+            ctx.prepare()
+            ctx.outer_iterations(1, dict(max_iterations=1), {})
+            assert ctx.gemm_timing(timed) == (0.0, 0, 0.0, 0)
+            costs = ctx.outer_iterations(3, dict(max_iterations=1), {})
+            ms_r, n_r, ms_l, n_l = ctx.gemm_timing(False)
+            outs.append(np.asarray(costs))
+            if timed:
+                assert (n_r, n_l) == (6, 6) and ms_r > 0 and ms_l > 0
+            else:
+                assert (n_r, n_l) == (0, 0)
+    assert np.array_equal(outs[0], outs[1])
