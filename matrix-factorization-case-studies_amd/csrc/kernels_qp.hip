@@ -837,7 +837,11 @@ __global__ __launch_bounds__(256) void k_qp_project_only(const double *__restric
 // Passes a sample may spend in the lane-per-sample kernel before it is handed to the
 // wave-per-sample kernel.
 int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
-int g_qp_refill_min = 24;      // idle lanes of a wave that trigger a refill (1..64)
+int g_qp_refill_min = 64;      // idle lanes of a wave that trigger a refill (1..64); 64 = only
+                               // when the whole wave is idle: a sample's start-up (strided row
+                               // loads, a cold projection) is executed by the whole wave, and
+                               // mid-flight refills cost more than the idle lanes they fill
+                               // (2.64 ms per outer iteration against 2.83 at 24)
 int g_qp_mode = 0;             // 0: by size, 1: wave-per-sample only, 2: lane-per-sample then wave-per-sample
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
 int g_qp_profile = 0;          // cycle accounting of k_qp (printed when stats are requested)
