@@ -110,6 +110,9 @@ int aa_device_count(int *count);
  *                               before it moves to the wave-per-sample kernel
  *   "qp_refill_min"     1..64  idle lanes of a wave that trigger pulling new samples (default
  *                               64: a wave works off 64 samples at a time)
+ *   "qp_sort"           0|1    1 (default): the lane-per-sample kernel takes the samples in the
+ *                               order of their pass counts in the previous weights update,
+ *                               longest first
  *   "qp_waves"          >= 1   most waves (64 samples each) the lane-per-sample kernel runs
  *                               at once; samples beyond that are pulled in as lanes free up
  *   "qp_overlap_tail"   0|1    1: the wave-per-sample kernel of the stragglers runs on a side

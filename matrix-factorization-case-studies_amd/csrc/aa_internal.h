@@ -175,7 +175,9 @@ struct Ctx {
     DevBuf proj;                               // ProjState
     DevBuf projList, projSegCnt;               // candidate lists of the column projection
     DevBuf Mdev, alphaDev;                     // KP*KP, KP
-    DevBuf qpIters;                            // n ints
+    DevBuf qpIters;                            // n ints: pass counts of the latest weights update
+    DevBuf qpPerm;                             // n ints: sample order of the lane kernel
+    bool qp_iters_valid = false;               // qpIters belongs to the current rows / state
     DevBuf qpStats;                            // 2 long long
     void *hostPinned = nullptr;                // small pinned staging
     size_t hostPinnedBytes = 0;
@@ -258,6 +260,7 @@ extern int g_qp_pass_cap;         // kernels_qp.hip
 extern int g_qp_mode;             // kernels_qp.hip
 extern int g_qp_refill_min;       // kernels_qp.hip
 extern int g_qp_waves;            // kernels_qp.hip
+extern int g_qp_sort;             // kernels_qp.hip
 extern int g_qp_profile;          // kernels_qp.hip
 extern int g_qp_overlap_tail;     // kernels_qp.hip
 

@@ -346,8 +346,10 @@ static int weights_update(Ctx *c, const aa_qp_params *qp, aa_qp_stats *stats)
     AA_REQUIRE(c->have_state && c->grams_valid, AA_ERR_STATE, "weights_update needs prepare() first");
     // Hessian D C K C' D (archetypal_analysis.py:387) and b-scale D are set up on the device
     const bool defer = g_qp_overlap_tail && c->form == AA_FORM_DATA;
+    AA_CHECK(c->qpIters.alloc((size_t)c->n * sizeof(int)));
     AA_CHECK(launch_qp(c, nullptr, c->Gr.as<double>(), 1, c->KP, nullptr, c->Zt.as<double>(), c->KP, c->n,
-                       c->k, qp, nullptr, stats, dev_CKCt(c), defer));
+                       c->k, qp, c->qpIters.as<int>(), stats, dev_CKCt(c), defer));
+    c->qp_iters_valid = true;
     AA_CHECK(refresh_after_weights(c));
     return AA_OK;
 }
@@ -404,6 +406,8 @@ int aa_set_option(const char *name, int value)
         g_use_graph = value != 0;
     } else if (!strcmp(name, "qp_profile")) {
         g_qp_profile = value != 0;
+    } else if (!strcmp(name, "qp_sort")) {
+        g_qp_sort = value != 0;
     } else if (!strcmp(name, "qp_waves")) {
         AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_waves must be >= 1");
         g_qp_waves = value;
@@ -464,7 +468,7 @@ int aa_ctx_destroy(aa_ctx *h)
     comm_destroy(c);
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->redPartial,
-                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters,
+                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters, &c->qpPerm,
                      &c->qpStats};
     for (DevBuf *b : all) b->release();
     for (int w = 0; w < 2; ++w)
@@ -592,6 +596,7 @@ int aa_set_state(aa_ctx *h, int k, const double *C, long ldc, const double *Z, c
     for (int i = 0; i < k; ++i) c->alpha[i] = alpha ? alpha[i] : 1.0;
     AA_CHECK(upload_alpha(c));
     c->have_state = true;
+    c->qp_iters_valid = false;
     c->grams_valid = false;
     c->dict_inputs_overridden = false;
     c->x_feasible = false;

@@ -715,3 +715,31 @@ def test_gemm_timing_counts_launches(cdr, orc):
             else:
                 assert (n_r, n_l) == (0, 0)
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_qp_sample_order_does_not_change_results(cdr, orc):
+    """The lane kernel takes the samples longest-first by their pass counts in the previous
+    weights update; samples are independent, so the order cannot change a single bit."""
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(31)
+    n, p, k = 2300, 180, 11
+    X = rng.standard_normal((n, p)).astype(np.float32)
+    C = orc.right_stochastic_matrix((k, n), rng)
+    Z = orc.right_stochastic_matrix((n, k), rng)
+    out = []
+    _backend.set_option("qp_mode", 2)
+    try:
+        for sort in (0, 1):
+            _backend.set_option("qp_sort", sort)
+            with _backend.Context(dtype="float32") as ctx:
+                ctx.set_data(X)
+                ctx.set_state(C, Z, np.ones(k))
+                ctx.prepare()
+                costs = np.asarray(ctx.outer_iterations(5, dict(max_iterations=1), {}))
+                Cf, Zf, _ = ctx.get_state()
+                out.append((costs, Cf, Zf))
+    finally:
+        _backend.set_option("qp_sort", 1)
+        _backend.set_option("qp_mode", 0)
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
