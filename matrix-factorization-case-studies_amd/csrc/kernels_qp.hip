@@ -851,38 +851,65 @@ int g_qp_waves = 1024;         // most waves the lane-per-sample kernel is launc
 static int qp_pass_cap() { return g_qp_pass_cap < 1 ? 1 : g_qp_pass_cap; }
 
 // Order of the samples for the lane kernel: by the pass count of the PREVIOUS weights update,
-// longest first (counting sort, one block; the order inside a bucket is arbitrary, which
+// longest first (counting sort: block histograms, then block-wise scatter into per-bucket
+// ranges; the order inside a bucket depends on block scheduling, which
 // cannot change any result: samples are independent).  A wave then works on 64 samples of
 // similar length -- a batch ends when its slowest sample does (mean 18.6 instead of 23.8
 // trips at a 0.83 correlation between consecutive updates) -- and the long batches start
 // first, the short ones fill the second round.
 #define QP_SORT_BUCKETS 64
-__global__ __launch_bounds__(1024) void k_qp_order_rows(const int *__restrict__ prev_iters, long n,
-                                                        int *__restrict__ perm)
+#define QP_SORT_ROWS_PER_BLOCK 1024
+
+__device__ __forceinline__ int qp_sort_bucket(int it)
 {
-    __shared__ int hist[QP_SORT_BUCKETS], start[QP_SORT_BUCKETS];
+    return it < 0 ? 0 : (it >= QP_SORT_BUCKETS ? QP_SORT_BUCKETS - 1 : it);
+}
+
+__global__ __launch_bounds__(256) void k_qp_order_hist(const int *__restrict__ prev_iters, long n,
+                                                       int *__restrict__ ghist)
+{
+    __shared__ int hist[QP_SORT_BUCKETS];
+    if (threadIdx.x < QP_SORT_BUCKETS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long r0 = (long)blockIdx.x * QP_SORT_ROWS_PER_BLOCK;
+#pragma unroll
+    for (int j = 0; j < QP_SORT_ROWS_PER_BLOCK / 256; ++j) {
+        const long r = r0 + threadIdx.x + 256 * j;
+        if (r < n) atomicAdd(&hist[qp_sort_bucket(prev_iters[r])], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < QP_SORT_BUCKETS && hist[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], hist[threadIdx.x]);
+}
+
+// ghist: complete histogram; gcursor: per-bucket fill counters (zeroed).  Buckets are laid
+// out in DESCENDING order of the pass count; a block reserves one range per bucket.
+__global__ __launch_bounds__(256) void k_qp_order_scatter(const int *__restrict__ prev_iters, long n,
+                                                          const int *__restrict__ ghist,
+                                                          int *__restrict__ gcursor,
+                                                          int *__restrict__ perm)
+{
+    __shared__ int hist[QP_SORT_BUCKETS], cursor[QP_SORT_BUCKETS];
     const int t = threadIdx.x;
     if (t < QP_SORT_BUCKETS) hist[t] = 0;
     __syncthreads();
-    for (long r = t; r < n; r += 1024) {
-        int b = prev_iters[r];
-        b = b < 0 ? 0 : (b >= QP_SORT_BUCKETS ? QP_SORT_BUCKETS - 1 : b);
-        atomicAdd(&hist[b], 1);
+    const long r0 = (long)blockIdx.x * QP_SORT_ROWS_PER_BLOCK;
+    int bk[QP_SORT_ROWS_PER_BLOCK / 256];
+#pragma unroll
+    for (int j = 0; j < QP_SORT_ROWS_PER_BLOCK / 256; ++j) {
+        const long r = r0 + t + 256 * j;
+        bk[j] = r < n ? qp_sort_bucket(prev_iters[r]) : -1;
+        if (bk[j] >= 0) atomicAdd(&hist[bk[j]], 1);
     }
     __syncthreads();
-    if (t == 0) {
-        int acc = 0;
-        for (int b = QP_SORT_BUCKETS - 1; b >= 0; --b) {      // descending: longest first
-            start[b] = acc;
-            acc += hist[b];
-        }
+    if (t < QP_SORT_BUCKETS) {
+        int base = 0;
+        for (int b = QP_SORT_BUCKETS - 1; b > t; --b) base += ghist[b];
+        cursor[t] = base + (hist[t] ? atomicAdd(&gcursor[t], hist[t]) : 0);   // this block's range
     }
     __syncthreads();
-    for (long r = t; r < n; r += 1024) {
-        int b = prev_iters[r];
-        b = b < 0 ? 0 : (b >= QP_SORT_BUCKETS ? QP_SORT_BUCKETS - 1 : b);
-        perm[atomicAdd(&start[b], 1)] = (int)r;
-    }
+#pragma unroll
+    for (int j = 0; j < QP_SORT_ROWS_PER_BLOCK / 256; ++j)
+        if (bk[j] >= 0) perm[atomicAdd(&cursor[bk[j]], 1)] = (int)(r0 + t + 256 * j);
 }
 
 // device-side set-up of the QP scratch: header zeroed, A = D G D padded to KQ and KW,
@@ -993,10 +1020,16 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         // the previous update of this context; the kernels below overwrite them)
         const int *perm = nullptr;
         if (g_qp_sort && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid) {
-            AA_CHECK(c->qpPerm.alloc((size_t)n * sizeof(int)));
-            hipLaunchKernelGGL(k_qp_order_rows, dim3(1), dim3(1024), 0, c->stream, (const int *)iters_dev, n,
-                               c->qpPerm.as<int>());
-            perm = c->qpPerm.as<int>();
+            AA_CHECK(c->qpPerm.alloc((size_t)n * sizeof(int) + 2 * QP_SORT_BUCKETS * sizeof(int)));
+            int *pm = c->qpPerm.as<int>();
+            int *ghist = pm + n, *gcursor = ghist + QP_SORT_BUCKETS;
+            AA_CHECK_HIP(hipMemsetAsync(ghist, 0, 2 * QP_SORT_BUCKETS * sizeof(int), c->stream));
+            const unsigned nblk = (unsigned)((n + QP_SORT_ROWS_PER_BLOCK - 1) / QP_SORT_ROWS_PER_BLOCK);
+            hipLaunchKernelGGL(k_qp_order_hist, dim3(nblk), dim3(256), 0, c->stream, (const int *)iters_dev, n,
+                               ghist);
+            hipLaunchKernelGGL(k_qp_order_scatter, dim3(nblk), dim3(256), 0, c->stream,
+                               (const int *)iters_dev, n, (const int *)ghist, gcursor, pm);
+            perm = pm;
         }
         QpDebug *dbgp = g_qp_profile ? reinterpret_cast<QpDebug *>(base + 64) : (QpDebug *)nullptr;
         if (dbgp) AA_CHECK_HIP(hipMemsetAsync(dbgp, 0, sizeof(QpDebug), c->stream));
