@@ -684,6 +684,31 @@ __device__ __forceinline__ double qw_matvec(const double (&Arow)[KQ], double v)
     }
     return a0 + a1;
 }
+// Mirrored form (k <= 32): lane (i, h = lane >> 5) holds only columns 16h .. 16h+15 of row i
+// (half the registers) and sums its half of the product; the halves are exchanged and added,
+// so both mirror lanes end with the full (A v)_i.
+__device__ __forceinline__ double qw_matvec_half(const double (&Ahalf)[16], double v, int lane)
+{
+    const unsigned long long nz = __ballot(v != 0.0);
+    const bool hi = lane >= 32;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) {
+        if (((nz >> j) & 0xfull) | ((nz >> (16 + j)) & 0xfull)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double vlo = qw_readlane(v, j + u), vhi = qw_readlane(v, 16 + j + u);
+                const double vj = hi ? vhi : vlo;
+                if (u & 1) a1 = fma(Ahalf[j + u], vj, a1);
+                else a0 = fma(Ahalf[j + u], vj, a0);
+            }
+        }
+    }
+    const double part = a0 + a1;
+    const double other = __hiloint2double(__shfl_xor(__double2hiint(part), 32, 64),
+                                          __shfl_xor(__double2loint(part), 32, 64));
+    return hi ? other + part : part + other;       // columns 0..15 first in both lanes
+}
 
 template <int KQ>
 __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*[KQ][KQ]*/,
@@ -703,10 +728,15 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
     const int lane = threadIdx.x & 63;
     const int comp = HALF ? (lane & 31) : lane;     // HALF: the upper half mirrors the lower
     const bool live = comp < k;
-    // row `comp` of A in registers
-    double Arow[KQ];
+    // row `comp` of A in registers (mirrored form: each of the two lanes of a component keeps
+    // one half of the row)
+    double Arow[HALF ? 16 : KQ];
 #pragma unroll
-    for (int j = 0; j < KQ; ++j) Arow[j] = A[comp * KQ + j];
+    for (int j = 0; j < (HALF ? 16 : KQ); ++j) Arow[j] = A[comp * KQ + (HALF ? 16 * (lane >> 5) : 0) + j];
+    auto matvec = [&](double v) -> double {
+        if constexpr (HALF) return qw_matvec_half(Arow, v, lane);
+        else return qw_matvec<KQ>(Arow, v);
+    };
     const int mem = p.memory < 1 ? 1 : (p.memory > QP_MAXMEM ? QP_MAXMEM : p.memory);
     // n_fresh >= 0: process rows [0, n_fresh) from scratch; otherwise the overflow list
     const bool fresh = n_fresh >= 0;
@@ -730,7 +760,7 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             x = live ? fmax(x - t0, 0.0) : 0.0;
             support_r = support;
         }
-        double g = qw_matvec<KQ>(Arow, x) + b;
+        double g = matvec(x) + b;
         if (fresh) {
             double xg, xb;
             qw_sum2<HALF>(x * g, x * b, lane, xg, xb);
@@ -761,7 +791,7 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             const double d = live ? fmax(x - alpha * g - td, 0.0) - x : 0.0;
             double delta, dd;
             qw_sum2<HALF>(d * g, d * d, lane, delta, dd);
-            const double Ad = qw_matvec<KQ>(Arow, d);
+            const double Ad = matvec(d);
             const double dAd = qw_sum<HALF>(d * Ad);
 
 #pragma unroll
