@@ -20,12 +20,14 @@ k = 32
 A, B, Z0 = problem(64, k)
 t0, _ = timed(A, B, Z0, max_iterations=1, epsilon_two=0.0, epsilon_one=0.0)
 for cap, label in ((1, "wave kernel"), (100000, "lane kernel")):
+    _backend.set_option("qp_mode", 1 if cap == 1 else 2)     # the size rule would pick wave-only here
     _backend.set_option("qp_pass_cap", cap)
     for iters in (50, 200):
         t, it = timed(A, B, Z0, max_iterations=iters, epsilon_two=0.0, epsilon_one=0.0, max_feval=10**8)
         print("%s: n=64, %d forced passes: %.3f ms total, %.2f us per pass (call overhead ~%.3f ms)"
               % (label, iters, 1e3 * t, 1e6 * (t - t0) / (iters - 1), 1e3 * t0), flush=True)
 A, B, Z0 = problem(65536, k)
+_backend.set_option("qp_mode", 2)
 _backend.set_option("qp_pass_cap", 100000)
 t1, _ = timed(A, B, Z0, max_iterations=1, epsilon_two=0.0, epsilon_one=0.0)
 t, it = timed(A, B, Z0, max_iterations=17, epsilon_two=0.0, epsilon_one=0.0, max_feval=10**8)
