@@ -96,6 +96,8 @@ int aa_device_count(int *count);
  *                               block-tiled (2: 64-column tiles, 3: 64 double-buffered,
  *                               4: 128, 5: 32 double-buffered, 6: 128 double-buffered, 7: 32),
  *                               8 wave-streaming (wave-private X tiles, shared B slabs)
+ *   "f64_mfma"          0|1    float64 data: 1 (default) pass kernels on the f64 matrix cores, 0 on
+ *                               the f64 VALU
  *   "row_local_waves"   0..16  waves per block of variant 8 (0: one block per CU)
  *   "proj_mode"         0|1    column simplex projection: 0 candidate lists, 1 iterative full
  *                               passes (also the fallback of a rank whose list overflows)

@@ -255,6 +255,7 @@ extern int g_row_local_variant;   // kernels_gemm.hip
 extern int g_row_local_waves;     // kernels_gemm.hip
 extern int g_row_local_stagger;   // kernels_gemm.hip
 extern int g_reduce_rows_unroll;  // kernels_gemm.hip
+extern int g_f64_mfma;            // kernels_gemm.hip
 extern int g_reduce_rows_blocks;  // kernels_gemm.hip
 extern int g_qp_pass_cap;         // kernels_qp.hip
 extern int g_qp_mode;             // kernels_qp.hip

@@ -133,6 +133,155 @@ __global__ __launch_bounds__(256) void k_reduce_rows_f64(const double *__restric
     for (int i = 0; i < KP; ++i) out[(size_t)i * p_pad + c] = acc[i];
 }
 
+// ---------------------------------------------------------------------------
+// float64 data (the reference dtype) on the f64 matrix cores, v_mfma_f64_16x16x4_f64:
+// A-operand lane l = Aop[m = l&15][k = l>>4], B-operand lane l = Bop[n = l&15][k = l>>4],
+// D lane l, reg r = D[m = (l>>4) + 4r][n = l&15]   (D = Aop * Bop').
+// ---------------------------------------------------------------------------
+typedef double f64x4g __attribute__((ext_vector_type(4)));
+typedef double f64x2g __attribute__((ext_vector_type(2)));
+
+// reduce over rows: D[m = component][n = column] += sum over 4 rows.  A wave owns a
+// 64-column strip and a row slab; per 4 rows a lane loads NT doubles of the tall operand and
+// two 16-byte pieces of X (columns c0 + 32u + 2*(l&15) + e: the two doubles of a piece feed
+// the B operands of two different column tiles, so the loads are 256 contiguous bytes per
+// row and quarter-wave).  Two register sets, software-pipelined as in k_reduce_rows_f32.
+template <int NT>
+__global__ __launch_bounds__(256) void k_reduce_rows_f64_mfma(const double *__restrict__ X, long ldx,
+                                                              const double *__restrict__ A,
+                                                              long rows_per_slab, long n_pad,
+                                                              int p_pad, double *__restrict__ partial)
+{
+    constexpr int KP = 16 * NT, U = 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = (blockIdx.x * 4 + wave) * 64;
+    if (c0 >= p_pad) return;   // wave-uniform; the kernel has no barriers
+    const int lc = lane & 15, lr = lane >> 4;
+    const long r_begin = (long)blockIdx.y * rows_per_slab;
+    long r_end = r_begin + rows_per_slab;
+    if (r_end > n_pad) r_end = n_pad;
+
+    f64x4g acc[NT][2][2];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) acc[ti][u][e] = (f64x4g){0.0, 0.0, 0.0, 0.0};
+
+    const double *xp = X + (r_begin + lr) * ldx + c0 + 2 * lc;
+    const double *ap = A + (r_begin + lr) * KP + lc;
+    f64x2g xa[U][2], xb[U][2];
+    double aa[U][NT], ab[U][NT];
+#define RD_LOAD(XV, AV, ROWOFF)                                                              \
+    _Pragma("unroll") for (int q = 0; q < U; ++q) {                                           \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u)                                         \
+            XV[q][u] = *reinterpret_cast<const f64x2g *>(xp + (long)((ROWOFF) + 4 * q) * ldx + 32 * u); \
+        _Pragma("unroll") for (int ti = 0; ti < NT; ++ti)                                     \
+            AV[q][ti] = ap[((ROWOFF) + 4 * q) * KP + 16 * ti];                                \
+    }
+#define RD_COMPUTE(XV, AV)                                                                   \
+    _Pragma("unroll") for (int q = 0; q < U; ++q)                                             \
+        _Pragma("unroll") for (int ti = 0; ti < NT; ++ti)                                     \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                     \
+                _Pragma("unroll") for (int e = 0; e < 2; ++e)                                 \
+                    acc[ti][u][e] = __builtin_amdgcn_mfma_f64_16x16x4f64(AV[q][ti], XV[q][u][e],   \
+                                                                         acc[ti][u][e], 0, 0, 0);
+    RD_LOAD(xa, aa, 0)
+    for (long r = r_begin; r < r_end; r += 8 * U) {
+        RD_LOAD(xb, ab, 4 * U)      // may run past r_end: X and A carry AA_SLACK_ROWS zero rows
+        __builtin_amdgcn_sched_barrier(0);
+        RD_COMPUTE(xa, aa)
+        __builtin_amdgcn_sched_barrier(0);
+        RD_LOAD(xa, aa, 8 * U)
+        __builtin_amdgcn_sched_barrier(0);
+        RD_COMPUTE(xb, ab)          // the row range is a multiple of 8*U
+        __builtin_amdgcn_sched_barrier(0);
+        xp += (long)(8 * U) * ldx;
+        ap += (8 * U) * KP;
+    }
+#undef RD_LOAD
+#undef RD_COMPUTE
+    double *out = partial + (size_t)blockIdx.y * KP * p_pad;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int comp = 16 * ti + lr + 4 * reg;
+                f64x2g v = {acc[ti][u][0][reg], acc[ti][u][1][reg]};
+                *reinterpret_cast<f64x2g *>(out + (size_t)comp * p_pad + c0 + 32 * u + 2 * lc) = v;
+            }
+}
+
+// row-local: D[m = row][n = component].  Block = 64 rows (a wave per 16), both operands
+// staged through LDS in 32-column tiles with coalesced 16-byte loads, register-prefetched one
+// tile ahead; LDS row stride 34 doubles => conflict-free fragment reads.
+template <int NT>
+__global__ __launch_bounds__(256) void k_row_local_f64_mfma(const double *__restrict__ X, long ldx,
+                                                            const double *__restrict__ B, int p_pad,
+                                                            double *__restrict__ out, long n_pad)
+{
+    constexpr int KP = 16 * NT, TC = 32, LS = 34;
+    constexpr int NB = KP * 16 / 256;                 // B chunks per thread and tile
+    __shared__ __attribute__((aligned(16))) double xs[64 * LS];
+    __shared__ __attribute__((aligned(16))) double bs[KP * LS];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int lc = lane & 15, lr = lane >> 4;
+    const long r0 = (long)blockIdx.x * 64;            // grid = n_pad / 64 exactly
+    f64x4g acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f64x4g){0.0, 0.0, 0.0, 0.0};
+
+    f64x2g sx[4], sb[NB];
+    auto load_tile = [&](int c0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int cid = t + 256 * e;
+            sx[e] = *reinterpret_cast<const f64x2g *>(X + (r0 + (cid >> 4)) * ldx + c0 + 2 * (cid & 15));
+        }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            const int cid = t + 256 * e;
+            sb[e] = *reinterpret_cast<const f64x2g *>(B + (long)(cid >> 4) * p_pad + c0 + 2 * (cid & 15));
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int cid = t + 256 * e;
+            *reinterpret_cast<f64x2g *>(xs + (cid >> 4) * LS + 2 * (cid & 15)) = sx[e];
+        }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            const int cid = t + 256 * e;
+            *reinterpret_cast<f64x2g *>(bs + (cid >> 4) * LS + 2 * (cid & 15)) = sb[e];
+        }
+    };
+    load_tile(0);
+    for (int c0 = 0; c0 < p_pad; c0 += TC) {
+        store_tile();
+        __syncthreads();
+        if (c0 + TC < p_pad) load_tile(c0 + TC);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < TC / 4; ++s) {
+            const double a = xs[(wave * 16 + lc) * LS + 4 * s + lr];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bs[(16 * nt + lc) * LS + 4 * s + lr],
+                                                               acc[nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            out[(r0 + wave * 16 + lr + 4 * reg) * KP + 16 * nt + lc] = acc[nt][reg];
+}
+
 // second stage of the split-row reduction: fixed summation order => deterministic.
 template <typename TP, typename TO>
 __global__ __launch_bounds__(256) void k_reduce_partials(const TP *__restrict__ partial, long nslab,
@@ -718,7 +867,14 @@ int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *out
     } else {
         dim3 grid((unsigned)((c->p_pad + 255) / 256), (unsigned)c->nslab);
         double *part = c->partial.as<double>();
-        if (c->KP == 32)
+        if (g_f64_mfma) {
+            if (c->KP == 32)
+                hipLaunchKernelGGL(k_reduce_rows_f64_mfma<2>, grid, block, 0, c->stream, c->X.as<double>(),
+                                   c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
+            else
+                hipLaunchKernelGGL(k_reduce_rows_f64_mfma<4>, grid, block, 0, c->stream, c->X.as<double>(),
+                                   c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
+        } else if (c->KP == 32)
             hipLaunchKernelGGL(k_reduce_rows_f64<32>, grid, block, 0, c->stream, c->X.as<double>(),
                                c->p_pad, A_tall, c->rows_per_slab, c->n_pad, (int)c->p_pad, part);
         else
@@ -772,6 +928,7 @@ int launch_reduce_rows_fixup(Ctx *c, const unsigned int *count_dev, const int *r
 // 4 (default) = 128, 5 = 32 double-buffered, 6 = 128 double-buffered, 7 = 32;
 // 8: wave-streaming (wave-private X tiles, B slabs shared per block).  aa_set_option.
 int g_row_local_variant = -1;   // -1: by size (8 from 32768 rows per GPU, else 4)
+int g_f64_mfma = 1;            // float64 data: pass kernels on the f64 matrix cores (0: f64 VALU)
 int g_reduce_rows_unroll = 4;  // row pairs per software-pipeline half step (4 or 8; k <= 32)
 int g_reduce_rows_blocks = 512; // target block count of the reduce-over-rows kernel
 int g_row_local_stagger = 0;   // variant 8: column-slab offset between consecutive blocks
@@ -859,7 +1016,14 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
     } else {
         const double *B = reinterpret_cast<const double *>(B_wideT);
         dim3 grid((unsigned)(c->n_pad / 64));
-        if (c->KP == 32)
+        if (g_f64_mfma) {
+            if (c->KP == 32)
+                hipLaunchKernelGGL(k_row_local_f64_mfma<2>, grid, block, 0, c->stream, c->X.as<double>(),
+                                   c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
+            else
+                hipLaunchKernelGGL(k_row_local_f64_mfma<4>, grid, block, 0, c->stream, c->X.as<double>(),
+                                   c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
+        } else if (c->KP == 32)
             hipLaunchKernelGGL(k_row_local_f64<32>, grid, block, 0, c->stream, c->X.as<double>(),
                                c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
         else
