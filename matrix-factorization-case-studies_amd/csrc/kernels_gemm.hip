@@ -282,6 +282,113 @@ __global__ __launch_bounds__(256) void k_row_local_f64_mfma(const double *__rest
             out[(r0 + wave * 16 + lr + 4 * reg) * KP + 16 * nt + lc] = acc[nt][reg];
 }
 
+// row-local, float64, "wave-streaming" form (the structure of k_row_local_f32_ws): a block is
+// W waves on one CU, every wave owns 32 rows (two 16-row MFMA tiles) for the whole kernel
+// and streams them through a wave-private LDS tile of 32 columns (256-byte row segments in,
+// fragments out, no barrier), one tile register-prefetched ahead; the small operand is shared
+// as double-buffered 64-column slabs (one barrier per slab).  Row strides of 34 / 66 doubles
+// make the fragment reads conflict free.  Dynamic LDS = 2 * KP * 66 * 8 + W * 32 * 34 * 8 B.
+template <int NT>
+__global__ __launch_bounds__(NT == 2 ? 1024 : 768) void k_row_local_f64_ws(const double *__restrict__ X, long ldx,
+                                                                             const double *__restrict__ B,
+                                                                             int p_pad, double *__restrict__ out,
+                                                                             long n_pad, int W)
+{
+    constexpr int KP = 16 * NT, SB = 64, TC = 32, XS = 34, BS = 66;
+    constexpr int NBI = NT;                          // B chunks per thread and slab at >= 512 threads
+    extern __shared__ __attribute__((aligned(16))) double wsd_smem[];
+    const int t = threadIdx.x, lane = t & 63, nthreads = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    double *bs = wsd_smem;
+    double *xs = wsd_smem + 2 * KP * BS + wave * (32 * XS);
+    const long r0 = ((long)blockIdx.x * W + wave) * 32;
+    const bool active = r0 < n_pad;
+    const long r0c = active ? r0 : n_pad - 32;       // surplus waves recompute the last tile
+    const int lc = lane & 15, lr = lane >> 4;
+
+    f64x4g acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f64x4g){0.0, 0.0, 0.0, 0.0};
+
+    f64x2g sb[NBI], sx[8];
+    auto load_b = [&](int c0) {
+#pragma unroll
+        for (int e = 0; e < NBI; ++e) {
+            const int cid = (t + e * nthreads) & (KP * 32 - 1);     // 32 chunks of 16 B per component
+            sb[e] = *reinterpret_cast<const f64x2g *>(B + (long)(cid >> 5) * p_pad + c0 + 2 * (cid & 31));
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < NBI; ++e) {
+            const int cid = (t + e * nthreads) & (KP * 32 - 1);
+            *reinterpret_cast<f64x2g *>(bs + buf * (KP * BS) + (cid >> 5) * BS + 2 * (cid & 31)) = sb[e];
+        }
+    };
+    const int xr = lane >> 4, xc = lane & 15;
+    const double *gx = X + (r0c + xr) * ldx + 2 * xc;
+    auto load_x = [&](int c0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            sx[e] = *reinterpret_cast<const f64x2g *>(gx + (long)(4 * e) * ldx + c0);
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            *reinterpret_cast<f64x2g *>(xs + (4 * e + xr) * XS + 2 * xc) = sx[e];
+    };
+    auto compute = [&](int buf, int half) {
+        const double *bb = bs + buf * (KP * BS) + half * TC;
+#pragma unroll
+        for (int s = 0; s < TC / 4; ++s) {
+            double bv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bb[(16 * nt + lc) * BS + 4 * s + lr];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const double a = xs[(16 * mt + lc) * XS + 4 * s + lr];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nslab = p_pad / SB;
+    load_b(0);
+    load_x(0);
+    store_b(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int c0 = s * SB;
+        const int snext = s + 1 < nslab ? s + 1 : s;       // last slab: harmless reload
+        store_x();                                // wave-private: LDS is in order per wave
+        load_x(c0 + TC);
+        load_b(snext * SB);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(s & 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        store_x();
+        store_b((s + 1) & 1);                     // that buffer was last read before the previous barrier
+        load_x(snext * SB);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(s & 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    if (active) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    out[(r0 + 16 * mt + lr + 4 * reg) * KP + 16 * nt + lc] = acc[mt][nt][reg];
+    }
+}
+
 // second stage of the split-row reduction: fixed summation order => deterministic.
 template <typename TP, typename TO>
 __global__ __launch_bounds__(256) void k_reduce_partials(const TP *__restrict__ partial, long nslab,
@@ -928,7 +1035,9 @@ int launch_reduce_rows_fixup(Ctx *c, const unsigned int *count_dev, const int *r
 // 4 (default) = 128, 5 = 32 double-buffered, 6 = 128 double-buffered, 7 = 32;
 // 8: wave-streaming (wave-private X tiles, B slabs shared per block).  aa_set_option.
 int g_row_local_variant = -1;   // -1: by size (8 from 32768 rows per GPU, else 4)
-int g_f64_mfma = 1;            // float64 data: pass kernels on the f64 matrix cores (0: f64 VALU)
+int g_f64_mfma = 1;            // float64 data: pass kernels on the f64 matrix cores (0: f64 VALU;
+                               // row-local: 1 = wave-streaming from 32768 rows, else block-tiled;
+                               // 2 / 3 = always wave-streaming / always block-tiled)
 int g_reduce_rows_unroll = 4;  // row pairs per software-pipeline half step (4 or 8; k <= 32)
 int g_reduce_rows_blocks = 512; // target block count of the reduce-over-rows kernel
 int g_row_local_stagger = 0;   // variant 8: column-slab offset between consecutive blocks
@@ -1016,7 +1125,31 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
     } else {
         const double *B = reinterpret_cast<const double *>(B_wideT);
         dim3 grid((unsigned)(c->n_pad / 64));
-        if (g_f64_mfma) {
+        if (g_f64_mfma == 2 || (g_f64_mfma == 1 && c->n_pad / 32 >= 8 * 128)) {
+            // wave-streaming kernel, W waves per block (see the float32 sibling)
+            const int nt = c->KP / 16;
+            const long tiles = c->n_pad / 32;
+            const int wmax = nt == 2 ? 14 : 10;                // 160 KB of LDS
+            int W = (int)((tiles + 255) / 256);
+            if (W < 8) W = 8;
+            if (W > wmax) W = wmax;
+            const size_t lds = ((size_t)2 * c->KP * 66 + (size_t)W * 32 * 34) * sizeof(double);
+            static bool attr_set64 = false;
+            if (!attr_set64) {
+                AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_local_f64_ws<2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_local_f64_ws<4>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set64 = true;
+            }
+            dim3 gw((unsigned)((tiles + W - 1) / W)), bw((unsigned)(64 * W));
+            if (nt == 2)
+                hipLaunchKernelGGL(k_row_local_f64_ws<2>, gw, bw, lds, c->stream, c->X.as<double>(), c->p_pad,
+                                   B, (int)c->p_pad, out_tall, c->n_pad, W);
+            else
+                hipLaunchKernelGGL(k_row_local_f64_ws<4>, gw, bw, lds, c->stream, c->X.as<double>(), c->p_pad,
+                                   B, (int)c->p_pad, out_tall, c->n_pad, W);
+        } else if (g_f64_mfma) {
             if (c->KP == 32)
                 hipLaunchKernelGGL(k_row_local_f64_mfma<2>, grid, block, 0, c->stream, c->X.as<double>(),
                                    c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);

@@ -386,7 +386,8 @@ int aa_set_option(const char *name, int value)
         AA_REQUIRE(value == 0 || (value >= 8 && value <= 16), AA_ERR_ARG, "row_local_waves must be 0 or 8..16");
         g_row_local_waves = value;
     } else if (!strcmp(name, "f64_mfma")) {
-        g_f64_mfma = value != 0;
+        AA_REQUIRE(value >= 0 && value <= 3, AA_ERR_ARG, "f64_mfma must be in 0..3");
+        g_f64_mfma = value;
     } else if (!strcmp(name, "reduce_rows_unroll")) {
         AA_REQUIRE(value == 4 || value == 8, AA_ERR_ARG, "reduce_rows_unroll must be 4 or 8");
         g_reduce_rows_unroll = value;

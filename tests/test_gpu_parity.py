@@ -743,3 +743,28 @@ def test_qp_sample_order_does_not_change_results(cdr, orc):
         _backend.set_option("qp_mode", 0)
     for a, b in zip(*out):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("k", [7, 40])
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_row_local_f64_variants_agree(cdr, orc, mode, k):
+    """float64 data: the row-local GEMM on the f64 VALU (0), wave-streaming on the f64 matrix
+    cores (2) and block-tiled on the matrix cores (3) give the same Gram products."""
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(k)
+    n, p = 1111, 450
+    X = rng.standard_normal((n, p))
+    C = orc.right_stochastic_matrix((k, n), rng)
+    Z = orc.right_stochastic_matrix((n, k), rng)
+    _backend.set_option("f64_mfma", mode)
+    try:
+        with _backend.Context(dtype="float64") as ctx:
+            ctx.set_data(X)
+            ctx.set_state(C, Z, np.ones(k))
+            ctx.prepare()
+            ZtZ, CKCt, CKZ, trace = ctx.grams()
+    finally:
+        _backend.set_option("f64_mfma", 1)
+    want = C.dot(X.dot(X.T.dot(Z)))
+    assert np.abs(CKZ - want).max() < 1e-12 * np.abs(want).max()
+    assert np.abs(CKCt - C.dot(X).dot(C.dot(X).T)).max() < 1e-12 * np.abs(CKCt).max()
