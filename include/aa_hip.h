@@ -96,8 +96,9 @@ int aa_device_count(int *count);
  *                               block-tiled (2: 64-column tiles, 3: 64 double-buffered,
  *                               4: 128, 5: 32 double-buffered, 6: 128 double-buffered, 7: 32),
  *                               8 wave-streaming (wave-private X tiles, shared B slabs)
- *   "f64_mfma"          0|1    float64 data: 1 (default) pass kernels on the f64 matrix cores, 0 on
- *                               the f64 VALU
+ *   "f64_mfma"          0..3   float64 data: pass kernels on the f64 matrix cores (1, default: the
+ *                               row-local one wave-streaming from 32768 rows per GPU, else
+ *                               block-tiled; 2 / 3 force either) or on the f64 VALU (0)
  *   "row_local_waves"   0..16  waves per block of variant 8 (0: one block per CU)
  *   "proj_mode"         0|1    column simplex projection: 0 candidate lists, 1 iterative full
  *                               passes (also the fallback of a rank whose list overflows)
