@@ -12,12 +12,15 @@
 //       X W       gpnh_convex_coding.py:270,292,352
 //       K Z       archetypal_analysis.py:411,502             (kernel form)
 //
-// float32: v_mfma_f32_32x32x2_f32, operands loaded straight from HBM into the MFMA
-// fragment layout (each X element is read exactly once per pass; the small operand
-// comes from L2).  Algorithmic traffic per pass = n*p*4 bytes; 2*k*n*p flop; at
-// k = 32 the intensity is 16 flop/B (< the 19.7 flop/B ridge) => HBM-bound.
-// float64: same decomposition on the f64 VALU (v_fma_f64 runs at the f64 MFMA rate
-// on gfx950), used by the reference-dtype parity path.
+// float32 (v_mfma_f32_32x32x2_f32): every X element is read exactly once per pass.
+// Algorithmic traffic per pass = n*p*4 bytes; 2*k*n*p flop; at k = 32 the intensity is
+// 16 flop/B (< the 19.7 flop/B ridge) => HBM-bound.  reduce-over-rows loads X straight
+// from HBM into the MFMA operand layout; row-local contracts along the contiguous axis and
+// stages X through wave-private LDS tiles ("wave-streaming", k_row_local_f32_ws; older
+// variants stay selectable).
+// float64, the reference dtype (v_mfma_f64_16x16x4_f64): the same two structures,
+// k_reduce_rows_f64_mfma and k_row_local_f64_ws / _mfma; the f64 VALU kernels they replaced
+// remain behind aa_set_option("f64_mfma", 0).
 #include "aa_internal.h"
 
 namespace aa {
