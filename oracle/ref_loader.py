@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE -- never imported by the product (``convex_dim_red``),
 never shipped, never run on the GPU box (``/root/reference`` does not exist
-there).  Only ``oracle/gen_golden.py`` and ``tests/test_oracle_vs_reference.py``
+there).  Only ``oracle/gen_golden.py`` and ``tests/test_oracle_golden.py``
 (skipped when the reference is absent) use it.
 
 The reference (``/root/reference/src/convex_dim_red``) is pure Python whose only

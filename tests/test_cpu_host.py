@@ -192,3 +192,43 @@ def test_solver_parameter_structs():
     assert (s.max_iterations, s.max_feval, s.alpha0, s.alpha_min) == (10000, 1000000, -1.0, 1e-5)
     with pytest.raises(TypeError):
         _backend.spg_params(bogus=1)
+
+
+# ---------------------------------------------------------------- k-means gap statistic (host)
+def test_gap_statistic_matches_its_definition():
+    """reference kmeans.py:81-108: distinct int32 seeds drawn first, one reference data set per
+    seed (uniform box / PCA box), KMeans(n_init=10) dispersion, gap = mean log W* - log W."""
+    from sklearn.cluster import KMeans
+    from sklearn.decomposition import TruncatedSVD
+    rng = np.random.RandomState(0)
+    centres = np.array([[0.0, 0.0, 0.0], [4.0, 4.0, 0.0], [0.0, 4.0, 4.0]])
+    X = np.vstack([c + 0.3 * rng.standard_normal((40, 3)) for c in centres])
+    Wk = KMeans(n_clusters=3, n_init=10, random_state=0).fit(X).inertia_
+    gap, sk = cdr.gap_statistic(X, Wk, 3, n_trials=6, random_state=5)
+    again = cdr.gap_statistic(X, Wk, 3, n_trials=6, random_state=5)
+    assert np.allclose((gap, sk), again, rtol=1e-12, atol=0)    # seeded: reproducible (up to the
+                                                                # threaded reduction order inside KMeans)
+    # the same quantity from the definition
+    srng = np.random.RandomState(5)
+    seeds = [srng.randint(np.iinfo(np.int32).max) for _ in range(6)]
+    logs = []
+    for s in seeds:
+        r = np.random.RandomState(s)
+        sample = (X.max(axis=0) - X.min(axis=0)) * r.uniform(size=X.shape) + X.min(axis=0)
+        logs.append(np.log(KMeans(n_clusters=3, n_init=10, random_state=r).fit(sample).inertia_))
+    assert abs(gap - (np.mean(logs) - np.log(Wk))) < 1e-12
+    assert abs(sk - np.std(logs) * np.sqrt(1 + 1.0 / 6)) < 1e-12
+    assert gap > 1.0                                            # three well separated clusters
+    g1, _ = cdr.gap_statistic(X, KMeans(n_clusters=1, n_init=10, random_state=0).fit(X).inertia_,
+                              1, n_trials=6, random_state=5)
+    assert gap > g1
+    # PCA reference: box drawn in the leading singular coordinates
+    from convex_dim_red import kmeans as km
+    w = km._calculate_pca_reference_wk(X, 3, n_components=2, random_state=3)
+    r = np.random.RandomState(3)
+    axes = TruncatedSVD(n_components=2, n_iter=10, random_state=r).fit(X).components_
+    Xp = X.dot(axes.T)
+    sample = ((Xp.max(axis=0) - Xp.min(axis=0)) * r.uniform(size=Xp.shape) + Xp.min(axis=0)).dot(axes)
+    assert abs(w - KMeans(n_clusters=3, n_init=10, random_state=r).fit(sample).inertia_) < 1e-9 * w
+    with pytest.raises(ValueError, match="unrecognized reference"):
+        cdr.gap_statistic(X, Wk, 3, n_trials=1, reference="nope")

@@ -1,4 +1,5 @@
 #!/bin/bash
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 # scratch: A/B of option sets on the benchmark in one box; usage: gpu_ab.sh "opts A" "opts B" ...
 mkdir -p gpurun_out
 i=0

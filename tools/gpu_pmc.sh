@@ -1,4 +1,5 @@
 #!/bin/bash
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 # scratch: HBM traffic counters for the two GEMM kernels (separate --pmc passes, as the
 # MI355X guide prescribes; no sys/hip trace domains together with --pmc)
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 # scratch: SQ-level counters of the GEMM kernels (one --pmc pass per counter group)
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 # scratch: kernel traces of the benchmark for two option sets
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp

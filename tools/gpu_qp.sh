@@ -1,4 +1,5 @@
 #!/bin/bash
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 TAG=${1:-x}
 timeout -k 10 200 python tools/qp_latency.py > gpurun_out/qplat_$TAG.log 2>&1 || { echo "latency failed"; tail gpurun_out/qplat_$TAG.log; exit 1; }

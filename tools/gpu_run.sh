@@ -1,4 +1,5 @@
 #!/bin/bash
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 # helper for gpurun calls (run from the repo root): tests, bench, rocprofv3 kernel stats
 mkdir -p gpurun_out
 TAG=${1:-x}
