@@ -122,9 +122,15 @@ int aa_device_count(int *count);
  *                               stream while Z'X is accumulated (float32 data); the rows it
  *                               changes enter Z'X as a rank-m correction.  Default 0: measured
  *                               neutral, the stragglers run 2x slower next to the GEMM
- *   "qp_mode"           0|1|2  0 (default): by size -- up to 16384 samples per GPU one wave per
- *                               sample, above that the lane-per-sample kernel followed by the
- *                               wave-per-sample kernel for the stragglers; 1 / 2 force either */
+ *   "qp_mode"           0..3   0 (default): the row kernel (16 lanes per sample, four samples
+ *                               per wave, samples run to completion) for k <= 32, one wave per
+ *                               sample for 32 < k <= 64; 1: one wave per sample; 2: the
+ *                               lane-per-sample kernel followed by the wave-per-sample kernel
+ *                               for the stragglers (round-1 default above 16384 samples);
+ *                               3: the row kernel (wave-per-sample above k = 32)
+ *   "qp_row_waves"      >= 1   most waves the row kernel runs with (default 3072: 3 per SIMD)
+ *   "qp_row_hot"        >= 0   SPG passes after which the wave of a sample raises its issue
+ *                               priority (also when the previous update needed twice as many) */
 int aa_set_option(const char *name, int value);
 
 /* -------------------------------------------- stateless ops (unit-test surface) */

@@ -259,6 +259,8 @@ extern int g_f64_mfma;            // kernels_gemm.hip
 extern int g_reduce_rows_blocks;  // kernels_gemm.hip
 extern int g_qp_pass_cap;         // kernels_qp.hip
 extern int g_qp_mode;             // kernels_qp.hip
+extern int g_qp_row_waves;        // kernels_qp.hip
+extern int g_qp_row_hot;          // kernels_qp.hip
 extern int g_qp_refill_min;       // kernels_qp.hip
 extern int g_qp_waves;            // kernels_qp.hip
 extern int g_qp_sort;             // kernels_qp.hip

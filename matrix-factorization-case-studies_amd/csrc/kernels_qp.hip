@@ -865,15 +865,367 @@ __global__ __launch_bounds__(256) void k_qp_project_only(const double *__restric
         if (i < k) Z[row * ldz + i] = fmax(x[i] - t0, 0.0);
 }
 
+// ---------------------------------------------------------------------------
+// ROW kernel (default for k <= 32): ONE DPP ROW (16 lanes) PER SAMPLE, CPL = 1 or 2
+// components per lane, four independent samples per wave, several waves per SIMD.
+//
+// Why a third mapping: the lane-per-sample kernel needs the whole sample state in one
+// lane's registers (one wave per SIMD, ~18 us per SPG pass), so it cannot finish the
+// heavy tail (a pass cap hands ~4 % of the samples, ~20 % of the passes, to the
+// wave-per-sample kernel) and its duration is bounded below by cap x 18 us; the
+// wave-per-sample kernel has the short pass (1.4 us) but runs one sample per wave.  A
+// 16-lane row keeps the short critical path -- every reduction is a four-step xor
+// butterfly on the DPP crossbar (quad_perm, quad_perm, row_half_mirror, row_mirror; both
+// partners add the same two numbers, so all 16 lanes end with identical bits and every
+// row-uniform decision is taken identically by every lane of the row) -- while a wave
+// carries four samples and a SIMD several waves, so the issue slots one latency-bound
+// chain leaves empty are filled by others.  Rows pull samples from the global queue
+// independently (longest first, k_qp_order_*), run them to completion (no pass cap, no
+// second kernel), and waves that hold a long-running sample raise their issue priority, so
+// the longest chain of the update runs at its own latency from t = 0 while the short
+// samples fill the machine around it.
+//
+// Per SPG pass of a row: direction projection (support-mask Michelot, one sum + one count
+// reduction per round), d, <d,g>, <d,d>; the direction goes through LDS (one 16-byte write
+// per lane, KQ/2 broadcast 16-byte reads) and A d is CPL*KQ FMAs against this lane's rows
+// of A (registers); d'Ad, the scalar Armijo loop, x, g, the BB step, the residual
+// projection and its norm: seven DPP reductions per pass.  A sample that starts puts P(z0)
+// through the same mat-vec slot (g = A x + b), like the lane kernel.  f_mem (spg.py:310,
+// 341-344) is distributed over the row (lane r holds f_mem[r]): memory up to 16.
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double qr_xchg(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int qr_xchg_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+// 0xB1 = quad_perm [1,0,3,2], 0x4E = quad_perm [2,3,0,1], 0x141 = row_half_mirror (the
+// values are quad-uniform by then, so i <-> 7 - i exchanges the two quads), 0x140 = row_mirror
+__device__ __forceinline__ double qr_sum(double v)
+{
+    v += qr_xchg<0xB1>(v);
+    v += qr_xchg<0x4E>(v);
+    v += qr_xchg<0x141>(v);
+    v += qr_xchg<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double qr_max(double v)
+{
+    v = fmax(v, qr_xchg<0xB1>(v));
+    v = fmax(v, qr_xchg<0x4E>(v));
+    v = fmax(v, qr_xchg<0x141>(v));
+    v = fmax(v, qr_xchg<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ int qr_sum_i(int v)
+{
+    v += qr_xchg_i<0xB1>(v);
+    v += qr_xchg_i<0x4E>(v);
+    v += qr_xchg_i<0x141>(v);
+    v += qr_xchg_i<0x140>(v);
+    return v;
+}
+// does any lane of this row (lanes rowshift .. rowshift + 15) satisfy p?
+__device__ __forceinline__ bool qr_any(bool p, int rowshift)
+{
+    return ((__ballot(p) >> rowshift) & 0xffffull) != 0ull;
+}
+
+// Threshold of the projection of the row-distributed vector w (CPL components per lane;
+// padding components carry a hugely negative w).  Same support-mask fixed point, same break
+// rule and the same closed form as qp_project_threshold / qw_threshold; `mask` holds the
+// support bits of this lane's own components.  Rows leave the loop independently.
+template <int CPL>
+__device__ __forceinline__ double qr_threshold(const double (&w)[CPL], unsigned &mask, int rowshift)
+{
+    unsigned m = mask;
+    int c = qr_sum_i(__popc(m));
+    double s = 0.0;
+    for (int pass = 0; pass < 32 * CPL + 8; ++pass) {
+        if (c == 0) {                              // cold start, or the warm guess emptied
+            double mx = w[0];
+#pragma unroll
+            for (int q = 1; q < CPL; ++q) mx = fmax(mx, w[q]);
+            const double t0 = qr_max(mx) - 1.0;
+            m = 0u;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q)
+                if (w[q] > t0) m |= 1u << q;
+            c = qr_sum_i(__popc(m));
+        }
+        double part = 0.0;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) part += ((m >> q) & 1u) ? w[q] : 0.0;
+        s = qr_sum(part);
+        const double sm1 = s - 1.0, cd = (double)c;
+        unsigned nm = 0u;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q)
+            if (w[q] * cd > sm1) nm |= 1u << q;
+        const int cn = qr_sum_i(__popc(nm));
+        const bool same = !qr_any(nm != m, rowshift);
+        if (same || (pass >= 2 && cn >= c)) break;
+        m = nm;
+        c = cn;
+    }
+    mask = m;
+    return (s - 1.0) / (double)c;
+}
+
+#define QR_MAXMEM 16
+template <int CPL>
+__global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[lda][lda], zero padded*/,
+                                               int lda, const double *__restrict__ B, long stride_j,
+                                               long stride_t, const double *__restrict__ bscale,
+                                               double *__restrict__ Z, int ldz, long n, int k,
+                                               aa_qp_params p, int *__restrict__ iters,
+                                               QpHeader *__restrict__ hdr,
+                                               const int *__restrict__ perm, int hot_passes)
+{
+    constexpr int KQ = 16 * CPL;
+    __shared__ __attribute__((aligned(16))) double vb[4][KQ];
+    const int lane = threadIdx.x, r = lane & 15, rowid = lane >> 4, rowshift = lane & 48;
+    const int comp0 = r * CPL;                     // this lane owns components comp0 .. comp0 + CPL - 1
+    // rows comp0.. of A in registers (A is symmetric: row = column)
+    double Ar[CPL][KQ];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) Ar[q][j] = A[(comp0 + q) * lda + j];
+    bool live[CPL];
+    double bs[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        live[q] = comp0 + q < k;
+        bs[q] = (bscale && live[q]) ? bscale[comp0 + q] : 1.0;
+    }
+    const int mem = p.memory < 1 ? 1 : (p.memory > QR_MAXMEM ? QR_MAXMEM : p.memory);
+
+    double x[CPL], g[CPL], d[CPL], v[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) x[q] = g[q] = d[q] = v[q] = 0.0;
+    double f = 0.0, alpha = 1.0, delta = 0.0, dd = 0.0;
+    double fm = NAN;                               // lane r: f_mem[r]
+    int n_iter = 0, n_feval = 0, predicted = 0;
+    long row = -1;
+    bool active = false, exhausted = false;
+    unsigned sup = 0u, sup_r = 0u;                 // supports of the latest direction / residual projection
+    int prio = 0;
+
+    for (long trip = 0; trip < (1L << 26); ++trip) {       // watchdog bound only
+        // ---- idle rows pull the next samples of the queue (one atomic per wave)
+        bool starting = false;
+        const bool want = !active && !exhausted;
+        const unsigned long long wb = __ballot(want && r == 0);
+        if (wb != 0ull) {
+            unsigned int base = 0u;
+            if (lane == 0) base = atomicAdd(&hdr->next_row, (unsigned int)__popcll(wb));
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (want) {
+                const long idx = (long)base + __popcll(wb & ((1ull << rowshift) - 1ull));
+                if (idx < n) {
+                    row = perm ? (long)perm[idx] : idx;
+                    starting = true;
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        if (!__any(active || starting)) break;
+        // waves that carry a long-running sample take issue priority: the longest chain of
+        // the update then runs at its own latency while short samples fill the gaps
+        {
+            const bool hot = active && (n_iter >= hot_passes || predicted >= 2 * hot_passes);
+            const int want_prio = __any(hot) ? 1 : 0;
+            if (want_prio != prio) {
+                if (want_prio) __builtin_amdgcn_s_setprio(3);
+                else __builtin_amdgcn_s_setprio(0);
+                prio = want_prio;
+            }
+        }
+
+        if (starting) {
+            // ---- start-up: x = P(z0)                                   (spg.py:298-300)
+            double w0[CPL];
+            unsigned m0 = 0u;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const double z = live[q] ? Z[row * ldz + comp0 + q] : 0.0;
+                w0[q] = live[q] ? z : -QP_PAD;
+                if (live[q] && z > 0.0) m0 |= 1u << q;     // z0 is (nearly) feasible: warm support
+            }
+            const double t0 = qr_threshold<CPL>(w0, m0, rowshift);
+            sup = m0;
+            sup_r = m0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                x[q] = live[q] ? fmax(w0[q] - t0, 0.0) : 0.0;
+                v[q] = x[q];
+            }
+            predicted = (perm && iters) ? iters[row] : 0;  // pass count of the previous update
+        } else if (active) {
+            // ---- one pass of the loop at spg.py:318-396, up to the search direction
+            if (n_iter == 0) {
+                if (p.alpha_min <= p.alpha0 && p.alpha0 <= p.alpha_max) {
+                    alpha = p.alpha0;
+                } else {
+                    double w1[CPL];
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) w1[q] = x[q] - g[q];
+                    const double t1 = qr_threshold<CPL>(w1, sup_r, rowshift);
+                    double am = 0.0;
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) am = fmax(am, fabs(fmax(w1[q] - t1, 0.0) - x[q]));
+                    double ainv = qr_max(am);
+                    if (fabs(ainv) < 1e-12) ainv = 1.0;
+                    alpha = fmin(fmax(p.alpha_min, 1.0 / ainv), p.alpha_max);
+                }
+            }
+            double w[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) w[q] = x[q] - alpha * g[q];
+            const double td = qr_threshold<CPL>(w, sup, rowshift);
+            double pg = 0.0, pd = 0.0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                d[q] = fmax(w[q] - td, 0.0) - x[q];
+                v[q] = d[q];
+                pg = fma(d[q], g[q], pg);
+                pd = fma(d[q], d[q], pd);
+            }
+            delta = qr_sum(pg);
+            dd = qr_sum(pd);
+        } else {
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) v[q] = 0.0;
+        }
+
+        // ---- A v for the four rows of the wave: v through LDS, rows of A from registers
+        double Av[CPL];
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) vb[rowid][comp0 + q] = v[q];
+            // one wave per block: LDS executes a wave's operations in order; the fences only
+            // keep the compiler from moving the reads above the writes of the other lanes
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            double acc[CPL][4];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[q][u] = 0.0;
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) {
+                const double vj = vb[rowid][j];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) acc[q][j & 3] = fma(Ar[q][j], vj, acc[q][j & 3]);
+            }
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) Av[q] = (acc[q][0] + acc[q][1]) + (acc[q][2] + acc[q][3]);
+        }
+
+        if (starting) {
+            // ---- g = A x + b; f = x'(g + b)/2                              (spg.py:302-315)
+            double pxg = 0.0, pxb = 0.0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const double bi = live[q] ? -B[(comp0 + q) * stride_j + row * stride_t] * bs[q] : QP_PAD;
+                g[q] = Av[q] + bi;
+                pxg = fma(x[q], g[q], pxg);
+                pxb = fma(x[q], bi, pxb);
+            }
+            f = 0.5 * (qr_sum(pxg) + qr_sum(pxb));
+            n_feval = 1;
+            n_iter = 0;
+            fm = NAN;
+            active = true;                         // its first pass runs in the next trip
+        } else if (active) {
+            double pq = 0.0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) pq = fma(d[q], Av[q], pq);
+            const double dAd = qr_sum(pq);
+            // non-monotone reference value (spg.py:341-344): roll, store, nanmax
+            double f_max = f;
+            if (mem > 1) {
+                const double up = qr_xchg<0x111>(fm);          // row_shr:1 -> f_mem[r - 1]
+                fm = r == 0 ? f : (r < mem ? up : NAN);
+                f_max = qr_max(fm == fm ? fm : -INFINITY);
+            }
+            double lam = 1.0;
+            double f_new = f + lam * delta + 0.5 * lam * lam * dAd;
+            n_feval += 1;
+            int guard = 0;
+            while (f_new > f_max + p.gamma * lam * delta && guard < 200) {
+                const double tmp = -0.5 * lam * lam * delta / (f_new - f - lam * delta);
+                lam = (p.sigma_one <= tmp && tmp <= p.sigma_two * lam) ? tmp : 0.5 * lam;
+                f_new = f + lam * delta + 0.5 * lam * lam * dAd;
+                n_feval += 1;
+                ++guard;
+                if (fabs(lam) < p.lambda_min) break;
+            }
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                x[q] = fma(lam, d[q], x[q]);
+                g[q] = fma(lam, Av[q], g[q]);
+            }
+            const double sksk = lam * lam * dd;
+            const double beta = lam * (lam * dAd);
+            alpha = (beta <= 0.0) ? p.alpha_max : fmin(p.alpha_max, fmax(p.alpha_min, sksk / beta));
+            f = f_new;
+            n_feval += 1;
+
+            double wr[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) wr[q] = x[q] - g[q];
+            const double tr = qr_threshold<CPL>(wr, sup_r, rowshift);
+            double pr2 = 0.0;
+            bool big = false;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const double rr = fmax(wr[q] - tr, 0.0) - x[q];
+                pr2 = fma(rr, rr, pr2);
+                big = big || !(fabs(rr) < p.epsilon_one);
+            }
+            const double r2 = qr_sum(pr2);
+            const bool rinf_small = !qr_any(big, rowshift);
+            n_iter += 1;
+            const bool conv = (sqrt(r2) < p.epsilon_two) || rinf_small;
+            if (conv || n_feval > p.max_feval || n_iter >= p.max_iterations) {
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+                    if (live[q]) Z[row * ldz + comp0 + q] = x[q];
+                if (r == 0) {
+                    if (iters) iters[row] = n_iter;
+                    atomicAdd(&hdr->total_passes, (unsigned long long)n_iter);
+                    atomicMax(&hdr->max_passes, (unsigned long long)n_iter);
+                }
+                active = false;
+            }
+        }
+    }
+}
+
 // Passes a sample may spend in the lane-per-sample kernel before it is handed to the
 // wave-per-sample kernel.
 int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
+int g_qp_row_waves = 3072;     // most waves of the row kernel (k_qp_row): 3 per SIMD
+int g_qp_row_hot = 24;         // passes after which a sample's wave takes issue priority
 int g_qp_refill_min = 64;      // idle lanes of a wave that trigger a refill (1..64); 64 = only
                                // when the whole wave is idle: a sample's start-up (strided row
                                // loads, a cold projection) is executed by the whole wave, and
                                // mid-flight refills cost more than the idle lanes they fill
                                // (2.64 ms per outer iteration against 2.83 at 24)
-int g_qp_mode = 0;             // 0: by size, 1: wave-per-sample only, 2: lane-per-sample then wave-per-sample
+int g_qp_mode = 0;             // 0: row kernel (k <= 32) / wave-per-sample, 1: wave-per-sample only,
+                               // 2: lane-per-sample then wave-per-sample, 3: row kernel
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
 int g_qp_profile = 0;          // cycle accounting of k_qp (printed when stats are requested)
 int g_qp_sort = 1;             // order the samples by the previous update's pass counts
@@ -970,6 +1322,21 @@ __global__ __launch_bounds__(256) void k_qp_setup(QpHeader *__restrict__ hdr, do
     if (t < 64) bsd[t] = t < k ? alpha[t] : 1.0;
 }
 
+// counting sort of the samples by their previous pass counts, longest first -> *perm_out
+static int qp_order_rows(Ctx *c, const int *iters_dev, long n, const int **perm_out)
+{
+    AA_CHECK(c->qpPerm.alloc((size_t)n * sizeof(int) + 2 * QP_SORT_BUCKETS * sizeof(int)));
+    int *pm = c->qpPerm.as<int>();
+    int *ghist = pm + n, *gcursor = ghist + QP_SORT_BUCKETS;
+    AA_CHECK_HIP(hipMemsetAsync(ghist, 0, 2 * QP_SORT_BUCKETS * sizeof(int), c->stream));
+    const unsigned nblk = (unsigned)((n + QP_SORT_ROWS_PER_BLOCK - 1) / QP_SORT_ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(k_qp_order_hist, dim3(nblk), dim3(256), 0, c->stream, iters_dev, n, ghist);
+    hipLaunchKernelGGL(k_qp_order_scatter, dim3(nblk), dim3(256), 0, c->stream, iters_dev, n,
+                       (const int *)ghist, gcursor, pm);
+    *perm_out = pm;
+    return AA_OK;
+}
+
 int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, long stride_t,
               const double *bscale_host, double *Ztall, int ldz, long n, int k,
               const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats, const double *gram_dev,
@@ -981,8 +1348,14 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     AA_REQUIRE(n < (1L << 31), AA_ERR_ARG, "QP: too many samples");
     // few samples (small shards of a multi-GPU run): the chip has more wave slots than
     // samples, so one wave per sample beats the >= pass-cap trips of the lane kernel
-    const bool wave_only = KQ > 32 || g_qp_mode == 1 || (g_qp_mode == 0 && n <= 16384);
-    const int KW = KQ > 32 ? 64 : 32;              // A padding of the wave kernel
+    // default: the row kernel (16 lanes per sample) for k <= 32, one wave per sample above
+    const bool row_mode = KQ <= 32 && (g_qp_mode == 0 || g_qp_mode == 3);
+    const bool wave_only = !row_mode && (KQ > 32 || g_qp_mode == 1 || g_qp_mode == 3);
+    const int KW = KQ > 32 ? 64 : 32;              // A padding of the wave and row kernels
+    // spg.py:310 allocates f_mem of any length; the kernels keep it in registers
+    AA_REQUIRE(p->memory <= (row_mode ? QR_MAXMEM : QP_MAXMEM), AA_ERR_ARG,
+               "QP: memory = %d exceeds the HIP backend limit of %d for k = %d", p->memory,
+               row_mode ? QR_MAXMEM : QP_MAXMEM, k);
     // scratch layout: QpHeader | A[KQ*KQ] | A2[KW*KW] | bscale[64] | ovf_rows[n] | ovf[n]
     const size_t off_A = 192;             // QpHeader at 0, QpDebug at 64 (96 bytes)
     const size_t off_A2 = off_A + (size_t)KQ * KQ * sizeof(double);
@@ -1026,6 +1399,22 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         switch (KQ) { case 4: QPP(4); break; case 8: QPP(8); break; case 16: QPP(16); break;
                       case 32: QPP(32); break; default: QPP(64); break; }
 #undef QPP
+    } else if (row_mode) {
+        // samples ordered by their previous pass count, longest first: the long chains start
+        // at t = 0 (iters_dev still holds the counts of the previous update of this context)
+        const int *perm = nullptr;
+        if (g_qp_sort && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid)
+            AA_CHECK(qp_order_rows(c, iters_dev, n, &perm));
+        long waves = (n + 3) / 4;
+        if (waves > g_qp_row_waves) waves = g_qp_row_waves;
+        if (k <= 16)
+            hipLaunchKernelGGL(k_qp_row<1>, dim3((unsigned)waves), dim3(64), 0, c->stream, A2d, KW, Btall,
+                               stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr, perm,
+                               g_qp_row_hot);
+        else
+            hipLaunchKernelGGL(k_qp_row<2>, dim3((unsigned)waves), dim3(64), 0, c->stream, A2d, KW, Btall,
+                               stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr, perm,
+                               g_qp_row_hot);
     } else if (wave_only) {
         long blocks = (n + 3) / 4;
         if (blocks > 2048) blocks = 2048;
@@ -1049,18 +1438,8 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         // samples ordered by their previous pass count (iters_dev still holds the counts of
         // the previous update of this context; the kernels below overwrite them)
         const int *perm = nullptr;
-        if (g_qp_sort && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid) {
-            AA_CHECK(c->qpPerm.alloc((size_t)n * sizeof(int) + 2 * QP_SORT_BUCKETS * sizeof(int)));
-            int *pm = c->qpPerm.as<int>();
-            int *ghist = pm + n, *gcursor = ghist + QP_SORT_BUCKETS;
-            AA_CHECK_HIP(hipMemsetAsync(ghist, 0, 2 * QP_SORT_BUCKETS * sizeof(int), c->stream));
-            const unsigned nblk = (unsigned)((n + QP_SORT_ROWS_PER_BLOCK - 1) / QP_SORT_ROWS_PER_BLOCK);
-            hipLaunchKernelGGL(k_qp_order_hist, dim3(nblk), dim3(256), 0, c->stream, (const int *)iters_dev, n,
-                               ghist);
-            hipLaunchKernelGGL(k_qp_order_scatter, dim3(nblk), dim3(256), 0, c->stream,
-                               (const int *)iters_dev, n, (const int *)ghist, gcursor, pm);
-            perm = pm;
-        }
+        if (g_qp_sort && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid)
+            AA_CHECK(qp_order_rows(c, iters_dev, n, &perm));
         QpDebug *dbgp = g_qp_profile ? reinterpret_cast<QpDebug *>(base + 64) : (QpDebug *)nullptr;
         if (dbgp) AA_CHECK_HIP(hipMemsetAsync(dbgp, 0, sizeof(QpDebug), c->stream));
 #define QPL3(KQV, FULLV, PROFV)                                                               \

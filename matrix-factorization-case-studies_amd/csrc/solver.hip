@@ -415,8 +415,14 @@ int aa_set_option(const char *name, int value)
         AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_waves must be >= 1");
         g_qp_waves = value;
     } else if (!strcmp(name, "qp_mode")) {
-        AA_REQUIRE(value >= 0 && value <= 2, AA_ERR_ARG, "qp_mode must be 0, 1 or 2");
+        AA_REQUIRE(value >= 0 && value <= 3, AA_ERR_ARG, "qp_mode must be 0, 1, 2 or 3");
         g_qp_mode = value;
+    } else if (!strcmp(name, "qp_row_waves")) {
+        AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_row_waves must be >= 1");
+        g_qp_row_waves = value;
+    } else if (!strcmp(name, "qp_row_hot")) {
+        AA_REQUIRE(value >= 0, AA_ERR_ARG, "qp_row_hot must be >= 0");
+        g_qp_row_hot = value;
     } else {
         set_error("unknown option '%s'", name);
         return AA_ERR_ARG;

@@ -73,9 +73,10 @@ def test_simplex_rows_vs_oracle(cdr, orc, shape):
 
 
 # ---------------------------------------------------------------- per-sample QP
-@pytest.fixture(params=[1, 2], ids=["wave-per-sample", "lane+wave"])
+@pytest.fixture(params=[1, 2, 3], ids=["wave-per-sample", "lane+wave", "row"])
 def qp_kernel(request):
-    """Both mappings of the batched QP (by default the sample count picks one)."""
+    """All three mappings of the batched QP (default: the row kernel for k <= 32, one wave per
+    sample above)."""
     from convex_dim_red import _backend
     _backend.set_option("qp_mode", request.param)
     yield request.param

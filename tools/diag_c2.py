@@ -1,0 +1,46 @@
+# scratch: stage-by-stage comparison against the oracle on the C2 shape (n=1610, p=25000, k=5)
+import sys, os, warnings
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(_R, "matrix-factorization-case-studies_amd")); sys.path.insert(0, _R)
+import numpy as np
+from convex_dim_red import _backend
+from oracle import aa_oracle as orc
+warnings.simplefilter("ignore")
+n, p, k = [int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (1610, 25000, 5))]
+dtype = sys.argv[4] if len(sys.argv) > 4 else "float64"
+rng = np.random.RandomState(0)
+B = rng.standard_normal((k, p)); Zt = orc.right_stochastic_matrix((n, k), rng) ** 4; Zt /= Zt.sum(axis=1, keepdims=True)
+X = Zt.dot(B) + 0.05 * rng.standard_normal((n, p))
+rs = np.random.RandomState(1); C = orc.right_stochastic_matrix((k, n), rs); Z = orc.right_stochastic_matrix((n, k), rs)
+alpha = np.ones(k); trX = (X * X).sum()
+def rel(a, b): return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+with _backend.Context(dtype=dtype) as ctx:
+    ctx.set_data(X.astype(np.float32) if dtype == "float32" else X)
+    ctx.set_state(C, Z, alpha)
+    c0 = ctx.prepare()
+    ZtZ, CKCt, CKZ, tr = ctx.grams(); P = ctx.archetypes()
+    CX = C.dot(X); XXtZ = X.dot(X.T.dot(Z))
+    print("prepare: cost", c0, "oracle", orc.kernel_aa_cost(X.dot(X.T), Z, C, alpha) if n <= 5000 else None)
+    print("  rel err: trace %.2e P %.2e ZtZ %.2e CKCt %.2e CKZ %.2e" % (abs(tr - trX) / trX, rel(P, CX), rel(ZtZ, Z.T.dot(Z)), rel(CKCt, CX.dot(CX.T)), rel(CKZ, C.dot(XXtZ))))
+    for it in range(3):
+        wC, wf, wit, wfe = orc.update_aa_dictionary(X, C, alpha, trX, XXtZ, Z.T.dot(Z), max_iterations=1)
+        st = ctx.dictionary_update(max_iterations=1)
+        gC, gZ, _ = ctx.get_state()
+        print("iter %d dictionary: f %.12e oracle %.12e | n_feval %d/%d | C maxdiff %.2e, cost %.12e" % (it, st.f, wf, st.n_feval, wfe, np.abs(gC - wC).max(), ctx.cost()))
+        C = wC
+        CX = C.dot(X); CXXt = CX.dot(X.T); CXXtCt = CX.dot(CX.T)
+        ZtZ2, CKCt2, CKZ2, _ = ctx.grams()
+        print("   grams after dict: CKCt %.2e CKZ %.2e" % (rel(CKCt2, CXXtCt), rel(CKZ2, C.dot(XXtZ))))
+        wZ, wit = orc.update_kernel_aa_weights(Z, alpha, CXXt, CXXtCt, return_iters=True)
+        qs = ctx.weights_update()
+        gC2, gZ, _ = ctx.get_state()
+        print("iter %d weights: Z maxdiff %.2e | oracle passes mean %.2f max %d | hip total %d max %d | cost %.12e" % (it, np.abs(gZ - wZ).max(), wit.mean(), wit.max(), qs.total_passes, qs.max_passes, ctx.cost()))
+        # same QP through the stateless entry point with the oracle's inputs
+        sZ, sit = _backend.qp_batch(CXXtCt, CXXt, Z, "kn", return_iters=True)
+        print("   stateless qp on oracle inputs: Z maxdiff %.2e, iters equal %s (mean %.2f)" % (np.abs(sZ - wZ).max(), np.array_equal(sit, wit), sit.mean()))
+        f = lambda Zm: (0.5 * np.einsum("ti,ij,tj->t", Zm, CXXtCt, Zm) - np.einsum("ti,it->t", Zm, CXXt)).sum()
+        print("   QP objective sum: hip %.12e stateless %.12e oracle %.12e" % (f(gZ), f(sZ), f(wZ)))
+        Z = wZ
+        XXtZ = X.dot(X.T.dot(Z))
+        oc = 0.5 * (trX - 2 * np.trace(C.dot(XXtZ)) + np.trace(Z.T.dot(Z).dot(CXXtCt))) / n
+        print("   oracle cost %.12e" % oc)
+        ctx.set_state(C, Z, alpha); ctx.prepare()
