@@ -175,6 +175,7 @@ struct Ctx {
     DevBuf proj;                               // ProjState
     DevBuf projList, projSegCnt;               // candidate lists of the column projection
     DevBuf Mdev, alphaDev;                     // KP*KP, KP
+    DevBuf tickets;                            // arrival counters of the last-block-done reductions
     DevBuf qpIters;                            // n ints: pass counts of the latest weights update
     DevBuf qpPerm;                             // n ints: sample order of the lane kernel
     bool qp_iters_valid = false;               // qpIters belongs to the current rows / state
@@ -188,6 +189,7 @@ struct Ctx {
     bool projWarm[4] = {false, false, false, false};   // ProjState::warm[kind] is valid
     bool x_feasible = false;                   // dictionary known to be on the simplex
     bool products_valid = false;               // P (= CX) and Gr (= C XX' or C K) match Ct
+    bool ckz_valid = false;                    // gramState's C K Z matches Ct and H
 };
 
 // ------------------------------------------------------------------ kernels_gemm.hip
@@ -207,10 +209,12 @@ int launch_stream_probe(Ctx *c, int variant);   // measurement: one streaming re
 
 // ------------------------------------------------------------------ kernels_tall.hip
 int tall_setup(Ctx *c);
-int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode);
+int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode,
+                const aa_spg_params *sp = nullptr, int stage_after = -1);
 enum { PROJ_FEAS = 0, PROJ_ALPHA = 1, PROJ_DIR = 2, PROJ_RES = 3 };
 int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, double scale,
-                const double *d_for_dot /*nullable*/, int dot_slot);
+                const double *d_for_dot /*nullable*/, int dot_slot, double *xupd = nullptr,
+                const aa_spg_params *sp = nullptr, int stage_after = -1);
 int launch_tall_axpy_lambda(Ctx *c, double *x, const double *d);             // x += lambda * d
 int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const double *alpha_dev,
                            int slot);   // sum x*H*alpha (alpha_dev nullable => 1)
@@ -225,6 +229,8 @@ int launch_wide_to_T(Ctx *c, const double *src, void *dstT);
 int launch_transpose_wide_to_tall(Ctx *c, const double *wide, double *tall); // [KP][p_pad] -> [n_pad][KP] (kernel form)
 int launch_transpose_tall_to_wide(Ctx *c, const double *tall, double *wide, void *wideT);
 int launch_scalar_stage(Ctx *c, int stage, const aa_spg_params *sp, int it);
+int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, int *cost_slot);
+int launch_dict_setup(Ctx *c, const aa_spg_params *sp, double fnorm);
 enum { ST_INIT_F = 0, ST_ALPHA = 1, ST_LINESEARCH = 2, ST_BB = 3, ST_CONV = 4 };
 int launch_row_sqnorm_sum(Ctx *c, double *trace_out_host);
 int launch_distance_column(Ctx *c, long j_local, int owner_has_row, const double *xj_host, double *d_host);
@@ -250,6 +256,7 @@ int launch_simplex_rows_generic(hipStream_t s, const double *in, double *out, lo
 
 extern int g_use_graph;           // solver.hip
 extern int g_proj_mode;           // kernels_tall.hip
+extern int g_fuse_finalize;       // kernels_tall.hip
 extern int g_proj_list_cap;       // kernels_tall.hip
 extern int g_row_local_variant;   // kernels_gemm.hip
 extern int g_row_local_waves;     // kernels_gemm.hip

@@ -942,12 +942,14 @@ __device__ __forceinline__ bool qr_any(bool p, int rowshift)
 // rule and the same closed form as qp_project_threshold / qw_threshold; `mask` holds the
 // support bits of this lane's own components.  Rows leave the loop independently.
 template <int CPL>
-__device__ __forceinline__ double qr_threshold(const double (&w)[CPL], unsigned &mask, int rowshift)
+__device__ __forceinline__ double qr_threshold(const double (&w)[CPL], unsigned &mask, int rowshift,
+                                               unsigned int &rounds)
 {
     unsigned m = mask;
     int c = qr_sum_i(__popc(m));
     double s = 0.0;
     for (int pass = 0; pass < 32 * CPL + 8; ++pass) {
+        rounds += 1u;
         if (c == 0) {                              // cold start, or the warm guess emptied
             double mx = w[0];
 #pragma unroll
@@ -979,6 +981,7 @@ __device__ __forceinline__ double qr_threshold(const double (&w)[CPL], unsigned 
 }
 
 #define QR_MAXMEM 16
+#define QR_CHUNK 4        // queue tickets a wave takes per atomic (one per row)
 template <int CPL>
 __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[lda][lda], zero padded*/,
                                                int lda, const double *__restrict__ B, long stride_j,
@@ -986,7 +989,7 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
                                                double *__restrict__ Z, int ldz, long n, int k,
                                                aa_qp_params p, int *__restrict__ iters,
                                                QpHeader *__restrict__ hdr,
-                                               const int *__restrict__ perm, int hot_passes)
+                                               const int *__restrict__ perm, int hot_passes, int prof)
 {
     constexpr int KQ = 16 * CPL;
     __shared__ __attribute__((aligned(16))) double vb[4][KQ];
@@ -1014,41 +1017,48 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
     double fm = NAN;                               // lane r: f_mem[r]
     int n_iter = 0, n_feval = 0, predicted = 0;
     long row = -1;
-    bool active = false, exhausted = false;
+    bool active = false;
     unsigned sup = 0u, sup_r = 0u;                 // supports of the latest direction / residual projection
     int prio = 0;
+    unsigned int dbg_rounds = 0u, dbg_trips = 0u;  // qp_profile: Michelot rounds / trips of this lane
+
+    // Work distribution.  The queue is the sample list in longest-first order; a wave takes
+    // QR_CHUNK tickets per atomic and always has the NEXT chunk's atomic in flight, and every
+    // row holds, next to the sample it works on, the one it will work on next with its z0 and
+    // b already loaded -- so neither the atomic's round trip nor the two global loads of a
+    // start-up sit on the critical path of the three other rows of the wave.
+    long nxt = -1;                                 // this row's next sample (prefetched), -1: none
+    double zn[CPL], bn[CPL];
+    int npred = 0;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) zn[q] = bn[q] = 0.0;
+    long q_base = 0;                               // wave-uniform: local chunk [q_base, q_base + q_left)
+    int q_left = 0;
+    unsigned int q_ahead = 0u;                     // ticket of the chunk whose atomic is in flight
+    bool have_ahead = false, drained = false;      // wave-uniform
 
     for (long trip = 0; trip < (1L << 26); ++trip) {       // watchdog bound only
-        // ---- idle rows pull the next samples of the queue (one atomic per wave)
+        // a wave that carries a long-running sample stops pulling work (its remaining rows idle
+        // once their local entries are used up) and takes issue priority: the longest chains of
+        // the update then advance at one pass per ~1500 cycles while short samples fill the
+        // rest of the machine
+        const bool hot_wave = __any(active && (n_iter >= hot_passes || predicted >= 2 * hot_passes));
+        if ((hot_wave ? 1 : 0) != prio) {
+            if (hot_wave) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
+            prio = hot_wave ? 1 : 0;
+        }
+        // ---- rows without a sample take their prefetched one
         bool starting = false;
-        const bool want = !active && !exhausted;
-        const unsigned long long wb = __ballot(want && r == 0);
-        if (wb != 0ull) {
-            unsigned int base = 0u;
-            if (lane == 0) base = atomicAdd(&hdr->next_row, (unsigned int)__popcll(wb));
-            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-            if (want) {
-                const long idx = (long)base + __popcll(wb & ((1ull << rowshift) - 1ull));
-                if (idx < n) {
-                    row = perm ? (long)perm[idx] : idx;
-                    starting = true;
-                } else {
-                    exhausted = true;
-                }
-            }
+        if (!active && nxt >= 0) {                 // zn / bn stay valid until the pop at the end of the trip
+            starting = true;
+            row = nxt;
+            predicted = npred;
+            nxt = -1;
         }
-        if (!__any(active || starting)) break;
-        // waves that carry a long-running sample take issue priority: the longest chain of
-        // the update then runs at its own latency while short samples fill the gaps
-        {
-            const bool hot = active && (n_iter >= hot_passes || predicted >= 2 * hot_passes);
-            const int want_prio = __any(hot) ? 1 : 0;
-            if (want_prio != prio) {
-                if (want_prio) __builtin_amdgcn_s_setprio(3);
-                else __builtin_amdgcn_s_setprio(0);
-                prio = want_prio;
-            }
-        }
+        const bool busy = __any(active || starting);
+        if (busy) {
+        dbg_trips += 1u;
 
         if (starting) {
             // ---- start-up: x = P(z0)                                   (spg.py:298-300)
@@ -1056,11 +1066,10 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
             unsigned m0 = 0u;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
-                const double z = live[q] ? Z[row * ldz + comp0 + q] : 0.0;
-                w0[q] = live[q] ? z : -QP_PAD;
-                if (live[q] && z > 0.0) m0 |= 1u << q;     // z0 is (nearly) feasible: warm support
+                w0[q] = live[q] ? zn[q] : -QP_PAD;
+                if (live[q] && zn[q] > 0.0) m0 |= 1u << q;     // z0 is (nearly) feasible: warm support
             }
-            const double t0 = qr_threshold<CPL>(w0, m0, rowshift);
+            const double t0 = qr_threshold<CPL>(w0, m0, rowshift, dbg_rounds);
             sup = m0;
             sup_r = m0;
 #pragma unroll
@@ -1068,7 +1077,6 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
                 x[q] = live[q] ? fmax(w0[q] - t0, 0.0) : 0.0;
                 v[q] = x[q];
             }
-            predicted = (perm && iters) ? iters[row] : 0;  // pass count of the previous update
         } else if (active) {
             // ---- one pass of the loop at spg.py:318-396, up to the search direction
             if (n_iter == 0) {
@@ -1078,7 +1086,7 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
                     double w1[CPL];
 #pragma unroll
                     for (int q = 0; q < CPL; ++q) w1[q] = x[q] - g[q];
-                    const double t1 = qr_threshold<CPL>(w1, sup_r, rowshift);
+                    const double t1 = qr_threshold<CPL>(w1, sup_r, rowshift, dbg_rounds);
                     double am = 0.0;
 #pragma unroll
                     for (int q = 0; q < CPL; ++q) am = fmax(am, fabs(fmax(w1[q] - t1, 0.0) - x[q]));
@@ -1090,7 +1098,7 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
             double w[CPL];
 #pragma unroll
             for (int q = 0; q < CPL; ++q) w[q] = x[q] - alpha * g[q];
-            const double td = qr_threshold<CPL>(w, sup, rowshift);
+            const double td = qr_threshold<CPL>(w, sup, rowshift, dbg_rounds);
             double pg = 0.0, pd = 0.0;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
@@ -1109,15 +1117,15 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
         // ---- A v for the four rows of the wave: v through LDS, rows of A from registers
         double Av[CPL];
         {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int q = 0; q < CPL; ++q) vb[rowid][comp0 + q] = v[q];
             // one wave per block: LDS executes a wave's operations in order; the fences only
             // keep the compiler from moving the reads above the writes of the other lanes
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             double acc[CPL][4];
 #pragma unroll
             for (int q = 0; q < CPL; ++q)
@@ -1138,10 +1146,9 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
             double pxg = 0.0, pxb = 0.0;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
-                const double bi = live[q] ? -B[(comp0 + q) * stride_j + row * stride_t] * bs[q] : QP_PAD;
-                g[q] = Av[q] + bi;
+                g[q] = Av[q] + bn[q];
                 pxg = fma(x[q], g[q], pxg);
-                pxb = fma(x[q], bi, pxb);
+                pxb = fma(x[q], bn[q], pxb);
             }
             f = 0.5 * (qr_sum(pxg) + qr_sum(pxb));
             n_feval = 1;
@@ -1186,7 +1193,7 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
             double wr[CPL];
 #pragma unroll
             for (int q = 0; q < CPL; ++q) wr[q] = x[q] - g[q];
-            const double tr = qr_threshold<CPL>(wr, sup_r, rowshift);
+            const double tr = qr_threshold<CPL>(wr, sup_r, rowshift, dbg_rounds);
             double pr2 = 0.0;
             bool big = false;
 #pragma unroll
@@ -1211,6 +1218,55 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
                 active = false;
             }
         }
+        }   // busy
+        // ---- rows without a prefetched sample pop the local chunk
+        {
+            const bool need = nxt < 0 && !drained;
+            const unsigned long long nbm = __ballot(need && r == 0);
+            if (nbm != 0ull) {
+                if (q_left == 0) {
+                    if (have_ahead) {                       // the chunk requested a while ago
+                        const long t0 = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)q_ahead);
+                        have_ahead = false;
+                        q_base = t0;
+                        q_left = t0 >= n ? 0 : (n - t0 < QR_CHUNK ? (int)(n - t0) : QR_CHUNK);
+                        if (q_left == 0) drained = true;
+                    }
+                    if (q_left == 0 && !drained && !hot_wave) {   // first trip (or after a hot phase)
+                        unsigned int t1 = 0u;
+                        if (lane == 0) t1 = atomicAdd(&hdr->next_row, (unsigned int)QR_CHUNK);
+                        const long t0 = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)t1);
+                        q_base = t0;
+                        q_left = t0 >= n ? 0 : (n - t0 < QR_CHUNK ? (int)(n - t0) : QR_CHUNK);
+                        if (q_left == 0) drained = true;
+                    }
+                    if (q_left > 0 && !hot_wave) {          // request the chunk after this one
+                        if (lane == 0) q_ahead = atomicAdd(&hdr->next_row, (unsigned int)QR_CHUNK);
+                        have_ahead = true;
+                    }
+                }
+                const int rank = __popcll(nbm & ((1ull << rowshift) - 1ull));
+                if (need && rank < q_left) {
+                    const long idx = q_base + rank;
+                    nxt = perm ? (long)perm[idx] : idx;
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) {
+                        zn[q] = live[q] ? Z[nxt * ldz + comp0 + q] : 0.0;
+                        bn[q] = live[q] ? -B[(comp0 + q) * stride_j + nxt * stride_t] * bs[q] : QP_PAD;
+                    }
+                    npred = (perm && iters) ? iters[nxt] : 0;      // pass count of the previous update
+                }
+                const int served = __popcll(nbm) < q_left ? __popcll(nbm) : q_left;
+                q_base += served;
+                q_left -= served;
+            }
+        }
+        if (!__any(active || nxt >= 0) && (drained || (q_left == 0 && !have_ahead && hot_wave))) break;
+    }
+    if (prof && r == 0) {                          // per row: Michelot rounds, trips of its wave
+        atomicAdd(&hdr->n_overflow, dbg_rounds);
+        if (lane == 0) atomicAdd(&hdr->next_overflow, dbg_trips);
+        if (lane == 0) atomicAdd(&hdr->pad, 1u);
     }
 }
 
@@ -1410,11 +1466,11 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         if (k <= 16)
             hipLaunchKernelGGL(k_qp_row<1>, dim3((unsigned)waves), dim3(64), 0, c->stream, A2d, KW, Btall,
                                stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr, perm,
-                               g_qp_row_hot);
+                               g_qp_row_hot, g_qp_profile);
         else
             hipLaunchKernelGGL(k_qp_row<2>, dim3((unsigned)waves), dim3(64), 0, c->stream, A2d, KW, Btall,
                                stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr, perm,
-                               g_qp_row_hot);
+                               g_qp_row_hot, g_qp_profile);
     } else if (wave_only) {
         long blocks = (n + 3) / 4;
         if (blocks > 2048) blocks = 2048;
@@ -1488,7 +1544,11 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         stats->total_passes = (long)h.total_passes;
         stats->max_passes = (int)h.max_passes;
         stats->reserved = (int)h.n_overflow;
-        if (g_qp_profile) {
+        if (g_qp_profile && row_mode && h.pad)
+            fprintf(stderr, "[qp_profile] row kernel: %u waves, %.1f trips per wave, %.2f Michelot rounds per "
+                    "row and trip, %.2f passes per sample\n", h.pad, (double)h.next_overflow / h.pad,
+                    (double)h.n_overflow / (4.0 * h.next_overflow), (double)h.total_passes / (double)n);
+        if (g_qp_profile && !row_mode) {
             QpDebug d;
             AA_CHECK_HIP(hipMemcpy(&d, base + 64, sizeof(d), hipMemcpyDeviceToHost));
             if (d.waves)

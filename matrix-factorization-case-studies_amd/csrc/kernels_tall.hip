@@ -56,6 +56,41 @@ __device__ __forceinline__ double load_a(double a_const, const double *scal, int
 
 #define PROJ_NT 1024       // threads per block of the first / finish passes of a projection
 
+// "Last block done": true in exactly one block of the grid -- the last one to arrive -- whose
+// threads then see every global write the other blocks made before their call (release fence,
+// atomic ticket, acquire fence).  That block runs the second stage of a two-stage reduction
+// and the scalar step behind it INSIDE the producing kernel, in the same fixed order the
+// separate finalize kernel uses (deterministic), instead of paying a ~5-9 us launch for a few
+// hundred numbers.  The ticket is returned to 0 for the next launch on the stream.
+__device__ __forceinline__ bool last_block_arrives(unsigned int *ticket)
+{
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int total = gridDim.x * gridDim.y;
+        const unsigned int t = atomicAdd(ticket, 1u);
+        s_last = (t == total - 1u) ? 1 : 0;
+        if (s_last) atomicExch(ticket, 0u);
+    }
+    __syncthreads();
+    const bool last = s_last != 0;
+    if (last) __threadfence();
+    return last;
+}
+
+// second stage + scalar step, defined further down; also callable from the last block of a
+// producing kernel (single rank)
+enum { POST_NONE = -1, POST_COLMAX = 0, POST_MICHELOT, POST_FIN, POST_SCALAR_SUM, POST_FIRST };
+#define FIN_NT 1024
+__device__ void post_step(int kind, int mode, const double *__restrict__ red, int KP, int k,
+                          ProjState *__restrict__ ps, double *__restrict__ scal, int slot);
+__device__ __forceinline__ void finalize_sum_block(const double *__restrict__ partial, int nb, int NV,
+                                                   int KP, unsigned max_mask, double *__restrict__ red,
+                                                   double *sm, double *__restrict__ gather, int rank,
+                                                   int world);
+__device__ void scalar_stage_simple(int stage, double *__restrict__ sc, const aa_spg_params &sp);
+
 // ---------------------------------------------------------------- projection passes
 // w[r][i] = x[r][i] - a * g[r][i]   (g == nullptr => w = x)
 // first pass of a projection: column maxima, and w = x - a*g written out once so the
@@ -128,7 +163,12 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_finish(int mode, const double 
                                                      long rows_pb, int k,
                                                      const ProjState *__restrict__ ps,
                                                      double *__restrict__ out,
-                                                     double *__restrict__ partial)
+                                                     double *__restrict__ partial,
+                                                     unsigned int *__restrict__ ticket,
+                                                     double *__restrict__ red,
+                                                     ProjState *__restrict__ psw,
+                                                     double *__restrict__ scalw, int stage_after,
+                                                     aa_spg_params sp)
 {
     __shared__ double sm[4 * PROJ_NT];
     constexpr int RS = PROJ_NT / KP;
@@ -167,6 +207,16 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_finish(int mode, const double 
         }
     }
     block_col_combine<KP, 4, PROJ_NT>(v, 8u, sm, partial + (size_t)blockIdx.x * 4 * KP);
+    // single rank: the last block sums the per-block partials, derives the SPG scalars of this
+    // projection (POST_FIN) and runs the scalar stage that follows it (spg.py:186-189 / :246-276)
+    if (ticket && last_block_arrives(ticket)) {
+        finalize_sum_block(partial, (int)gridDim.x, 4, KP, 8u, red, sm, nullptr, 0, 1);
+        post_step(POST_FIN, mode, red, KP, k, psw, scalw, 0);
+        if (stage_after >= 0) {
+            __syncthreads();
+            if (threadIdx.x == 0) scalar_stage_simple(stage_after, scalw, sp);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- candidate-list projection
@@ -187,9 +237,13 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_first(const double *__restrict
                                                     long n, long rows_pb, int k, int warm_slot,
                                                     const ProjState *__restrict__ ps,
                                                     double *__restrict__ wout,
-                                                    double *__restrict__ partial)
+                                                    double *__restrict__ partial,
+                                                    unsigned int *__restrict__ ticket,
+                                                    double *__restrict__ red,
+                                                    ProjState *__restrict__ psw,
+                                                    double *__restrict__ scalw)
 {
-    __shared__ double sm[3 * PROJ_NT];
+    __shared__ double sm[4 * PROJ_NT];
     constexpr int RS = PROJ_NT / KP;
     const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
     const double a = load_a(a_const, scal, a_slot);
@@ -211,6 +265,10 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_first(const double *__restrict
         }
     }
     block_col_combine<KP, 3, PROJ_NT>(v, 1u, sm, partial + (size_t)blockIdx.x * 3 * KP);
+    if (ticket && last_block_arrives(ticket)) {          // single rank: lower bounds of t* in place
+        finalize_sum_block(partial, (int)gridDim.x, 3, KP, 1u, red, sm, nullptr, 0, 1);
+        post_step(POST_FIRST, 0, red, KP, k, psw, scalw, 0);
+    }
 }
 
 // candidates {w > t_lower}: thread (rsub, comp) of block b appends its own rows, in row
@@ -489,8 +547,6 @@ __global__ void k_proj_fallback_init(ProjState *__restrict__ ps, int k)
 // ---------------------------------------------------------------- finalize
 // partial [nb][NV][KP] -> red [NV][KP] (fixed order), then (single rank) the post step
 // in the same launch.  One block of 256 threads.
-enum { POST_NONE = -1, POST_COLMAX = 0, POST_MICHELOT, POST_FIN, POST_SCALAR_SUM, POST_FIRST };
-
 __device__ void post_step(int kind, int mode, const double *__restrict__ red, int KP, int k,
                           ProjState *__restrict__ ps, double *__restrict__ scal, int slot)
 {
@@ -595,19 +651,13 @@ __device__ void post_step(int kind, int mode, const double *__restrict__ red, in
     }
 }
 
-#define FIN_NT 1024
-__global__ __launch_bounds__(FIN_NT) void k_finalize_sum(const double *__restrict__ partial, int nb,
-                                                         int NV, int KP, unsigned max_mask,
-                                                         double *__restrict__ red,
-                                                         const ProjState *__restrict__ ps_gate,
-                                                         int kind, int mode, int k,
-                                                         ProjState *__restrict__ ps,
-                                                         double *__restrict__ scal, int slot,
-                                                         double *__restrict__ gather, int rank,
-                                                         int world)
+// partial [nb][NV][KP] -> red [NV][KP], fixed order; all FIN_NT threads of one block; sm holds
+// 4 * FIN_NT doubles.  `gather`: multi-rank slot buffer (see k_finalize_sum).
+__device__ __forceinline__ void finalize_sum_block(const double *__restrict__ partial, int nb, int NV,
+                                                   int KP, unsigned max_mask, double *__restrict__ red,
+                                                   double *sm, double *__restrict__ gather, int rank,
+                                                   int world)
 {
-    if (ps_gate && ps_gate->done) return;
-    __shared__ double sm[4 * FIN_NT];
     const int RS = FIN_NT / KP;                 // 32 or 16 partial groups, all NV values at once
     const int t = threadIdx.x, comp = t % KP, part = t / KP;
     double acc[4];
@@ -651,6 +701,21 @@ __global__ __launch_bounds__(FIN_NT) void k_finalize_sum(const double *__restric
             for (int r = 0; r < world; ++r) gather[((size_t)r * NV + a) * KP + comp] = r == rank ? s : 0.0;
     }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(FIN_NT) void k_finalize_sum(const double *__restrict__ partial, int nb,
+                                                         int NV, int KP, unsigned max_mask,
+                                                         double *__restrict__ red,
+                                                         const ProjState *__restrict__ ps_gate,
+                                                         int kind, int mode, int k,
+                                                         ProjState *__restrict__ ps,
+                                                         double *__restrict__ scal, int slot,
+                                                         double *__restrict__ gather, int rank,
+                                                         int world)
+{
+    if (ps_gate && ps_gate->done) return;
+    __shared__ double sm[4 * FIN_NT];
+    finalize_sum_block(partial, nb, NV, KP, max_mask, red, sm, gather, rank, world);
     if (kind != POST_NONE) post_step(kind, mode, red, KP, k, ps, scal, slot);
 }
 
@@ -697,7 +762,11 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
                                               long n, long rows_pb, int k,
                                               double *__restrict__ gout,
                                               const double *__restrict__ d,
-                                              double *__restrict__ partial)
+                                              double *__restrict__ partial,
+                                              double *__restrict__ xupd,
+                                              unsigned int *__restrict__ ticket,
+                                              double *__restrict__ scalw, int dot_slot,
+                                              int stage_after, aa_spg_params sp)
 {
     constexpr int T = KP / 16;       // component tiles
     constexpr int S = KP / 4;        // contraction steps
@@ -715,6 +784,9 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
     const long rb = (long)blockIdx.x * rows_pb;      // rows_pb is a multiple of 64
     long re = rb + rows_pb;
     double dot = 0.0;
+    // xupd: x <- x + lambda d for the rows of this block (the accepted SPG step, spg.py:208-222;
+    // d is read for <d, g_new> anyway)
+    const double lam = xupd ? scalw[SC_LAMBDA] : 0.0;
     for (long r0 = rb + 16 * wave; r0 < re; r0 += 64) {
         if (r0 >= n) break;                           // wave-uniform
         f64x4 acc[T];
@@ -738,7 +810,11 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
                     const long e = r * KP + comp;
                     const double ge = (acc[ti][reg] - H[e] * al[ti]) * scale;
                     gout[e] = ge;
-                    if (d) dot += d[e] * ge;
+                    if (d) {
+                        const double de = d[e];
+                        dot += de * ge;
+                        if (xupd) xupd[e] = xupd[e] + lam * de;
+                    }
                 }
             }
     }
@@ -752,6 +828,22 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
             __syncthreads();
         }
         if (threadIdx.x < KP) partial[(size_t)blockIdx.x * KP + threadIdx.x] = threadIdx.x == 0 ? sm[0] : 0.0;
+        // single rank: the last block adds the per-block dots in block order (the order the
+        // finalize kernel uses) and runs the BB stage behind them (spg.py:232-244)
+        if (ticket && last_block_arrives(ticket)) {
+            double s = 0.0;
+            for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) s += partial[(size_t)b * KP];
+            sm[threadIdx.x] = s;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                scalw[dot_slot] = sm[0];
+                if (stage_after >= 0) scalar_stage_simple(stage_after, scalw, sp);
+            }
+        }
     }
 }
 
@@ -990,6 +1082,46 @@ __device__ double block_trace_MG(const double *__restrict__ M, const double *__r
     return r;
 }
 
+// spg.py:196-229 on one thread: f along x + lambda d in closed form,
+//   f(x + lam d) = 0.5 (tr - 2 (s1 + lam s1d) + a0 + lam a1 + lam^2 a2) / fnorm,
+// with a1 = tr(M (PQ' + QP')), a2 = tr(M QQ'): the Armijo loop with safeguarded quadratic
+// interpolation needs no further pass over the data.
+__device__ void linesearch_thread0(double *__restrict__ sc, const aa_spg_params &sp, double tr1, double tr2)
+{
+    const double a1 = tr1, a2 = tr2;
+    const double tr = sc[SC_TRACE], s1 = sc[SC_S1], s1d = sc[SC_S1D], a0 = sc[SC_A0];
+    const double fn = sc[SC_FNORM], f_old = sc[SC_F_OLD], delta = sc[SC_DELTA];
+    int mem = sp.memory < 1 ? 1 : (sp.memory > 16 ? 16 : sp.memory);
+    for (int i = mem - 1; i > 0; --i) sc[SC_FMEM0 + i] = sc[SC_FMEM0 + i - 1];
+    sc[SC_FMEM0] = f_old;
+    double f_max = sc[SC_FMEM0];
+    for (int i = 1; i < mem; ++i) f_max = (sc[SC_FMEM0 + i] >= f_max) ? sc[SC_FMEM0 + i] : f_max;
+    double lam = 1.0;
+    double nfe = sc[SC_NFEVAL];
+    int flags = (int)sc[SC_FLAGS];
+    double f_new = 0.5 * (tr - 2.0 * (s1 + lam * s1d) + a0 + lam * a1 + lam * lam * a2) / fn;
+    nfe += 1.0;
+    int guard = 0;
+    while (f_new > f_max + sp.gamma * lam * delta && guard < 200) {
+        lam = dev_line_search_step(lam, delta, f_old, f_new, sp.sigma_one, sp.sigma_two);
+        f_new = 0.5 * (tr - 2.0 * (s1 + lam * s1d) + a0 + lam * a1 + lam * lam * a2) / fn;
+        nfe += 1.0;
+        ++guard;
+        if (fabs(lam) < sp.lambda_min) {
+            flags |= AA_SPG_FLAG_LAMBDA_MIN;
+            break;
+        }
+    }
+    sc[SC_LAMBDA] = lam;
+    sc[SC_F_NEW] = f_new;
+    sc[SC_S1] = s1 + lam * s1d;
+    sc[SC_A0] = a0 + lam * a1 + lam * lam * a2;
+    sc[SC_A1] = a1;
+    sc[SC_A2] = a2;
+    sc[SC_NFEVAL] = nfe;
+    sc[SC_FLAGS] = (double)flags;
+}
+
 // gram: [0] = C K C' (or (CX)(CX)'), [1] = cross1, [2] = D K D', [3] = cross2
 __global__ __launch_bounds__(256) void k_scalar_stage(int stage, double *__restrict__ sc,
                                                       const double *__restrict__ gram,
@@ -1017,45 +1149,23 @@ __global__ __launch_bounds__(256) void k_scalar_stage(int stage, double *__restr
         for (int i = 0; i < 16; ++i) sc[SC_FMEM0 + i] = 0.0;   // f_mem = zeros (spg.py:153)
         sc[SC_ALPHA_SET] = (sp.alpha0 >= 0.0) ? 1.0 : 0.0;
         sc[SC_ALPHA] = sp.alpha0;
-    } else if (stage == ST_ALPHA) {      // spg.py:178-189
+    } else if (stage == ST_ALPHA || stage == ST_BB || stage == ST_CONV) {
+        scalar_stage_simple(stage, sc, sp);
+    } else if (stage == ST_LINESEARCH) {
+        linesearch_thread0(sc, sp, tr1, tr2);
+    }
+}
+
+// the scalar stages that need no Gram trace, one thread (also called from the last block of
+// the kernel that produces their inputs)
+__device__ void scalar_stage_simple(int stage, double *__restrict__ sc, const aa_spg_params &sp)
+{
+    if (stage == ST_ALPHA) {             // spg.py:178-189
         if (sc[SC_ALPHA_SET] == 0.0) {
             const double ainv = sc[SC_AINV];
             sc[SC_ALPHA] = (fabs(ainv) > 1e-12) ? 1.0 / ainv : 1.0;
             sc[SC_ALPHA_SET] = 1.0;
         }
-    } else if (stage == ST_LINESEARCH) { // spg.py:196-229, f along x + lambda d in closed form
-        const double a1 = tr1, a2 = tr2;
-        const double tr = sc[SC_TRACE], s1 = sc[SC_S1], s1d = sc[SC_S1D], a0 = sc[SC_A0];
-        const double fn = sc[SC_FNORM], f_old = sc[SC_F_OLD], delta = sc[SC_DELTA];
-        int mem = sp.memory < 1 ? 1 : (sp.memory > 16 ? 16 : sp.memory);
-        for (int i = mem - 1; i > 0; --i) sc[SC_FMEM0 + i] = sc[SC_FMEM0 + i - 1];
-        sc[SC_FMEM0] = f_old;
-        double f_max = sc[SC_FMEM0];
-        for (int i = 1; i < mem; ++i) f_max = (sc[SC_FMEM0 + i] >= f_max) ? sc[SC_FMEM0 + i] : f_max;
-        double lam = 1.0;
-        double nfe = sc[SC_NFEVAL];
-        int flags = (int)sc[SC_FLAGS];
-        double f_new = 0.5 * (tr - 2.0 * (s1 + lam * s1d) + a0 + lam * a1 + lam * lam * a2) / fn;
-        nfe += 1.0;
-        int guard = 0;
-        while (f_new > f_max + sp.gamma * lam * delta && guard < 200) {
-            lam = dev_line_search_step(lam, delta, f_old, f_new, sp.sigma_one, sp.sigma_two);
-            f_new = 0.5 * (tr - 2.0 * (s1 + lam * s1d) + a0 + lam * a1 + lam * lam * a2) / fn;
-            nfe += 1.0;
-            ++guard;
-            if (fabs(lam) < sp.lambda_min) {
-                flags |= AA_SPG_FLAG_LAMBDA_MIN;
-                break;
-            }
-        }
-        sc[SC_LAMBDA] = lam;
-        sc[SC_F_NEW] = f_new;
-        sc[SC_S1] = s1 + lam * s1d;
-        sc[SC_A0] = a0 + lam * a1 + lam * lam * a2;
-        sc[SC_A1] = a1;
-        sc[SC_A2] = a2;
-        sc[SC_NFEVAL] = nfe;
-        sc[SC_FLAGS] = (double)flags;
     } else if (stage == ST_BB) {         // spg.py:232-244
         const double lam = sc[SC_LAMBDA];
         const double sksk = lam * lam * sc[SC_DD];
@@ -1075,6 +1185,137 @@ __global__ __launch_bounds__(256) void k_scalar_stage(int stage, double *__restr
         if (conv) flags |= AA_SPG_FLAG_CONVERGED;
         else if (sc[SC_NFEVAL] > (double)sp.max_feval) flags |= AA_SPG_FLAG_MAX_FEVAL;
         sc[SC_FLAGS] = (double)flags;
+    }
+}
+
+// ---------------------------------------------------------------- fused small stages
+// (P Q') and (Q Q') of the line search in ONE pass over the two wide arrays, and -- in the
+// last block to finish -- everything that used to be five more launches: the fixed-order sum
+// of the per-block partials, the line search itself (linesearch_thread0), the Gram of the
+// accepted point
+//     (P + lam Q)(P + lam Q)' = PP' + lam (PQ' + QP') + lam^2 QQ'
+// written to the Gram state (archetypal_analysis.py:620: no further pass over P), and the
+// cost after the dictionary update from the line search's own scalars
+//     0.5 (tr - 2 tr(C H D) + tr(M CXX'C')) / n        (archetypal_analysis.py:623-627).
+// gram: [0] = P P' (in), [1] = P Q', [2] = Q Q' (out).
+template <int KP>
+__global__ __launch_bounds__(256) void k_gram_wide_pq(const double *__restrict__ P,
+                                                      const double *__restrict__ Q, int ld,
+                                                      double *__restrict__ partial,
+                                                      unsigned int *__restrict__ ticket,
+                                                      double *__restrict__ gram,
+                                                      const double *__restrict__ M,
+                                                      double *__restrict__ sc, aa_spg_params sp, int k,
+                                                      double *__restrict__ ckct_state,
+                                                      double n_global, double *__restrict__ cost_out,
+                                                      int *__restrict__ cost_slot)
+{
+    constexpr int JT = KP * KP / 256;
+    constexpr int TPI = KP / JT;
+    constexpr int CW = 32;
+    constexpr int GS = KP * KP;
+    __shared__ double As[KP][CW + 1], Bs[KP][CW + 1];
+    __shared__ double smt[256];
+    const int t = threadIdx.x, i = t / TPI, j0 = (t % TPI) * JT;
+    const int c0 = blockIdx.x * 128;
+    double acc1[JT], acc2[JT];
+#pragma unroll
+    for (int q = 0; q < JT; ++q) acc1[q] = acc2[q] = 0.0;
+    for (int cc = 0; cc < 128; cc += CW) {
+        for (int e = t; e < KP * CW; e += 256) {
+            As[e / CW][e % CW] = P[(long)(e / CW) * ld + c0 + cc + e % CW];
+            Bs[e / CW][e % CW] = Q[(long)(e / CW) * ld + c0 + cc + e % CW];
+        }
+        __syncthreads();
+        for (int c = 0; c < CW; ++c) {
+            const double a = As[i][c], b = Bs[i][c];
+#pragma unroll
+            for (int q = 0; q < JT; ++q) {
+                const double bq = Bs[j0 + q][c];
+                acc1[q] = fma(a, bq, acc1[q]);
+                acc2[q] = fma(b, bq, acc2[q]);
+            }
+        }
+        __syncthreads();
+    }
+    double *dst = partial + (size_t)blockIdx.x * 2 * GS;
+#pragma unroll
+    for (int q = 0; q < JT; ++q) {
+        dst[i * KP + j0 + q] = acc1[q];
+        dst[GS + i * KP + j0 + q] = acc2[q];
+    }
+    if (!last_block_arrives(ticket)) return;
+    // ---- last block: partials -> gram[1], gram[2] (the order of k_gram_finalize)
+    const int nb = (int)gridDim.x;
+    for (int e = t; e < 2 * GS; e += 256) {
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        int b = 0;
+        for (; b + 3 < nb; b += 4) {
+            const double v0 = partial[(size_t)b * 2 * GS + e], v1 = partial[(size_t)(b + 1) * 2 * GS + e];
+            const double v2 = partial[(size_t)(b + 2) * 2 * GS + e], v3 = partial[(size_t)(b + 3) * 2 * GS + e];
+            s4[0] += v0; s4[1] += v1; s4[2] += v2; s4[3] += v3;
+        }
+        for (; b < nb; ++b) s4[b & 3] += partial[(size_t)b * 2 * GS + e];
+        gram[GS + e] = ((s4[0] + s4[1]) + s4[2]) + s4[3];
+    }
+    __syncthreads();
+    const double tr1 = block_trace_MG(M, gram + GS, k, KP, false, smt) +
+                       block_trace_MG(M, gram + GS, k, KP, true, smt);
+    const double tr2 = block_trace_MG(M, gram + 2 * GS, k, KP, false, smt);
+    if (t == 0) {
+        linesearch_thread0(sc, sp, tr1, tr2);
+        if (cost_out) {
+            const int idx = cost_slot ? (*cost_slot)++ : 0;
+            cost_out[idx] = 0.5 * (sc[SC_TRACE] - 2.0 * sc[SC_S1] + sc[SC_A0]) / n_global;
+        }
+    }
+    __syncthreads();
+    const double lam = sc[SC_LAMBDA];
+    for (int e = t; e < GS; e += 256) {
+        const int r = e / KP, q = e % KP;
+        const double v = gram[e] + lam * (gram[GS + e] + gram[GS + q * KP + r]) + lam * lam * gram[2 * GS + e];
+        gram[e] = v;
+        if (ckct_state) ckct_state[e] = v;
+    }
+}
+
+// Start of a dictionary update whose inputs are already on the device (the state a weights
+// update leaves: Z'Z, C K C', C K Z in the Gram state): M = D Z'Z D
+// (archetypal_analysis.py:310,330), gram[0] = C K C', the scalars, tr(C H D) = sum_i
+// alpha_i (C K Z)_ii, and f(x) (spg.py:153-157) -- one block instead of seven launches.
+__global__ __launch_bounds__(256) void k_dict_setup(const double *__restrict__ state /*ZtZ|CKCt|CKZ*/,
+                                                    const double *__restrict__ alpha, int k, int KP,
+                                                    double trace, double fnorm, double *__restrict__ Mout,
+                                                    double *__restrict__ gram, double *__restrict__ sc,
+                                                    aa_spg_params sp)
+{
+    __shared__ double sm[256];
+    const int GS = KP * KP, t = threadIdx.x;
+    const double *ZtZ = state, *CKCt = state + GS, *CKZ = state + 2 * GS;
+    for (int e = t; e < GS; e += 256) {
+        const int i = e / KP, j = e % KP;
+        Mout[e] = (i < k && j < k) ? alpha[i] * ZtZ[e] * alpha[j] : 0.0;
+        gram[e] = CKCt[e];
+    }
+    __syncthreads();
+    const double a0 = block_trace_MG(Mout, gram, k, KP, false, sm);
+    sm[t] = t < k ? alpha[t] * CKZ[t * KP + t] : 0.0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) sm[t] += sm[t + o];
+        __syncthreads();
+    }
+    if (t == 0) {
+        sc[SC_TRACE] = trace;
+        sc[SC_FNORM] = fnorm;
+        sc[SC_S1] = sm[0];
+        sc[SC_A0] = a0;
+        sc[SC_F_OLD] = 0.5 * (trace - 2.0 * sm[0] + a0) / fnorm;
+        sc[SC_NFEVAL] = 1.0;
+        sc[SC_FLAGS] = 0.0;
+        for (int i = 0; i < 16; ++i) sc[SC_FMEM0 + i] = 0.0;   // f_mem = zeros (spg.py:153)
+        sc[SC_ALPHA_SET] = (sp.alpha0 >= 0.0) ? 1.0 : 0.0;
+        sc[SC_ALPHA] = sp.alpha0;
     }
 }
 
@@ -1242,6 +1483,7 @@ int tall_setup(Ctx *c)
     }
     AA_CHECK(c->Mdev.alloc((size_t)c->KP * c->KP * sizeof(double)));
     AA_CHECK(c->alphaDev.alloc((size_t)c->KP * sizeof(double)));
+    AA_CHECK(c->tickets.alloc(64 * sizeof(unsigned int)));
     return AA_OK;
 }
 
@@ -1304,6 +1546,7 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
 static int g_proj_hard_cap = 200;
 
 int g_proj_mode = 0;        // 0: candidate lists, 1: iterative full passes
+int g_fuse_finalize = 1;    // 1: second reduction stages run in the last block of their producer (single rank)
 int g_proj_list_cap = 2048; // multi-rank: most candidates per rank and column in the list all-reduce
                             // (the union must fit the solver's LDS: effective cap = min(this, 2048 / world))
 
@@ -1331,21 +1574,35 @@ static int proj_iterative_passes(Ctx *c, const double *wsrc, int mode, long rpb,
     return AA_OK;
 }
 
-int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode)
+// tickets of the "last block done" reductions, one per producing kernel kind
+enum { TK_PROJ_FIRST = 0, TK_PROJ_FINISH, TK_GRAD, TK_GRAM_PQ, TK_GRAM_FIN, TK_COUNT };
+static inline unsigned int *ticket_of(Ctx *c, int which) { return c->tickets.as<unsigned int>() + which; }
+
+// stage_after >= 0: the scalar stage (ST_ALPHA / ST_CONV) that consumes this projection's
+// reductions runs right behind them -- in the last block of the finish pass on a single rank,
+// as its own launch behind the all-reduce otherwise.
+int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode,
+                const aa_spg_params *sp, int stage_after)
 {
     const long rpb = tall_rows_pb(c);
     double *part = c->redPartial.as<double>();
-    const double *scal = c->scalars.as<double>();
+    double *scal = c->scalars.as<double>();
     ProjState *ps = c->proj.as<ProjState>();
     double *wbuf = g ? c->tmpTall.as<double>() : (double *)nullptr;
     const double *wsrc = g ? (const double *)wbuf : x;
     const bool multi = c->world > 1 || c->force_comm;
+    const bool fused = !multi && g_fuse_finalize;
+    aa_spg_params spv;
+    memset(&spv, 0, sizeof(spv));
+    if (sp) spv = *sp;
+    else stage_after = -1;
     if (g_proj_mode == 0) {
         const int RS = 256 / c->KP;
         const long nseg = (long)c->tallBlocks * RS, segcap = rpb / RS;
-        TALL_DISPATCH_NT(PROJ_NT, k_proj_first, x, g, a_const, scal, a_slot, c->n, rpb, c->k,
-                      c->projWarm[mode] ? mode : 0, (const ProjState *)ps, wbuf, part);
-        AA_CHECK(finalize_and_post(c, 3, 1u, POST_FIRST, 0, 0, false));
+        TALL_DISPATCH_NT(PROJ_NT, k_proj_first, x, g, a_const, (const double *)scal, a_slot, c->n, rpb, c->k,
+                      c->projWarm[mode] ? mode : 0, (const ProjState *)ps, wbuf, part,
+                      fused ? ticket_of(c, TK_PROJ_FIRST) : (unsigned int *)nullptr, red_buf(c), ps, scal);
+        if (!fused) AA_CHECK(finalize_and_post(c, 3, 1u, POST_FIRST, 0, 0, false));
         TALL_DISPATCH(k_proj_collect, wsrc, c->n, rpb, c->k, (const ProjState *)ps,
                       c->projList.as<double>(), c->projSegCnt.as<int>());
         if (!multi) {
@@ -1384,7 +1641,7 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
         }
         AA_CHECK_HIP(hipGetLastError());
     } else {
-        TALL_DISPATCH(k_proj_colmax, x, g, a_const, scal, a_slot, c->n, rpb, c->k, wbuf, part);
+        TALL_DISPATCH(k_proj_colmax, x, g, a_const, (const double *)scal, a_slot, c->n, rpb, c->k, wbuf, part);
         AA_CHECK(finalize_and_post(c, 1, 1u, POST_COLMAX, 0, c->projWarm[mode] ? mode : 0, false));
         AA_CHECK(proj_iterative_passes(c, wsrc, mode, rpb,
                                        c->projPassHint[mode] > 0 ? c->projPassHint[mode] + 1 : 12));
@@ -1392,15 +1649,25 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     double *out = nullptr;
     if (mode == PROJ_FEAS) out = const_cast<double *>(x);
     if (mode == PROJ_DIR) out = c->Dt.as<double>();
-    TALL_DISPATCH_NT(PROJ_NT, k_proj_finish, mode, x, g, a_const, scal, a_slot, c->H.as<double>(),
-                  c->alphaDev.as<double>(), c->n, rpb, c->k, (const ProjState *)ps, out, part);
-    AA_CHECK(finalize_and_post(c, 4, 8u, POST_FIN, mode, 0, false));
+    TALL_DISPATCH_NT(PROJ_NT, k_proj_finish, mode, x, g, a_const, (const double *)scal, a_slot,
+                  (const double *)c->H.as<double>(), (const double *)c->alphaDev.as<double>(), c->n, rpb,
+                  c->k, (const ProjState *)ps, out, part,
+                  fused ? ticket_of(c, TK_PROJ_FINISH) : (unsigned int *)nullptr, red_buf(c), ps, scal,
+                  fused ? stage_after : -1, spv);
+    if (!fused) {
+        AA_CHECK(finalize_and_post(c, 4, 8u, POST_FIN, mode, 0, false));
+        if (stage_after >= 0) AA_CHECK(launch_scalar_stage(c, stage_after, &spv, 0));
+    }
+    AA_CHECK_HIP(hipGetLastError());
     if (mode > 0) c->projWarm[mode] = true;
     return AA_OK;
 }
 
+// xupd (nullable, needs d_for_dot): x += lambda d in the same pass.  stage_after >= 0 (with
+// sp): the scalar stage that consumes <d, g> (ST_BB) runs behind the reduction.
 int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, double scale,
-                const double *d_for_dot, int dot_slot)
+                const double *d_for_dot, int dot_slot, double *xupd, const aa_spg_params *sp,
+                int stage_after)
 {
     // 16 rows per wave and step with nothing in flight across steps: ~4 blocks per CU
     long gb = (c->n + 63) / 64;
@@ -1410,16 +1677,28 @@ int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, doubl
     const int nb = (int)((c->n + rpb - 1) / rpb);
     double *part = c->redPartial.as<double>();
     double *pdot = d_for_dot ? part : (double *)nullptr;
+    const bool multi = c->world > 1 || c->force_comm;
+    const bool fused = d_for_dot && !multi && g_fuse_finalize;
+    aa_spg_params spv;
+    memset(&spv, 0, sizeof(spv));
+    if (sp) spv = *sp;
+    else stage_after = -1;
+    unsigned int *tk = fused ? ticket_of(c, TK_GRAD) : (unsigned int *)nullptr;
     if (c->KP == 32)
         hipLaunchKernelGGL(k_grad<32>, dim3(nb), dim3(256), 0, c->stream, Graw, H,
                            (const double *)c->Mdev.as<double>(), (const double *)c->alphaDev.as<double>(),
-                           scale, c->n, rpb, c->k, gout, d_for_dot, pdot);
+                           scale, c->n, rpb, c->k, gout, d_for_dot, pdot, xupd, tk,
+                           c->scalars.as<double>(), dot_slot, fused ? stage_after : -1, spv);
     else
         hipLaunchKernelGGL(k_grad<64>, dim3(nb), dim3(256), 0, c->stream, Graw, H,
                            (const double *)c->Mdev.as<double>(), (const double *)c->alphaDev.as<double>(),
-                           scale, c->n, rpb, c->k, gout, d_for_dot, pdot);
+                           scale, c->n, rpb, c->k, gout, d_for_dot, pdot, xupd, tk,
+                           c->scalars.as<double>(), dot_slot, fused ? stage_after : -1, spv);
     AA_CHECK_HIP(hipGetLastError());
-    if (d_for_dot) AA_CHECK(finalize_and_post(c, 1, 0u, POST_SCALAR_SUM, 0, dot_slot, false, nb));
+    if (d_for_dot && !fused) {
+        AA_CHECK(finalize_and_post(c, 1, 0u, POST_SCALAR_SUM, 0, dot_slot, false, nb));
+        if (stage_after >= 0) AA_CHECK(launch_scalar_stage(c, stage_after, &spv, 0));
+    }
     return AA_OK;
 }
 
@@ -1549,6 +1828,35 @@ int launch_gram_wide(Ctx *c, const double *A, const double *B, double *out_dev)
                        nb, elems, out_dev);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;   // wide operands are already replicated across ranks
+}
+
+// line search of the data form in one launch (see k_gram_wide_pq); cost_out / cost_slot:
+// optional recording of the cost after the dictionary update
+int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, int *cost_slot)
+{
+    const int nb = (int)(c->p_pad / 128);
+    double *part = c->redPartial.as<double>();
+    double *ckct = c->gramState.as<double>() + (size_t)c->KP * c->KP;
+#define GPQ(KPV)                                                                              \
+    hipLaunchKernelGGL(k_gram_wide_pq<KPV>, dim3(nb), dim3(256), 0, c->stream,                \
+                       (const double *)c->P.as<double>(), (const double *)c->Q.as<double>(),  \
+                       (int)c->p_pad, part, ticket_of(c, TK_GRAM_PQ), c->gramOut.as<double>(), \
+                       (const double *)c->Mdev.as<double>(), c->scalars.as<double>(), *sp, c->k, ckct, \
+                       (double)c->n_global, cost_out, cost_slot)
+    if (c->KP == 32) GPQ(32); else GPQ(64);
+#undef GPQ
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_dict_setup(Ctx *c, const aa_spg_params *sp, double fnorm)
+{
+    hipLaunchKernelGGL(k_dict_setup, dim3(1), dim3(256), 0, c->stream,
+                       (const double *)c->gramState.as<double>(), (const double *)c->alphaDev.as<double>(),
+                       c->k, c->KP, c->trace, fnorm, c->Mdev.as<double>(), c->gramOut.as<double>(),
+                       c->scalars.as<double>(), *sp);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
 }
 
 int launch_wide_axpy_lambda(Ctx *c, double *P, const double *Q, void *PT)

@@ -137,8 +137,20 @@ static inline double *dev_ZtZ(Ctx *c) { return c->gramState.as<double>(); }
 static inline double *dev_CKCt(Ctx *c) { return c->gramState.as<double>() + (size_t)c->KP * c->KP; }
 static inline double *dev_CKZ(Ctx *c) { return c->gramState.as<double>() + (size_t)2 * c->KP * c->KP; }
 
+// C K Z = C' H (k x k) is only needed by the host (scale-factor update, aa_get_grams) and
+// by the Gram form of the cost: after a dictionary update it is recomputed on demand
+static int ensure_ckz(Ctx *c)
+{
+    if (c->ckz_valid) return AA_OK;
+    AA_CHECK(launch_gram_tall(c, c->Ct.as<double>(), c->H.as<double>(), dev_CKZ(c)));
+    c->ckz_valid = true;
+    c->host_grams_valid = false;
+    return AA_OK;
+}
+
 static int sync_host_grams(Ctx *c)
 {
+    AA_CHECK(ensure_ckz(c));
     if (c->host_grams_valid) return AA_OK;
     const size_t GS = (size_t)c->KP * c->KP;
     std::vector<double> tmp(3 * GS);
@@ -159,6 +171,7 @@ static int sync_host_grams(Ctx *c)
 static int device_cost(Ctx *c, double *cost)
 {
     AA_CHECK(c->costDev.alloc(64 * sizeof(double)));
+    AA_CHECK(ensure_ckz(c));
     AA_CHECK(launch_aa_cost(c, c->costDev.as<double>()));
     AA_CHECK_HIP(hipMemcpyAsync(cost, c->costDev.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -174,13 +187,21 @@ static int ensure_trace(Ctx *c)
 }
 
 // ----------------------------------------------------------------- Gram refresh
-static int refresh_after_dictionary(Ctx *c, bool recompute_products)
+static int refresh_after_dictionary(Ctx *c, bool recompute_products, bool ckct_done = false)
 {
     double *gpp = dev_CKCt(c);
     if (c->form == AA_FORM_DATA) {
         if (recompute_products) {
             AA_CHECK(launch_reduce_rows(c, c->Ct.as<double>(), c->P.as<double>(), operandT(c, c->P, c->Pw)));
             AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));
+        }
+        // the fused line search leaves (P + lam Q)(P + lam Q)' in the Gram state and the host
+        // fetches C K Z on demand (ensure_ckz)
+        if (ckct_done) {
+            c->products_valid = true;
+            c->ckz_valid = false;
+            c->host_grams_valid = false;
+            return AA_OK;
         }
         AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), gpp));
     } else {
@@ -192,6 +213,7 @@ static int refresh_after_dictionary(Ctx *c, bool recompute_products)
     }
     c->products_valid = true;
     AA_CHECK(launch_gram_tall(c, c->Ct.as<double>(), c->H.as<double>(), dev_CKZ(c)));
+    c->ckz_valid = true;
     c->host_grams_valid = false;
     return AA_OK;
 }
@@ -218,6 +240,7 @@ static int refresh_after_weights(Ctx *c)
         AA_CHECK(launch_row_local(c, operandT(c, c->ZtX, c->Qw), c->H.as<double>()));
     }
     AA_CHECK(launch_gram_tall(c, c->Ct.as<double>(), c->H.as<double>(), dev_CKZ(c)));
+    c->ckz_valid = true;
     c->host_grams_valid = false;
     c->dict_inputs_overridden = false;
     return AA_OK;
@@ -236,16 +259,21 @@ static int prepare(Ctx *c, double *cost)
 }
 
 // ----------------------------------------------------------------- dictionary SPG
-static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, bool refresh)
+// cost_out / cost_slot (device, nullable): where the cost after the update is recorded.
+// *cost_recorded tells the caller whether that happened inside the update (fused line search,
+// one SPG iteration) or is still to be done with launch_aa_cost.
+static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, bool refresh,
+                             double *cost_out = nullptr, int *cost_slot = nullptr,
+                             bool *cost_recorded = nullptr)
 {
     AA_REQUIRE(c->have_state && (c->grams_valid || c->dict_inputs_overridden), AA_ERR_STATE,
                "dictionary_update needs prepare() or set_dictionary_inputs() first");
     AA_REQUIRE(sp->max_iterations >= 1, AA_ERR_ARG, "spg max_iterations must be >= 1");
+    AA_REQUIRE(sp->memory <= 16, AA_ERR_ARG,
+               "spg memory = %d exceeds the HIP backend limit of 16", sp->memory);
     const int k = c->k, KP = c->KP;
     const bool data = c->form == AA_FORM_DATA;
-    // M = D Z'Z D  (archetypal_analysis.py:310,330), formed on the device
-    AA_CHECK(launch_scale_gram(c, c->Mdev.as<double>(), dev_ZtZ(c)));
-    AA_CHECK(launch_set_scalars(c, c->trace, (double)k));   // archetypal_analysis.py:265,277
+    if (cost_recorded) *cost_recorded = false;
 
     double *x = c->Ct.as<double>();
     double *gram = c->gramOut.as<double>();
@@ -261,22 +289,34 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
     // ingredients of this one (spg.py:156,176) -- the weights update in between does not
     // touch the dictionary -- so two passes over X are saved (`warm`).
     const bool warm = c->x_feasible && c->products_valid;
-    if (!c->x_feasible) AA_CHECK(launch_proj(c, x, nullptr, 0.0, -1, PROJ_FEAS));
-    if (!warm) {
-        if (data) {
-            AA_CHECK(launch_reduce_rows(c, x, c->P.as<double>(), operandT(c, c->P, c->Pw)));
-            AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), gram));
-        } else {
-            AA_CHECK(launch_reduce_rows(c, x, c->wideScratch.as<double>(), nullptr));
-            AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gr.as<double>()));
-            AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), x, gram));
-        }
+    // fused small stages (fewer, fatter launches; aa_set_option("fuse_finalize", 0) restores the
+    // one-kernel-per-step sequence): with everything the update needs already in the Gram
+    // state, one block sets up M, the scalars and f(x)
+    const bool fused = data && g_fuse_finalize;
+    const bool fast = fused && warm && c->grams_valid && c->ckz_valid && !c->dict_inputs_overridden;
+    if (fast) {
+        AA_CHECK(launch_dict_setup(c, sp, (double)k));                          // spg.py:153-157
     } else {
-        AA_CHECK_HIP(hipMemcpyAsync(gram, dev_CKCt(c), GS * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        // M = D Z'Z D  (archetypal_analysis.py:310,330), formed on the device
+        AA_CHECK(launch_scale_gram(c, c->Mdev.as<double>(), dev_ZtZ(c)));
+        AA_CHECK(launch_set_scalars(c, c->trace, (double)k));   // archetypal_analysis.py:265,277
+        if (!c->x_feasible) AA_CHECK(launch_proj(c, x, nullptr, 0.0, -1, PROJ_FEAS));
+        if (!warm) {
+            if (data) {
+                AA_CHECK(launch_reduce_rows(c, x, c->P.as<double>(), operandT(c, c->P, c->Pw)));
+                AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), gram));
+            } else {
+                AA_CHECK(launch_reduce_rows(c, x, c->wideScratch.as<double>(), nullptr));
+                AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gr.as<double>()));
+                AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), x, gram));
+            }
+        } else {
+            AA_CHECK_HIP(hipMemcpyAsync(gram, dev_CKCt(c), GS * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
+        AA_CHECK(launch_tall_dot_scaled(c, x, c->H.as<double>(), c->alphaDev.as<double>(), SC_S1));
+        AA_CHECK(launch_scalar_stage(c, ST_INIT_F, sp, 0));                     // spg.py:156
+        if (data && !warm) AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));
     }
-    AA_CHECK(launch_tall_dot_scaled(c, x, c->H.as<double>(), c->alphaDev.as<double>(), SC_S1));
-    AA_CHECK(launch_scalar_stage(c, ST_INIT_F, sp, 0));                         // spg.py:156
-    if (data && !warm) AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));
     c->products_valid = false;
     AA_CHECK(launch_grad(c, c->Gr.as<double>(), c->H.as<double>(), c->gk.as<double>(), gscale, nullptr, 0));
 
@@ -285,15 +325,22 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
     for (int it = 0; it < sp->max_iterations; ++it) {
         n_iter = it;
         if (it == 0 && sp->alpha0 < 0.0) {                                      // spg.py:178-189
-            AA_CHECK(launch_proj(c, x, c->gk.as<double>(), 1.0, -1, PROJ_ALPHA));
-            AA_CHECK(launch_scalar_stage(c, ST_ALPHA, sp, 0));
+            AA_CHECK(launch_proj(c, x, c->gk.as<double>(), 1.0, -1, PROJ_ALPHA, sp, ST_ALPHA));
         }
         AA_CHECK(launch_proj(c, x, c->gk.as<double>(), 0.0, SC_ALPHA, PROJ_DIR)); // spg.py:191-194,206
         if (data) {
             AA_CHECK(launch_reduce_rows(c, c->Dt.as<double>(), c->Q.as<double>(), nullptr));
-            AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->Q.as<double>(), gram + GS));
-            AA_CHECK(launch_gram_wide(c, c->Q.as<double>(), c->Q.as<double>(), gram + 2 * GS));
-            AA_CHECK(launch_scalar_stage(c, ST_LINESEARCH, sp, 1));
+            if (fused) {
+                // (P Q'), (Q Q'), the line search, the Gram of the accepted point and -- with one
+                // SPG iteration per update -- the cost after the update: one launch
+                const bool rec = cost_out && sp->max_iterations == 1;
+                AA_CHECK(launch_linesearch_fused(c, sp, rec ? cost_out : nullptr, rec ? cost_slot : nullptr));
+                if (rec && cost_recorded) *cost_recorded = true;
+            } else {
+                AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->Q.as<double>(), gram + GS));
+                AA_CHECK(launch_gram_wide(c, c->Q.as<double>(), c->Q.as<double>(), gram + 2 * GS));
+                AA_CHECK(launch_scalar_stage(c, ST_LINESEARCH, sp, 1));
+            }
         } else {
             AA_CHECK(launch_reduce_rows(c, c->Dt.as<double>(), c->wideScratch.as<double>(), nullptr));
             AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gn.as<double>()));
@@ -302,20 +349,20 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
             AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), c->Dt.as<double>(), gram + 3 * GS));
             AA_CHECK(launch_scalar_stage(c, ST_LINESEARCH, sp, 0));
         }
-        AA_CHECK(launch_tall_axpy_lambda(c, x, c->Dt.as<double>()));            // x = x_old + lam d
         if (data) {
+            // x = x_old + lam d happens inside the gradient kernel (it reads d for <d, g_new>),
+            // the BB stage (spg.py:232-244) in the last block of that kernel
             AA_CHECK(launch_wide_axpy_lambda(c, c->P.as<double>(), c->Q.as<double>(), operandT(c, c->P, c->Pw)));
             AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gn.as<double>()));
             AA_CHECK(launch_grad(c, c->Gn.as<double>(), c->H.as<double>(), c->gn.as<double>(), gscale,
-                                 c->Dt.as<double>(), SC_DGN));
+                                 c->Dt.as<double>(), SC_DGN, x, sp, ST_BB));
         } else {
+            AA_CHECK(launch_tall_axpy_lambda(c, x, c->Dt.as<double>()));        // x = x_old + lam d
             AA_CHECK(launch_tall_axpy_lambda(c, c->Gr.as<double>(), c->Gn.as<double>()));
             AA_CHECK(launch_grad(c, c->Gr.as<double>(), c->H.as<double>(), c->gn.as<double>(), gscale,
-                                 c->Dt.as<double>(), SC_DGN));
+                                 c->Dt.as<double>(), SC_DGN, nullptr, sp, ST_BB));
         }
-        AA_CHECK(launch_scalar_stage(c, ST_BB, sp, 0));                         // spg.py:232-244
-        AA_CHECK(launch_proj(c, x, c->gn.as<double>(), 1.0, -1, PROJ_RES));     // spg.py:250
-        AA_CHECK(launch_scalar_stage(c, ST_CONV, sp, 0));
+        AA_CHECK(launch_proj(c, x, c->gn.as<double>(), 1.0, -1, PROJ_RES, sp, ST_CONV));   // spg.py:250-276
         if (data) std::swap(c->Gr, c->Gn);
         std::swap(c->gk, c->gn);
         // the host needs the flags only to decide on a further iteration or to report
@@ -337,7 +384,7 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
         st->res_norm = sqrt(sc[SC_RES2]);
     }
     c->x_feasible = true;
-    if (refresh) AA_CHECK(refresh_after_dictionary(c, false));
+    if (refresh) AA_CHECK(refresh_after_dictionary(c, false, fused));
     return AA_OK;
 }
 
@@ -403,6 +450,8 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "proj_mode")) {
         AA_REQUIRE(value == 0 || value == 1, AA_ERR_ARG, "proj_mode must be 0 or 1");
         g_proj_mode = value;
+    } else if (!strcmp(name, "fuse_finalize")) {
+        g_fuse_finalize = value != 0;
     } else if (!strcmp(name, "qp_overlap_tail")) {
         g_qp_overlap_tail = value != 0;
     } else if (!strcmp(name, "use_graph")) {
@@ -477,7 +526,7 @@ int aa_ctx_destroy(aa_ctx *h)
     comm_destroy(c);
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->redPartial,
-                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->Mdev, &c->alphaDev, &c->qpIters, &c->qpPerm,
+                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->tickets, &c->qpIters, &c->qpPerm,
                      &c->qpStats};
     for (DevBuf *b : all) b->release();
     for (int w = 0; w < 2; ++w)
@@ -610,6 +659,7 @@ int aa_set_state(aa_ctx *h, int k, const double *C, long ldc, const double *Z, c
     c->dict_inputs_overridden = false;
     c->x_feasible = false;
     c->products_valid = false;
+    c->ckz_valid = false;
     for (int m = 0; m < 4; ++m) {
         c->projWarm[m] = false;
         c->projPassHint[m] = 0;
@@ -717,8 +767,12 @@ int aa_outer_iterations(aa_ctx *h, int n_outer, const aa_spg_params *spg, const 
     double *cd = c->costDev.as<double>();
     AA_CHECK_HIP(hipMemsetAsync(slot, 0, sizeof(int), c->stream));
     auto one_iteration = [&]() -> int {
-        AA_CHECK(dictionary_update(c, spg, nullptr, true));
-        if (costs) AA_CHECK(launch_aa_cost(c, cd, slot));
+        bool recorded = false;
+        AA_CHECK(dictionary_update(c, spg, nullptr, true, costs ? cd : nullptr, slot, &recorded));
+        if (costs && !recorded) {
+            AA_CHECK(ensure_ckz(c));
+            AA_CHECK(launch_aa_cost(c, cd, slot));
+        }
         AA_CHECK(weights_update(c, qp, nullptr));
         if (costs) AA_CHECK(launch_aa_cost(c, cd, slot));
         return AA_OK;
@@ -977,9 +1031,10 @@ int aa_quad_simplex_spg_batch(int device, const double *A, const double *B, long
             rc = AA_ERR_HIP;
         }
     }
+    aa_qp_stats prof_stats;
     if (rc == AA_OK)
         rc = launch_qp(c, A, dB.as<double>(), stride_j, stride_t, nullptr, dZ.as<double>(), k, n, k, params,
-                       dI.as<int>(), nullptr);
+                       dI.as<int>(), g_qp_profile ? &prof_stats : (aa_qp_stats *)nullptr);
     if (rc == AA_OK) {
         hipError_t e = hipStreamSynchronize(c->stream);
         if (e == hipSuccess) e = hipMemcpy(Zout, dZ.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost);

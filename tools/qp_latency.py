@@ -19,9 +19,9 @@ def timed(A, B, Z0, **kw):
 k = 32
 A, B, Z0 = problem(64, k)
 t0, _ = timed(A, B, Z0, max_iterations=1, epsilon_two=0.0, epsilon_one=0.0)
-for cap, label in ((1, "wave kernel"), (100000, "lane kernel")):
-    _backend.set_option("qp_mode", 1 if cap == 1 else 2)     # the size rule would pick wave-only here
-    _backend.set_option("qp_pass_cap", cap)
+for cap, label in ((1, "wave kernel"), (100000, "lane kernel"), (-1, "row kernel")):
+    _backend.set_option("qp_mode", 1 if cap == 1 else (3 if cap < 0 else 2))
+    _backend.set_option("qp_pass_cap", max(cap, 1))
     for iters in (50, 200):
         t, it = timed(A, B, Z0, max_iterations=iters, epsilon_two=0.0, epsilon_one=0.0, max_feval=10**8)
         print("%s: n=64, %d forced passes: %.3f ms total, %.2f us per pass (call overhead ~%.3f ms)"
@@ -33,3 +33,13 @@ t1, _ = timed(A, B, Z0, max_iterations=1, epsilon_two=0.0, epsilon_one=0.0)
 t, it = timed(A, B, Z0, max_iterations=17, epsilon_two=0.0, epsilon_one=0.0, max_feval=10**8)
 print("lane kernel: n=65536 (1024 waves), 16 extra forced passes: %.3f ms -> %.2f us per pass"
       % (1e3 * (t - t1), 1e6 * (t - t1) / 16), flush=True)
+
+_backend.set_option("qp_mode", 3)
+_backend.set_option("qp_profile", 1)
+for nn in (4, 8192, 65536):
+    A, B, Z0 = problem(nn, k)
+    t1, _ = timed(A, B, Z0, max_iterations=1, epsilon_two=0.0, epsilon_one=0.0)
+    t, it = timed(A, B, Z0, max_iterations=17, epsilon_two=0.0, epsilon_one=0.0, max_feval=10**8)
+    print("row kernel: n=%d, 16 extra forced passes: %.3f ms -> %.2f us per pass" % (nn, 1e3 * (t - t1), 1e6 * (t - t1) / 16), flush=True)
+    t, it = timed(A, B, Z0)
+    print("row kernel: n=%d to convergence: %.3f ms, mean passes %.2f max %d" % (nn, 1e3 * t, it.mean(), it.max()), flush=True)
