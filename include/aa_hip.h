@@ -210,6 +210,37 @@ int aa_dictionary_update(aa_ctx *ctx, const aa_spg_params *params, aa_spg_stats 
  * refresh at :640-643 (:501-503). */
 int aa_weights_update(aa_ctx *ctx, const aa_qp_params *params, aa_qp_stats *stats);
 
+/* The alternating loop of _iterate_aa / _iterate_kernel_aa (archetypal_analysis.py:586-663,
+ * :455-524) for delta == 0, with the monotonicity check (:167-174) and the stopping rule
+ * (:177-197, :663) evaluated ON THE DEVICE after every iteration: the host enqueues
+ * `check_every` iterations at a time and reads one small status record per batch instead of
+ * synchronising three times per iteration.  When the rule fires at iteration j the factors of
+ * iteration j are kept (a conditional device-side snapshot), the iterations that were already
+ * enqueued behind it are discarded, and the context is left consistent with iteration j. */
+typedef struct {
+    int    max_outer;          /* archetypal_analysis.py:586 `max_iterations`             */
+    double tolerance;
+    int    criterion;          /* 0: abs_delta_f, 1: rel_delta_f (:177-197)                */
+    int    require_monotonic;  /* :167-174                                                 */
+    int    update_dictionary, update_weights;
+    int    check_every;        /* iterations per host poll (>= 1)                          */
+} aa_iter_params;
+
+typedef struct {
+    int    n_iter;             /* 0-based index of the last iteration (reference n_iter)   */
+    int    converged;          /* the stopping rule fired                                  */
+    int    error_stage;        /* 0 none, 1 / 2: cost increased after dictionary / weights */
+    int    error_iter;
+    int    spg_flags;          /* OR of the dictionary SPG's AA_SPG_FLAG_* over iterations */
+    int    reserved;
+    double cost;               /* cost after the last iteration kept                       */
+} aa_iter_stats;
+
+/* cost0: cost of the prepared state (aa_prepare); costs: 2 * max_outer entries, filled for the
+ * iterations kept.  Returns AA_OK also when error_stage != 0 (the caller raises). */
+int aa_iterate(aa_ctx *ctx, const aa_iter_params *it, const aa_spg_params *spg,
+               const aa_qp_params *qp, double cost0, double *costs, aa_iter_stats *stats);
+
 /* n_outer full outer iterations (dictionary, weights) without returning to the
  * caller; costs[2*i], costs[2*i+1] = cost after the dictionary / weights update of
  * iteration i.  delta == 0 only (no scale-factor update).  Replaces the loop body

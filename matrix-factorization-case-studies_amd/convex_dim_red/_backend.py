@@ -55,6 +55,20 @@ class SPGStats(ctypes.Structure):
                 ("flags", ctypes.c_int), ("res_norm", ctypes.c_double)]
 
 
+class IterParams(ctypes.Structure):
+    """aa_iter_params: the loop controls of _iterate_aa (reference archetypal_analysis.py:534-541)."""
+    _fields_ = [("max_outer", ctypes.c_int), ("tolerance", ctypes.c_double),
+                ("criterion", ctypes.c_int), ("require_monotonic", ctypes.c_int),
+                ("update_dictionary", ctypes.c_int), ("update_weights", ctypes.c_int),
+                ("check_every", ctypes.c_int)]
+
+
+class IterStats(ctypes.Structure):
+    _fields_ = [("n_iter", ctypes.c_int), ("converged", ctypes.c_int),
+                ("error_stage", ctypes.c_int), ("error_iter", ctypes.c_int),
+                ("spg_flags", ctypes.c_int), ("reserved", ctypes.c_int), ("cost", ctypes.c_double)]
+
+
 class QPStats(ctypes.Structure):
     _fields_ = [("total_passes", ctypes.c_long), ("max_passes", ctypes.c_int),
                 ("reserved", ctypes.c_int)]
@@ -90,6 +104,9 @@ _SIGNATURES = {
     "aa_weights_update": (ctypes.c_int, [_vp, ctypes.POINTER(QPParams), ctypes.POINTER(QPStats)]),
     "aa_outer_iterations": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(SPGParams),
                                            ctypes.POINTER(QPParams), _dp]),
+    "aa_iterate": (ctypes.c_int, [_vp, ctypes.POINTER(IterParams), ctypes.POINTER(SPGParams),
+                                  ctypes.POINTER(QPParams), ctypes.c_double, _dp,
+                                  ctypes.POINTER(IterStats)]),
     "aa_reconstruction_cost": (ctypes.c_int, [_vp, _dp]),
     "aa_get_archetypes": (ctypes.c_int, [_vp, _dp, ctypes.c_long]),
     "aa_distance_column": (ctypes.c_int, [_vp, ctypes.c_long, _dp]),
@@ -374,6 +391,22 @@ class Context(object):
         _check(self.lib.aa_outer_iterations(self.h, n_outer, ctypes.byref(sp), ctypes.byref(qp),
                                             _ptr(costs)))
         return costs
+
+    def iterate(self, cost0, max_outer, tolerance, stopping_criterion, require_monotonic,
+                update_dictionary, update_weights, spg_kw, qp_kw, check_every=8):
+        """Up to ``max_outer`` outer iterations with the monotonicity check and the stopping rule
+        evaluated on the device (aa_iterate); returns (costs[2 * (n_iter + 1)], IterStats)."""
+        crit = {"abs_delta_f": 0, "rel_delta_f": 1}.get(stopping_criterion)
+        if crit is None:
+            raise ValueError("unsupported stopping criterion '%s'" % stopping_criterion)
+        ip = IterParams(int(max_outer), float(tolerance), crit, int(bool(require_monotonic)),
+                        int(bool(update_dictionary)), int(bool(update_weights)), int(check_every))
+        sp, qp = spg_params(**spg_kw), qp_params(**qp_kw)
+        costs = np.zeros(2 * int(max_outer))
+        st = IterStats()
+        _check(self.lib.aa_iterate(self.h, ctypes.byref(ip), ctypes.byref(sp), ctypes.byref(qp),
+                                   float(cost0), _ptr(costs), ctypes.byref(st)))
+        return costs[:2 * (st.n_iter + 1)], st
 
     def reconstruction_cost(self):
         c = ctypes.c_double(0)

@@ -31,6 +31,7 @@ from .validation_utils import check_array_shape, check_stochastic_matrix
 
 INTEGER_TYPES = (numbers.Integral, np.integer)
 INITIALIZATION_METHODS = (None, 'random', 'furthest_sum',)
+_DEVICE_LOOP_BATCH = 8          # outer iterations between two host polls of the device loop
 
 
 # ----------------------------------------------------------------------------
@@ -179,14 +180,16 @@ def _update_kernel_aa_scale_factors(alpha, trace_K, CKZ, ZtZ, CKCt, delta, **kwa
 # device-backed building blocks
 # ----------------------------------------------------------------------------
 def _warn_from_spg_flags(stats):
-    """Re-issue the UserWarnings spg() raises (reference spg.py:225-229,272-281)."""
-    if stats.flags & _backend.SPG_FLAG_LAMBDA_MIN:
+    """Re-issue the UserWarnings spg() raises (reference spg.py:225-229,272-281); ``stats``
+    is one update's SPGStats or the device loop's IterStats (flags OR-ed over its iterations)."""
+    flags = stats.flags if hasattr(stats, 'flags') else stats.spg_flags
+    if flags & _backend.SPG_FLAG_LAMBDA_MIN:
         warnings.warn('step size below tolerance in SPG line search', UserWarning)
-    if stats.flags & _backend.SPG_FLAG_MAX_FEVAL:
+    if flags & _backend.SPG_FLAG_MAX_FEVAL:
         warnings.warn('maximum number of function evaluations exceeded in SPG', UserWarning)
-    if stats.flags & _backend.SPG_FLAG_MAX_ITER:
+    if flags & _backend.SPG_FLAG_MAX_ITER:
         warnings.warn('maximum number of iterations exceeded in SPG', UserWarning)
-    if stats.flags & _backend.SPG_FLAG_PROJ_UNCONV:
+    if flags & _backend.SPG_FLAG_PROJ_UNCONV:
         warnings.warn('simplex projection pass cap reached on the device', RuntimeWarning)
 
 
@@ -269,6 +272,45 @@ def _iterate_on_device(ctx, label, weights, dictionary, alpha, delta, update_wei
         print('{:<12s} | {:<13s} | {:<13s} | {:<12s}'.format(
             'Iteration', 'Cost', 'Cost delta', 'Time'))
         print(80 * '-')
+
+    if not (update_scale_factors and delta != 0):
+        # delta == 0 (every driver configuration): the loop runs on the device, monotonicity
+        # check and stopping rule included; the host reads one status record per batch of
+        # iterations (aa_iterate).  verbose: one batch per call so the table can be printed.
+        stop_name = kwargs.get('stopping_criterion', 'abs_delta_f')
+        n_iter = -1
+        done = False
+        while not done and n_iter + 1 < max_iterations:
+            budget = max_iterations - (n_iter + 1)
+            chunk = min(budget, _DEVICE_LOOP_BATCH) if verbose else budget
+            start_time = time.perf_counter()
+            costs, st = ctx.iterate(new_cost, chunk, tolerance, stop_name, require_monotonic,
+                                    update_dictionary, update_weights, dictionary_solver_kwargs,
+                                    weights_solver_kwargs, check_every=_DEVICE_LOOP_BATCH)
+            elapsed = time.perf_counter() - start_time
+            ran = max(st.reserved, 1)
+            per_iter = elapsed / ran
+            if update_dictionary:
+                _warn_from_spg_flags(st)
+            if st.error_stage:
+                raise RuntimeError('factorization cost increased after {} update'.format(
+                    'dictionary' if st.error_stage == 1 else 'weights'))
+            starts = np.concatenate(([new_cost], costs[1::2][:-1]))
+            finals = costs[1::2]
+            for j in range(st.n_iter + 1):
+                iter_times.append(per_iter)
+                cost_deltas.append(finals[j] - starts[j])
+                if verbose:
+                    print('{:12d} | {: 12.6e} | {: 12.6e} | {: 12.6e}'.format(
+                        n_iter + 2 + j, finals[j], finals[j] - starts[j], per_iter))
+            n_iter += st.n_iter + 1
+            new_cost = st.cost
+            if st.converged:
+                if verbose:
+                    print('*** Converged at iteration {:d} ***'.format(n_iter + 1))
+                done = True
+        dictionary, weights, _ = ctx.get_state()
+        return (weights, dictionary, alpha, new_cost, n_iter, np.mean(iter_times), cost_deltas)
 
     n_iter = -1
     for n_iter in range(max_iterations):

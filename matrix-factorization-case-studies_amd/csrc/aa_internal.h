@@ -121,6 +121,10 @@ struct ProjState {          // per projection, device memory
     double warm[4][AA_MAX_K];     // final thresholds of the previous projection of each kind
 };
 
+struct IterState {          // aa_iterate: device-side loop status
+    int stop, converged, error_stage, stop_iter, last_iter, spg_flags, pad0, pad1;
+};
+
 // ------------------------------------------------------------------ context
 struct Comm;   // RCCL wrapper (comm.hip)
 
@@ -175,7 +179,7 @@ struct Ctx {
     DevBuf proj;                               // ProjState
     DevBuf projList, projSegCnt;               // candidate lists of the column projection
     DevBuf Mdev, alphaDev;                     // KP*KP, KP
-    DevBuf tickets;                            // arrival counters of the last-block-done reductions
+    DevBuf iterState, snapC, snapZ;            // aa_iterate: status record, factors at the stopping iteration
     DevBuf qpIters;                            // n ints: pass counts of the latest weights update
     DevBuf qpPerm;                             // n ints: sample order of the lane kernel
     bool qp_iters_valid = false;               // qpIters belongs to the current rows / state
@@ -231,6 +235,9 @@ int launch_transpose_tall_to_wide(Ctx *c, const double *tall, double *wide, void
 int launch_scalar_stage(Ctx *c, int stage, const aa_spg_params *sp, int it);
 int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, int *cost_slot);
 int launch_dict_setup(Ctx *c, const aa_spg_params *sp, double fnorm);
+int launch_iter_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
+                      const aa_iter_params *ip);
+int launch_cost_carry(Ctx *c, double *costs, int *slot, double cost0);
 enum { ST_INIT_F = 0, ST_ALPHA = 1, ST_LINESEARCH = 2, ST_BB = 3, ST_CONV = 4 };
 int launch_row_sqnorm_sum(Ctx *c, double *trace_out_host);
 int launch_distance_column(Ctx *c, long j_local, int owner_has_row, const double *xj_host, double *d_host);
@@ -268,6 +275,7 @@ extern int g_qp_pass_cap;         // kernels_qp.hip
 extern int g_qp_mode;             // kernels_qp.hip
 extern int g_qp_row_waves;        // kernels_qp.hip
 extern int g_qp_row_hot;          // kernels_qp.hip
+extern int g_qp_row_chunk;        // kernels_qp.hip
 extern int g_qp_refill_min;       // kernels_qp.hip
 extern int g_qp_waves;            // kernels_qp.hip
 extern int g_qp_sort;             // kernels_qp.hip

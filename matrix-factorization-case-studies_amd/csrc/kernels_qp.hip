@@ -981,7 +981,6 @@ __device__ __forceinline__ double qr_threshold(const double (&w)[CPL], unsigned 
 }
 
 #define QR_MAXMEM 16
-#define QR_CHUNK 4        // queue tickets a wave takes per atomic (one per row)
 template <int CPL>
 __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[lda][lda], zero padded*/,
                                                int lda, const double *__restrict__ B, long stride_j,
@@ -989,7 +988,7 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
                                                double *__restrict__ Z, int ldz, long n, int k,
                                                aa_qp_params p, int *__restrict__ iters,
                                                QpHeader *__restrict__ hdr,
-                                               const int *__restrict__ perm, int hot_passes, int prof)
+                                               const int *__restrict__ perm, int hot_passes, int prof, int QR_CHUNK)
 {
     constexpr int KQ = 16 * CPL;
     __shared__ __attribute__((aligned(16))) double vb[4][KQ];
@@ -1021,6 +1020,8 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
     unsigned sup = 0u, sup_r = 0u;                 // supports of the latest direction / residual projection
     int prio = 0;
     unsigned int dbg_rounds = 0u, dbg_trips = 0u;  // qp_profile: Michelot rounds / trips of this lane
+    unsigned long long st_total = 0ull;            // pass statistics of this row, one atomic per wave at exit
+    int st_max = 0;
 
     // Work distribution.  The queue is the sample list in longest-first order; a wave takes
     // QR_CHUNK tickets per atomic and always has the NEXT chunk's atomic in flight, and every
@@ -1210,11 +1211,9 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
 #pragma unroll
                 for (int q = 0; q < CPL; ++q)
                     if (live[q]) Z[row * ldz + comp0 + q] = x[q];
-                if (r == 0) {
-                    if (iters) iters[row] = n_iter;
-                    atomicAdd(&hdr->total_passes, (unsigned long long)n_iter);
-                    atomicMax(&hdr->max_passes, (unsigned long long)n_iter);
-                }
+                if (r == 0 && iters) iters[row] = n_iter;
+                st_total += (unsigned long long)n_iter;
+                st_max = n_iter > st_max ? n_iter : st_max;
                 active = false;
             }
         }
@@ -1263,6 +1262,22 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
         }
         if (!__any(active || nxt >= 0) && (drained || (q_left == 0 && !have_ahead && hot_wave))) break;
     }
+    {   // statistics: the four rows' totals combined in lane 0, one atomic pair per wave
+        unsigned long long tot = 0ull;
+        int mx = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)st_total, 16 * q);
+            const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(st_total >> 32), 16 * q);
+            tot += ((unsigned long long)hi << 32) | lo;
+            const int m = __builtin_amdgcn_readlane(st_max, 16 * q);
+            mx = m > mx ? m : mx;
+        }
+        if (lane == 0 && tot) {
+            atomicAdd(&hdr->total_passes, tot);
+            atomicMax(&hdr->max_passes, (unsigned long long)mx);
+        }
+    }
     if (prof && r == 0) {                          // per row: Michelot rounds, trips of its wave
         atomicAdd(&hdr->n_overflow, dbg_rounds);
         if (lane == 0) atomicAdd(&hdr->next_overflow, dbg_trips);
@@ -1275,6 +1290,7 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
 int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
 int g_qp_row_waves = 3072;     // most waves of the row kernel (k_qp_row): 3 per SIMD
 int g_qp_row_hot = 24;         // passes after which a sample's wave takes issue priority
+int g_qp_row_chunk = 4;        // queue tickets a wave takes per atomic
 int g_qp_refill_min = 64;      // idle lanes of a wave that trigger a refill (1..64); 64 = only
                                // when the whole wave is idle: a sample's start-up (strided row
                                // loads, a cold projection) is executed by the whole wave, and
@@ -1466,11 +1482,11 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         if (k <= 16)
             hipLaunchKernelGGL(k_qp_row<1>, dim3((unsigned)waves), dim3(64), 0, c->stream, A2d, KW, Btall,
                                stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr, perm,
-                               g_qp_row_hot, g_qp_profile);
+                               g_qp_row_hot, g_qp_profile, g_qp_row_chunk);
         else
             hipLaunchKernelGGL(k_qp_row<2>, dim3((unsigned)waves), dim3(64), 0, c->stream, A2d, KW, Btall,
                                stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr, perm,
-                               g_qp_row_hot, g_qp_profile);
+                               g_qp_row_hot, g_qp_profile, g_qp_row_chunk);
     } else if (wave_only) {
         long blocks = (n + 3) / 4;
         if (blocks > 2048) blocks = 2048;

@@ -56,31 +56,7 @@ __device__ __forceinline__ double load_a(double a_const, const double *scal, int
 
 #define PROJ_NT 1024       // threads per block of the first / finish passes of a projection
 
-// "Last block done": true in exactly one block of the grid -- the last one to arrive -- whose
-// threads then see every global write the other blocks made before their call (release fence,
-// atomic ticket, acquire fence).  That block runs the second stage of a two-stage reduction
-// and the scalar step behind it INSIDE the producing kernel, in the same fixed order the
-// separate finalize kernel uses (deterministic), instead of paying a ~5-9 us launch for a few
-// hundred numbers.  The ticket is returned to 0 for the next launch on the stream.
-__device__ __forceinline__ bool last_block_arrives(unsigned int *ticket)
-{
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int total = gridDim.x * gridDim.y;
-        const unsigned int t = atomicAdd(ticket, 1u);
-        s_last = (t == total - 1u) ? 1 : 0;
-        if (s_last) atomicExch(ticket, 0u);
-    }
-    __syncthreads();
-    const bool last = s_last != 0;
-    if (last) __threadfence();
-    return last;
-}
-
-// second stage + scalar step, defined further down; also callable from the last block of a
-// producing kernel (single rank)
+// second stage + scalar step, defined further down
 enum { POST_NONE = -1, POST_COLMAX = 0, POST_MICHELOT, POST_FIN, POST_SCALAR_SUM, POST_FIRST };
 #define FIN_NT 1024
 __device__ void post_step(int kind, int mode, const double *__restrict__ red, int KP, int k,
@@ -163,12 +139,7 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_finish(int mode, const double 
                                                      long rows_pb, int k,
                                                      const ProjState *__restrict__ ps,
                                                      double *__restrict__ out,
-                                                     double *__restrict__ partial,
-                                                     unsigned int *__restrict__ ticket,
-                                                     double *__restrict__ red,
-                                                     ProjState *__restrict__ psw,
-                                                     double *__restrict__ scalw, int stage_after,
-                                                     aa_spg_params sp)
+                                                     double *__restrict__ partial)
 {
     __shared__ double sm[4 * PROJ_NT];
     constexpr int RS = PROJ_NT / KP;
@@ -207,16 +178,6 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_finish(int mode, const double 
         }
     }
     block_col_combine<KP, 4, PROJ_NT>(v, 8u, sm, partial + (size_t)blockIdx.x * 4 * KP);
-    // single rank: the last block sums the per-block partials, derives the SPG scalars of this
-    // projection (POST_FIN) and runs the scalar stage that follows it (spg.py:186-189 / :246-276)
-    if (ticket && last_block_arrives(ticket)) {
-        finalize_sum_block(partial, (int)gridDim.x, 4, KP, 8u, red, sm, nullptr, 0, 1);
-        post_step(POST_FIN, mode, red, KP, k, psw, scalw, 0);
-        if (stage_after >= 0) {
-            __syncthreads();
-            if (threadIdx.x == 0) scalar_stage_simple(stage_after, scalw, sp);
-        }
-    }
 }
 
 // ---------------------------------------------------------------- candidate-list projection
@@ -237,13 +198,9 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_first(const double *__restrict
                                                     long n, long rows_pb, int k, int warm_slot,
                                                     const ProjState *__restrict__ ps,
                                                     double *__restrict__ wout,
-                                                    double *__restrict__ partial,
-                                                    unsigned int *__restrict__ ticket,
-                                                    double *__restrict__ red,
-                                                    ProjState *__restrict__ psw,
-                                                    double *__restrict__ scalw)
+                                                    double *__restrict__ partial)
 {
-    __shared__ double sm[4 * PROJ_NT];
+    __shared__ double sm[3 * PROJ_NT];
     constexpr int RS = PROJ_NT / KP;
     const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
     const double a = load_a(a_const, scal, a_slot);
@@ -265,10 +222,6 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_first(const double *__restrict
         }
     }
     block_col_combine<KP, 3, PROJ_NT>(v, 1u, sm, partial + (size_t)blockIdx.x * 3 * KP);
-    if (ticket && last_block_arrives(ticket)) {          // single rank: lower bounds of t* in place
-        finalize_sum_block(partial, (int)gridDim.x, 3, KP, 1u, red, sm, nullptr, 0, 1);
-        post_step(POST_FIRST, 0, red, KP, k, psw, scalw, 0);
-    }
 }
 
 // candidates {w > t_lower}: thread (rsub, comp) of block b appends its own rows, in row
@@ -711,12 +664,18 @@ __global__ __launch_bounds__(FIN_NT) void k_finalize_sum(const double *__restric
                                                          ProjState *__restrict__ ps,
                                                          double *__restrict__ scal, int slot,
                                                          double *__restrict__ gather, int rank,
-                                                         int world)
+                                                         int world, int stage_after, aa_spg_params sp)
 {
     if (ps_gate && ps_gate->done) return;
     __shared__ double sm[4 * FIN_NT];
     finalize_sum_block(partial, nb, NV, KP, max_mask, red, sm, gather, rank, world);
     if (kind != POST_NONE) post_step(kind, mode, red, KP, k, ps, scal, slot);
+    // the scalar stage that consumes these reductions (ST_ALPHA / ST_BB / ST_CONV) rides along
+    // instead of being its own ~5 us launch
+    if (stage_after >= 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) scalar_stage_simple(stage_after, scal, sp);
+    }
 }
 
 // red [NV][KP] -> projection state / scalars, as its own launch (multi-rank: runs after
@@ -725,7 +684,7 @@ __global__ __launch_bounds__(256) void k_post(int kind, int mode, double *__rest
                                               int KP, int k, ProjState *__restrict__ ps,
                                               double *__restrict__ scal, int slot, int gated,
                                               const double *__restrict__ gather, int world, int NV,
-                                              unsigned max_mask)
+                                              unsigned max_mask, int stage_after, aa_spg_params sp)
 {
     if (gated && ps->done) return;
     // gathered [world][NV][KP] -> red [NV][KP], ranks combined in rank order on every rank
@@ -743,6 +702,10 @@ __global__ __launch_bounds__(256) void k_post(int kind, int mode, double *__rest
     }
     __syncthreads();
     post_step(kind, mode, red, KP, k, ps, scal, slot);
+    if (stage_after >= 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) scalar_stage_simple(stage_after, scal, sp);
+    }
 }
 
 // ---------------------------------------------------------------- gradient
@@ -764,9 +727,7 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
                                               const double *__restrict__ d,
                                               double *__restrict__ partial,
                                               double *__restrict__ xupd,
-                                              unsigned int *__restrict__ ticket,
-                                              double *__restrict__ scalw, int dot_slot,
-                                              int stage_after, aa_spg_params sp)
+                                              const double *__restrict__ scalw)
 {
     constexpr int T = KP / 16;       // component tiles
     constexpr int S = KP / 4;        // contraction steps
@@ -828,22 +789,6 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
             __syncthreads();
         }
         if (threadIdx.x < KP) partial[(size_t)blockIdx.x * KP + threadIdx.x] = threadIdx.x == 0 ? sm[0] : 0.0;
-        // single rank: the last block adds the per-block dots in block order (the order the
-        // finalize kernel uses) and runs the BB stage behind them (spg.py:232-244)
-        if (ticket && last_block_arrives(ticket)) {
-            double s = 0.0;
-            for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) s += partial[(size_t)b * KP];
-            sm[threadIdx.x] = s;
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) {
-                scalw[dot_slot] = sm[0];
-                if (stage_after >= 0) scalar_stage_simple(stage_after, scalw, sp);
-            }
-        }
     }
 }
 
@@ -1062,6 +1007,11 @@ __device__ double dev_line_search_step(double lam, double delta, double f_old, d
     return 0.5 * lam;
 }
 
+// the same for a block of more than 256 threads: only the first 256 accumulate, all join the
+// barriers
+__device__ double block_trace_MG_n(const double *__restrict__ M, const double *__restrict__ G, int k,
+                                   int KP, bool transposed, double *sm);
+
 // tr(M * G) (or tr(M * G') when transposed), all 256 threads, fixed-order tree.
 __device__ double block_trace_MG(const double *__restrict__ M, const double *__restrict__ G, int k,
                                  int KP, bool transposed, double *sm)
@@ -1120,6 +1070,27 @@ __device__ void linesearch_thread0(double *__restrict__ sc, const aa_spg_params 
     sc[SC_A2] = a2;
     sc[SC_NFEVAL] = nfe;
     sc[SC_FLAGS] = (double)flags;
+}
+
+__device__ double block_trace_MG_n(const double *__restrict__ M, const double *__restrict__ G, int k,
+                                   int KP, bool transposed, double *sm)
+{
+    const int t = threadIdx.x;
+    double s = 0.0;
+    if (t < 256)
+        for (int e = t; e < k * k; e += 256) {
+            const int i = e / k, j = e % k;
+            s += M[i * KP + j] * (transposed ? G[i * KP + j] : G[j * KP + i]);
+        }
+    if (t < 256) sm[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) sm[t] += sm[t + o];
+        __syncthreads();
+    }
+    const double r = sm[0];
+    __syncthreads();
+    return r;
 }
 
 // gram: [0] = C K C' (or (CX)(CX)'), [1] = cross1, [2] = D K D', [3] = cross2
@@ -1189,10 +1160,10 @@ __device__ void scalar_stage_simple(int stage, double *__restrict__ sc, const aa
 }
 
 // ---------------------------------------------------------------- fused small stages
-// (P Q') and (Q Q') of the line search in ONE pass over the two wide arrays, and -- in the
-// last block to finish -- everything that used to be five more launches: the fixed-order sum
-// of the per-block partials, the line search itself (linesearch_thread0), the Gram of the
-// accepted point
+// (P Q') and (Q Q') of the line search in ONE pass over the two wide arrays (per-block
+// partials), and ONE block behind it for everything that used to be five more launches: the
+// fixed-order sum of the partials, the line search itself (linesearch_thread0), the Gram of
+// the accepted point
 //     (P + lam Q)(P + lam Q)' = PP' + lam (PQ' + QP') + lam^2 QQ'
 // written to the Gram state (archetypal_analysis.py:620: no further pass over P), and the
 // cost after the dictionary update from the line search's own scalars
@@ -1201,21 +1172,13 @@ __device__ void scalar_stage_simple(int stage, double *__restrict__ sc, const aa
 template <int KP>
 __global__ __launch_bounds__(256) void k_gram_wide_pq(const double *__restrict__ P,
                                                       const double *__restrict__ Q, int ld,
-                                                      double *__restrict__ partial,
-                                                      unsigned int *__restrict__ ticket,
-                                                      double *__restrict__ gram,
-                                                      const double *__restrict__ M,
-                                                      double *__restrict__ sc, aa_spg_params sp, int k,
-                                                      double *__restrict__ ckct_state,
-                                                      double n_global, double *__restrict__ cost_out,
-                                                      int *__restrict__ cost_slot)
+                                                      double *__restrict__ partial)
 {
     constexpr int JT = KP * KP / 256;
     constexpr int TPI = KP / JT;
     constexpr int CW = 32;
     constexpr int GS = KP * KP;
     __shared__ double As[KP][CW + 1], Bs[KP][CW + 1];
-    __shared__ double smt[256];
     const int t = threadIdx.x, i = t / TPI, j0 = (t % TPI) * JT;
     const int c0 = blockIdx.x * 128;
     double acc1[JT], acc2[JT];
@@ -1244,10 +1207,22 @@ __global__ __launch_bounds__(256) void k_gram_wide_pq(const double *__restrict__
         dst[i * KP + j0 + q] = acc1[q];
         dst[GS + i * KP + j0 + q] = acc2[q];
     }
-    if (!last_block_arrives(ticket)) return;
-    // ---- last block: partials -> gram[1], gram[2] (the order of k_gram_finalize)
-    const int nb = (int)gridDim.x;
-    for (int e = t; e < 2 * GS; e += 256) {
+}
+
+// one block of 1024 threads: partials -> gram[1], gram[2], line search, Gram of the accepted
+// point, cost
+__global__ __launch_bounds__(1024) void k_linesearch_fin(const double *__restrict__ partial, int nb,
+                                                         int KP, double *__restrict__ gram,
+                                                         const double *__restrict__ M,
+                                                         double *__restrict__ sc, aa_spg_params sp, int k,
+                                                         double *__restrict__ ckct_state,
+                                                         double n_global, double *__restrict__ cost_out,
+                                                         int *__restrict__ cost_slot)
+{
+    __shared__ double smt[256];
+    const int GS = KP * KP, t = threadIdx.x;
+    // the order of k_gram_finalize: four interleaved chains over the blocks, then ((0+1)+2)+3
+    for (int e = t; e < 2 * GS; e += 1024) {
         double s4[4] = {0.0, 0.0, 0.0, 0.0};
         int b = 0;
         for (; b + 3 < nb; b += 4) {
@@ -1259,9 +1234,9 @@ __global__ __launch_bounds__(256) void k_gram_wide_pq(const double *__restrict__
         gram[GS + e] = ((s4[0] + s4[1]) + s4[2]) + s4[3];
     }
     __syncthreads();
-    const double tr1 = block_trace_MG(M, gram + GS, k, KP, false, smt) +
-                       block_trace_MG(M, gram + GS, k, KP, true, smt);
-    const double tr2 = block_trace_MG(M, gram + 2 * GS, k, KP, false, smt);
+    double tr1 = 0.0, tr2 = 0.0;
+    tr1 = block_trace_MG_n(M, gram + GS, k, KP, false, smt) + block_trace_MG_n(M, gram + GS, k, KP, true, smt);
+    tr2 = block_trace_MG_n(M, gram + 2 * GS, k, KP, false, smt);
     if (t == 0) {
         linesearch_thread0(sc, sp, tr1, tr2);
         if (cost_out) {
@@ -1271,7 +1246,7 @@ __global__ __launch_bounds__(256) void k_gram_wide_pq(const double *__restrict__
     }
     __syncthreads();
     const double lam = sc[SC_LAMBDA];
-    for (int e = t; e < GS; e += 256) {
+    for (int e = t; e < GS; e += 1024) {
         const int r = e / KP, q = e % KP;
         const double v = gram[e] + lam * (gram[GS + e] + gram[GS + q * KP + r]) + lam * lam * gram[2 * GS + e];
         gram[e] = v;
@@ -1464,6 +1439,7 @@ int tall_setup(Ctx *c)
     // gram partials: tall grams use tallBlocks blocks, wide grams p_pad/128 blocks
     long gb = nb > c->p_pad / 128 ? nb : c->p_pad / 128;
     if (gb < 256) gb = 256;          // tall Grams use up to 256 blocks whatever n is
+    if (gb < 2 * (c->p_pad / 128)) gb = 2 * (c->p_pad / 128);   // k_gram_wide_pq: two Grams per block
     size_t need = (size_t)gb * c->KP * c->KP * sizeof(double);
     size_t need2 = (size_t)nb * 4 * c->KP * sizeof(double) + 4 * c->KP * sizeof(double);
     // residual / distance partials: one per 4 rows
@@ -1483,15 +1459,19 @@ int tall_setup(Ctx *c)
     }
     AA_CHECK(c->Mdev.alloc((size_t)c->KP * c->KP * sizeof(double)));
     AA_CHECK(c->alphaDev.alloc((size_t)c->KP * sizeof(double)));
-    AA_CHECK(c->tickets.alloc(64 * sizeof(unsigned int)));
     return AA_OK;
 }
 
 static inline double *red_buf(Ctx *c) { return c->redOut.as<double>(); }
 
 static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mode, int slot,
-                             bool gated, int nb = 0)
+                             bool gated, int nb = 0, const aa_spg_params *sp = nullptr,
+                             int stage_after = -1)
 {
+    aa_spg_params spv;
+    memset(&spv, 0, sizeof(spv));
+    if (sp) spv = *sp;
+    else stage_after = -1;
     if (nb <= 0) nb = c->tallBlocks;
     double *part = c->redPartial.as<double>();
     double *red = red_buf(c);
@@ -1500,7 +1480,7 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
     if ((c->world <= 1 && !c->force_comm)) {
         hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(FIN_NT), 0, c->stream, part, nb, NV,
                            c->KP, max_mask, red, gate, kind, mode, c->k, ps, c->scalars.as<double>(),
-                           slot, (double *)nullptr, 0, 1);
+                           slot, (double *)nullptr, 0, 1, stage_after, spv);
     } else {
         // one sum all-reduce of a [world][NV][KP] buffer in which every rank fills its own
         // slot, whatever mix of sums and maxima the NV values are; the ranks' values are
@@ -1510,11 +1490,11 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
         double *gather = c->redGather.as<double>();
         hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(FIN_NT), 0, c->stream, part, nb, NV,
                            c->KP, max_mask, red, gate, (int)POST_NONE, mode, c->k, ps,
-                           c->scalars.as<double>(), slot, gather, c->rank, c->world);
+                           c->scalars.as<double>(), slot, gather, c->rank, c->world, -1, spv);
         AA_CHECK(comm_allreduce(c, gather, (long)c->world * NV * c->KP, 0));
         hipLaunchKernelGGL(k_post, dim3(1), dim3(256), 0, c->stream, kind, mode, red, c->KP, c->k, ps,
                            c->scalars.as<double>(), slot, gated ? 1 : 0, (const double *)gather,
-                           c->world, NV, max_mask);
+                           c->world, NV, max_mask, stage_after, spv);
     }
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
@@ -1574,13 +1554,8 @@ static int proj_iterative_passes(Ctx *c, const double *wsrc, int mode, long rpb,
     return AA_OK;
 }
 
-// tickets of the "last block done" reductions, one per producing kernel kind
-enum { TK_PROJ_FIRST = 0, TK_PROJ_FINISH, TK_GRAD, TK_GRAM_PQ, TK_GRAM_FIN, TK_COUNT };
-static inline unsigned int *ticket_of(Ctx *c, int which) { return c->tickets.as<unsigned int>() + which; }
-
 // stage_after >= 0: the scalar stage (ST_ALPHA / ST_CONV) that consumes this projection's
-// reductions runs right behind them -- in the last block of the finish pass on a single rank,
-// as its own launch behind the all-reduce otherwise.
+// reductions runs inside the kernel that finalizes them.
 int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode,
                 const aa_spg_params *sp, int stage_after)
 {
@@ -1591,18 +1566,15 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     double *wbuf = g ? c->tmpTall.as<double>() : (double *)nullptr;
     const double *wsrc = g ? (const double *)wbuf : x;
     const bool multi = c->world > 1 || c->force_comm;
-    const bool fused = !multi && g_fuse_finalize;
-    aa_spg_params spv;
-    memset(&spv, 0, sizeof(spv));
-    if (sp) spv = *sp;
-    else stage_after = -1;
+    if (!sp || !g_fuse_finalize) {
+        // unfused: the caller launches the stage itself (see below)
+    }
     if (g_proj_mode == 0) {
         const int RS = 256 / c->KP;
         const long nseg = (long)c->tallBlocks * RS, segcap = rpb / RS;
         TALL_DISPATCH_NT(PROJ_NT, k_proj_first, x, g, a_const, (const double *)scal, a_slot, c->n, rpb, c->k,
-                      c->projWarm[mode] ? mode : 0, (const ProjState *)ps, wbuf, part,
-                      fused ? ticket_of(c, TK_PROJ_FIRST) : (unsigned int *)nullptr, red_buf(c), ps, scal);
-        if (!fused) AA_CHECK(finalize_and_post(c, 3, 1u, POST_FIRST, 0, 0, false));
+                      c->projWarm[mode] ? mode : 0, (const ProjState *)ps, wbuf, part);
+        AA_CHECK(finalize_and_post(c, 3, 1u, POST_FIRST, 0, 0, false));
         TALL_DISPATCH(k_proj_collect, wsrc, c->n, rpb, c->k, (const ProjState *)ps,
                       c->projList.as<double>(), c->projSegCnt.as<int>());
         if (!multi) {
@@ -1651,12 +1623,12 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     if (mode == PROJ_DIR) out = c->Dt.as<double>();
     TALL_DISPATCH_NT(PROJ_NT, k_proj_finish, mode, x, g, a_const, (const double *)scal, a_slot,
                   (const double *)c->H.as<double>(), (const double *)c->alphaDev.as<double>(), c->n, rpb,
-                  c->k, (const ProjState *)ps, out, part,
-                  fused ? ticket_of(c, TK_PROJ_FINISH) : (unsigned int *)nullptr, red_buf(c), ps, scal,
-                  fused ? stage_after : -1, spv);
-    if (!fused) {
+                  c->k, (const ProjState *)ps, out, part);
+    if (sp && stage_after >= 0 && !g_fuse_finalize) {
         AA_CHECK(finalize_and_post(c, 4, 8u, POST_FIN, mode, 0, false));
-        if (stage_after >= 0) AA_CHECK(launch_scalar_stage(c, stage_after, &spv, 0));
+        AA_CHECK(launch_scalar_stage(c, stage_after, sp, 0));
+    } else {
+        AA_CHECK(finalize_and_post(c, 4, 8u, POST_FIN, mode, 0, false, 0, sp, stage_after));
     }
     AA_CHECK_HIP(hipGetLastError());
     if (mode > 0) c->projWarm[mode] = true;
@@ -1664,7 +1636,7 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
 }
 
 // xupd (nullable, needs d_for_dot): x += lambda d in the same pass.  stage_after >= 0 (with
-// sp): the scalar stage that consumes <d, g> (ST_BB) runs behind the reduction.
+// sp): the scalar stage that consumes <d, g> (ST_BB) runs inside the finalize kernel.
 int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, double scale,
                 const double *d_for_dot, int dot_slot, double *xupd, const aa_spg_params *sp,
                 int stage_after)
@@ -1677,27 +1649,24 @@ int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, doubl
     const int nb = (int)((c->n + rpb - 1) / rpb);
     double *part = c->redPartial.as<double>();
     double *pdot = d_for_dot ? part : (double *)nullptr;
-    const bool multi = c->world > 1 || c->force_comm;
-    const bool fused = d_for_dot && !multi && g_fuse_finalize;
-    aa_spg_params spv;
-    memset(&spv, 0, sizeof(spv));
-    if (sp) spv = *sp;
-    else stage_after = -1;
-    unsigned int *tk = fused ? ticket_of(c, TK_GRAD) : (unsigned int *)nullptr;
     if (c->KP == 32)
         hipLaunchKernelGGL(k_grad<32>, dim3(nb), dim3(256), 0, c->stream, Graw, H,
                            (const double *)c->Mdev.as<double>(), (const double *)c->alphaDev.as<double>(),
-                           scale, c->n, rpb, c->k, gout, d_for_dot, pdot, xupd, tk,
-                           c->scalars.as<double>(), dot_slot, fused ? stage_after : -1, spv);
+                           scale, c->n, rpb, c->k, gout, d_for_dot, pdot, xupd,
+                           (const double *)c->scalars.as<double>());
     else
         hipLaunchKernelGGL(k_grad<64>, dim3(nb), dim3(256), 0, c->stream, Graw, H,
                            (const double *)c->Mdev.as<double>(), (const double *)c->alphaDev.as<double>(),
-                           scale, c->n, rpb, c->k, gout, d_for_dot, pdot, xupd, tk,
-                           c->scalars.as<double>(), dot_slot, fused ? stage_after : -1, spv);
+                           scale, c->n, rpb, c->k, gout, d_for_dot, pdot, xupd,
+                           (const double *)c->scalars.as<double>());
     AA_CHECK_HIP(hipGetLastError());
-    if (d_for_dot && !fused) {
-        AA_CHECK(finalize_and_post(c, 1, 0u, POST_SCALAR_SUM, 0, dot_slot, false, nb));
-        if (stage_after >= 0) AA_CHECK(launch_scalar_stage(c, stage_after, &spv, 0));
+    if (d_for_dot) {
+        if (sp && stage_after >= 0 && !g_fuse_finalize) {
+            AA_CHECK(finalize_and_post(c, 1, 0u, POST_SCALAR_SUM, 0, dot_slot, false, nb));
+            AA_CHECK(launch_scalar_stage(c, stage_after, sp, 0));
+        } else {
+            AA_CHECK(finalize_and_post(c, 1, 0u, POST_SCALAR_SUM, 0, dot_slot, false, nb, sp, stage_after));
+        }
     }
     return AA_OK;
 }
@@ -1789,6 +1758,94 @@ __global__ void k_set_scalars(double *__restrict__ sc, double trace, double fnor
     }
 }
 
+// ---------------------------------------------------------------- device-side loop control
+// Status record of aa_iterate (device memory): written by one thread after every outer
+// iteration, read by the host once per batch.
+// costs[2*it], costs[2*it + 1]: cost after the dictionary / weights update of iteration `it`.
+__global__ void k_iter_judge(int it, double cost0, const double *__restrict__ costs,
+                             IterState *__restrict__ st, double tol, int criterion, int require,
+                             int upd_dict, int upd_w, const double *__restrict__ scal)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->stop) return;
+    const double old = it == 0 ? cost0 : costs[2 * it - 1];
+    const double c1 = costs[2 * it], c2 = costs[2 * it + 1];
+    if (upd_dict) {
+        // the SPG loop ends converged, at the function-evaluation cap, or at the iteration cap
+        // (the warning of spg.py:278-281)
+        int fl = (int)scal[SC_FLAGS];
+        if (!(fl & (AA_SPG_FLAG_CONVERGED | AA_SPG_FLAG_MAX_FEVAL))) fl |= AA_SPG_FLAG_MAX_ITER;
+        st->spg_flags |= fl & ~AA_SPG_FLAG_CONVERGED;
+    }
+    // archetypal_analysis.py:167-174, evaluated after each update against the cost the
+    // iteration started from
+    if (upd_dict && require && c1 > old && fabs(c1 - old) > tol) {
+        st->stop = 1;
+        st->error_stage = 1;
+        st->stop_iter = it;
+        return;
+    }
+    if (upd_w && require && c2 > old && fabs(c2 - old) > tol) {
+        st->stop = 1;
+        st->error_stage = 2;
+        st->stop_iter = it;
+        return;
+    }
+    // :177-197
+    bool conv;
+    if (criterion == 0) conv = fabs(c2 - old) < tol;
+    else conv = fabs((c2 - old) / fmax(fabs(c2), fabs(old))) < tol;
+    st->last_iter = it;
+    if (conv) {
+        st->stop = 1;
+        st->converged = 1;
+        st->stop_iter = it;
+    }
+}
+
+// keeps the factors of the iteration at which the loop stopped (later iterations of the same
+// batch overwrite Ct / Zt); every block reads one word and leaves unless this is that iteration
+__global__ __launch_bounds__(256) void k_iter_snapshot(int it, const IterState *__restrict__ st,
+                                                       const double *__restrict__ Ct,
+                                                       const double *__restrict__ Zt,
+                                                       double *__restrict__ snapC,
+                                                       double *__restrict__ snapZ, long elems)
+{
+    if (!st->stop || st->stop_iter != it) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < elems; i += (long)gridDim.x * 256) {
+        snapC[i] = Ct[i];
+        snapZ[i] = Zt[i];
+    }
+}
+
+// costs[slot] = the previous entry (an update that is switched off leaves the cost unchanged)
+__global__ void k_cost_carry(double *__restrict__ costs, int *__restrict__ slot, double cost0)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int idx = (*slot)++;
+    costs[idx] = idx == 0 ? cost0 : costs[idx - 1];
+}
+
+int launch_iter_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
+                      const aa_iter_params *ip)
+{
+    hipLaunchKernelGGL(k_iter_judge, dim3(1), dim3(64), 0, c->stream, it, cost0, costs, st, ip->tolerance,
+                       ip->criterion, ip->require_monotonic, ip->update_dictionary, ip->update_weights,
+                       (const double *)c->scalars.as<double>());
+    hipLaunchKernelGGL(k_iter_snapshot, dim3(512), dim3(256), 0, c->stream, it, (const IterState *)st,
+                       (const double *)c->Ct.as<double>(), (const double *)c->Zt.as<double>(),
+                       c->snapC.as<double>(), c->snapZ.as<double>(), (long)c->n_pad * c->KP);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_cost_carry(Ctx *c, double *costs, int *slot, double cost0)
+{
+    hipLaunchKernelGGL(k_cost_carry, dim3(1), dim3(64), 0, c->stream, costs, slot, cost0);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
 int launch_scale_gram(Ctx *c, double *dst, const double *src)
 {
     const int elems = c->KP * c->KP;
@@ -1830,21 +1887,24 @@ int launch_gram_wide(Ctx *c, const double *A, const double *B, double *out_dev)
     return AA_OK;   // wide operands are already replicated across ranks
 }
 
-// line search of the data form in one launch (see k_gram_wide_pq); cost_out / cost_slot:
-// optional recording of the cost after the dictionary update
+// line search of the data form in two launches (k_gram_wide_pq, k_linesearch_fin); cost_out /
+// cost_slot: optional recording of the cost after the dictionary update
 int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, int *cost_slot)
 {
     const int nb = (int)(c->p_pad / 128);
     double *part = c->redPartial.as<double>();
     double *ckct = c->gramState.as<double>() + (size_t)c->KP * c->KP;
-#define GPQ(KPV)                                                                              \
-    hipLaunchKernelGGL(k_gram_wide_pq<KPV>, dim3(nb), dim3(256), 0, c->stream,                \
-                       (const double *)c->P.as<double>(), (const double *)c->Q.as<double>(),  \
-                       (int)c->p_pad, part, ticket_of(c, TK_GRAM_PQ), c->gramOut.as<double>(), \
-                       (const double *)c->Mdev.as<double>(), c->scalars.as<double>(), *sp, c->k, ckct, \
-                       (double)c->n_global, cost_out, cost_slot)
-    if (c->KP == 32) GPQ(32); else GPQ(64);
-#undef GPQ
+    if (c->KP == 32)
+        hipLaunchKernelGGL(k_gram_wide_pq<32>, dim3(nb), dim3(256), 0, c->stream,
+                           (const double *)c->P.as<double>(), (const double *)c->Q.as<double>(),
+                           (int)c->p_pad, part);
+    else
+        hipLaunchKernelGGL(k_gram_wide_pq<64>, dim3(nb), dim3(256), 0, c->stream,
+                           (const double *)c->P.as<double>(), (const double *)c->Q.as<double>(),
+                           (int)c->p_pad, part);
+    hipLaunchKernelGGL(k_linesearch_fin, dim3(1), dim3(1024), 0, c->stream, (const double *)part, nb, c->KP,
+                       c->gramOut.as<double>(), (const double *)c->Mdev.as<double>(),
+                       c->scalars.as<double>(), *sp, c->k, ckct, (double)c->n_global, cost_out, cost_slot);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }

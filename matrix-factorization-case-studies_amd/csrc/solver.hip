@@ -469,6 +469,9 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "qp_row_waves")) {
         AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_row_waves must be >= 1");
         g_qp_row_waves = value;
+    } else if (!strcmp(name, "qp_row_chunk")) {
+        AA_REQUIRE(value >= 1 && value <= 4096, AA_ERR_ARG, "qp_row_chunk must be in 1..4096");
+        g_qp_row_chunk = value;
     } else if (!strcmp(name, "qp_row_hot")) {
         AA_REQUIRE(value >= 0, AA_ERR_ARG, "qp_row_hot must be >= 0");
         g_qp_row_hot = value;
@@ -526,7 +529,7 @@ int aa_ctx_destroy(aa_ctx *h)
     comm_destroy(c);
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->redPartial,
-                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->tickets, &c->qpIters, &c->qpPerm,
+                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->iterState, &c->snapC, &c->snapZ, &c->qpIters, &c->qpPerm,
                      &c->qpStats};
     for (DevBuf *b : all) b->release();
     for (int w = 0; w < 2; ++w)
@@ -815,6 +818,79 @@ int aa_outer_iterations(aa_ctx *h, int n_outer, const aa_spg_params *spg, const 
         AA_CHECK_HIP(hipMemcpyAsync(costs, c->costDev.p, (size_t)2 * n_outer * sizeof(double),
                                     hipMemcpyDeviceToHost, c->stream));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return AA_OK;
+}
+
+int aa_iterate(aa_ctx *h, const aa_iter_params *ip, const aa_spg_params *spg, const aa_qp_params *qp,
+               double cost0, double *costs, aa_iter_stats *stats)
+{
+    AA_REQUIRE(h && ip && spg && qp && costs && stats, AA_ERR_ARG, "null argument");
+    AA_REQUIRE(ip->max_outer >= 1 && ip->check_every >= 1, AA_ERR_ARG, "bad iteration counts");
+    AA_REQUIRE(ip->criterion == 0 || ip->criterion == 1, AA_ERR_ARG, "bad stopping criterion");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->have_state && c->grams_valid, AA_ERR_STATE, "aa_iterate needs aa_prepare first");
+    const int n_max = ip->max_outer;
+    const size_t tall_bytes = (size_t)c->n_pad * c->KP * sizeof(double);
+    AA_CHECK(c->costDev.alloc((size_t)(2 * n_max + 64) * sizeof(double)));
+    AA_CHECK(c->costSlot.alloc(64));
+    AA_CHECK(c->iterState.alloc(sizeof(IterState)));
+    AA_CHECK(c->snapC.alloc(tall_bytes));
+    AA_CHECK(c->snapZ.alloc(tall_bytes));
+    int *slot = c->costSlot.as<int>();
+    double *cd = c->costDev.as<double>();
+    IterState *st = c->iterState.as<IterState>();
+    AA_CHECK_HIP(hipMemsetAsync(slot, 0, sizeof(int), c->stream));
+    AA_CHECK_HIP(hipMemsetAsync(st, 0, sizeof(IterState), c->stream));
+    IterState hs;
+    memset(&hs, 0, sizeof(hs));
+    int done = 0;
+    while (done < n_max) {
+        const int batch = n_max - done < ip->check_every ? n_max - done : ip->check_every;
+        for (int b = 0; b < batch; ++b) {
+            if (ip->update_dictionary) {
+                bool recorded = false;
+                AA_CHECK(dictionary_update(c, spg, nullptr, true, cd, slot, &recorded));
+                if (!recorded) {
+                    AA_CHECK(ensure_ckz(c));
+                    AA_CHECK(launch_aa_cost(c, cd, slot));
+                }
+            } else {
+                AA_CHECK(launch_cost_carry(c, cd, slot, cost0));
+            }
+            if (ip->update_weights) {
+                AA_CHECK(weights_update(c, qp, nullptr));
+                AA_CHECK(launch_aa_cost(c, cd, slot));
+            } else {
+                AA_CHECK(launch_cost_carry(c, cd, slot, cost0));
+            }
+            AA_CHECK(launch_iter_judge(c, done + b, cost0, cd, st, ip));
+        }
+        done += batch;
+        AA_CHECK_HIP(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+        AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+        if (hs.stop) break;
+    }
+    const int last = hs.stop ? hs.stop_iter : n_max - 1;
+    AA_CHECK_HIP(hipMemcpy(costs, cd, (size_t)2 * (last + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    stats->n_iter = last;
+    stats->converged = hs.converged;
+    stats->error_stage = hs.error_stage;
+    stats->error_iter = hs.error_stage ? hs.stop_iter : -1;
+    stats->spg_flags = hs.spg_flags;
+    stats->reserved = done;                      /* iterations enqueued (>= n_iter + 1) */
+    stats->cost = costs[2 * last + 1];
+    if (hs.stop && hs.stop_iter < done - 1 && !hs.error_stage) {
+        // iterations behind the stopping one have run: restore its factors and rebuild the
+        // products from them (four passes over the data, once per fit)
+        AA_CHECK_HIP(hipMemcpy(c->Ct.p, c->snapC.p, tall_bytes, hipMemcpyDeviceToDevice));
+        AA_CHECK_HIP(hipMemcpy(c->Zt.p, c->snapZ.p, tall_bytes, hipMemcpyDeviceToDevice));
+        c->products_valid = false;
+        c->grams_valid = false;
+        c->qp_iters_valid = false;
+        AA_CHECK(prepare(c, nullptr));
+        c->x_feasible = true;                    // came out of our own update
+    }
     return AA_OK;
 }
 

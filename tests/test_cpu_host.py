@@ -181,8 +181,6 @@ def test_estimator_argument_validation():
         check_array_shape(np.zeros((2, 3)), (3, 2), "t")
     with pytest.raises(ValueError):
         check_stochastic_matrix(np.ones((2, 2)), (2, 2), "t", axis=1)
-    with pytest.raises(NotImplementedError):
-        cdr.gap_statistic(X)
 
 
 def test_solver_parameter_structs():

@@ -206,7 +206,7 @@ def test_iterate_aa_traces_golden(cdr, qp_kernel, dtype, tol):
             want_cost, want_it = g["out_cost_" + tag]
             assert abs(cost - want_cost) < tol, tag
             if dtype == "float64":
-                assert abs(n_iter - int(want_it)) <= 3, tag
+                assert n_iter == int(want_it), tag
             assert np.array_equal(C.argmax(axis=1), g["out_C_" + tag].argmax(axis=1)), tag
             assert len(deltas) == n_iter + 1
         Z, C, al, cost, n_iter, _, deltas = aa._iterate_aa(
@@ -230,7 +230,7 @@ def test_iterate_kernel_aa_golden(cdr):
                 K, Z0.copy(), C0.copy(), np.ones(k), tolerance=1e-6, max_iterations=40, **kw)
             want_cost, want_it = g["out_cost_" + tag]
             assert abs(cost - want_cost) < 2e-6, tag
-            assert abs(n_iter - int(want_it)) <= 3, tag
+            assert n_iter == int(want_it), tag
             _assert_simplex(C, 1e-12)
             _assert_simplex(Z, 1e-12)
 
@@ -255,7 +255,7 @@ def test_aa_estimator_known_answers(cdr, dtype, tol):
                 want_cost, want_it = g["out_cost_" + key]
                 assert abs(m.cost - want_cost) < tol, key
                 assert sorted(m.dictionary.argmax(axis=1)) == sorted(g["out_argmax_" + key]), key
-                assert abs(m.n_iter - int(want_it)) <= (3 if dtype == "float64" else max(3, int(0.25 * want_it))), key
+                assert abs(m.n_iter - int(want_it)) <= (0 if dtype == "float64" else max(3, int(0.25 * want_it))), key
                 assert np.abs(m.archetypes - m.dictionary.dot(X)).max() < 1e-4 if dtype == "float32" \
                     else np.abs(m.archetypes - m.dictionary.dot(X)).max() < 1e-12
                 _assert_simplex(W, 1e-12)
@@ -769,3 +769,102 @@ def test_row_local_f64_variants_agree(cdr, orc, mode, k):
     want = C.dot(X.dot(X.T.dot(Z)))
     assert np.abs(CKZ - want).max() < 1e-12 * np.abs(want).max()
     assert np.abs(CKCt - C.dot(X).dot(C.dot(X).T)).max() < 1e-12 * np.abs(CKCt).max()
+
+
+# ---------------------------------------------------------------- device-side loop control
+@pytest.mark.parametrize("check_every", [1, 3, 8])
+@pytest.mark.parametrize("criterion,tol", [("abs_delta_f", 1e-5), ("rel_delta_f", 1e-4)])
+def test_device_loop_matches_host_loop(cdr, orc, check_every, criterion, tol):
+    """aa_iterate (monotonicity check and stopping rule on the device, the host polling every
+    `check_every` iterations, factors of the stopping iteration kept by a conditional snapshot)
+    against the same loop driven from the host one update at a time
+    (archetypal_analysis.py:586-663): same n_iter, same factors bit for bit, same costs."""
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(41)
+    n, p, k = 900, 64, 5
+    B = rng.uniform(size=(k, p))
+    X = orc.right_stochastic_matrix((n, k), rng).dot(B) + 0.01 * rng.standard_normal((n, p))
+    C0 = orc.right_stochastic_matrix((k, n), rng)
+    Z0 = orc.right_stochastic_matrix((n, k), rng)
+    spg_kw, qp_kw = dict(max_iterations=1), {}
+    done = {"abs_delta_f": lambda o, c: abs(c - o) < tol,
+            "rel_delta_f": lambda o, c: abs((c - o) / max(abs(c), abs(o))) < tol}[criterion]
+    with _backend.Context(dtype="float64") as ctx:
+        ctx.set_data(X)
+        ctx.set_state(C0, Z0, np.ones(k))
+        cost = ctx.prepare()
+        host_costs, n_host = [], -1
+        for n_host in range(200):
+            old = cost
+            ctx.dictionary_update(**spg_kw)
+            c1 = ctx.cost()
+            ctx.weights_update(**qp_kw)
+            cost = ctx.cost()
+            host_costs += [c1, cost]
+            if done(old, cost):
+                break
+        Ch, Zh, _ = ctx.get_state()
+    assert 3 < n_host < 199
+    with _backend.Context(dtype="float64") as ctx:
+        ctx.set_data(X)
+        ctx.set_state(C0, Z0, np.ones(k))
+        cost0 = ctx.prepare()
+        costs, st = ctx.iterate(cost0, 200, tol, criterion, True, True, True, spg_kw, qp_kw,
+                                check_every=check_every)
+        Cd, Zd, _ = ctx.get_state()
+        after = ctx.cost()                                   # context consistent with the kept state
+        more = ctx.outer_iterations(1, spg_kw, qp_kw)        # ... and usable for further work
+    assert st.n_iter == n_host and st.converged == 1 and st.error_stage == 0
+    assert st.reserved >= n_host + 1 and st.reserved <= n_host + check_every
+    assert np.array_equal(Cd, Ch) and np.array_equal(Zd, Zh)
+    assert np.array_equal(costs[1::2], host_costs[1::2])     # after-weights costs: same kernel
+    assert np.abs(costs[0::2] - np.asarray(host_costs[0::2])).max() < 1e-12 * abs(cost0)
+    assert abs(after - costs[-1]) < 1e-12 * abs(cost0) and st.cost == costs[-1]
+    assert more[-1] <= after + 1e-12
+    assert st.spg_flags & _backend.SPG_FLAG_MAX_ITER           # spg.py:278-281 on every update
+
+
+def test_device_loop_reports_cost_increase(cdr, orc):
+    """archetypal_analysis.py:167-174: a cost that goes up by more than the tolerance stops the
+    loop with the stage that caused it.  Provoked with float32 data whose trace-form cost
+    cancels tr(XX')/n = 5e6 down to ~1e2: its float32 noise (~0.5) is far above the tolerance,
+    so some update soon appears to raise the cost."""
+    from convex_dim_red import archetypal_analysis as aa
+    rng = np.random.RandomState(3)
+    n, p, k = 600, 512, 3
+    X = (100.0 + rng.uniform(size=(n, p))).astype(np.float32)
+    C0 = orc.right_stochastic_matrix((k, n), rng)
+    Z0 = orc.right_stochastic_matrix((n, k), rng)
+    kw = dict(tolerance=1e-9, max_iterations=80, dtype="float32",
+              dictionary_solver_kwargs=dict(max_iterations=1))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(RuntimeError, match="factorization cost increased after (dictionary|weights) update"):
+            aa._iterate_aa(X, Z0, C0, np.ones(k), **kw)
+        # require_monotonic_cost_decrease=False: the same run goes through to the iteration cap
+        out = aa._iterate_aa(X, Z0, C0, np.ones(k), require_monotonic_cost_decrease=False, **kw)
+    assert out[4] == 79 and len(out[6]) == 80
+
+
+def test_device_loop_update_switches(cdr, orc):
+    """update_dictionary / update_weights = False (archetypal_analysis.py:534-541) leave that
+    factor untouched and the loop still records two costs per iteration."""
+    from convex_dim_red import archetypal_analysis as aa
+    rng = np.random.RandomState(8)
+    n, p, k = 400, 30, 4
+    X = rng.uniform(size=(n, p))
+    C0 = orc.right_stochastic_matrix((k, n), rng)
+    Z0 = orc.right_stochastic_matrix((n, k), rng)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kw = dict(tolerance=0, max_iterations=4, dictionary_solver_kwargs=dict(max_iterations=1))
+        Z, C, _, cost_w, n_iter, _, deltas = aa._iterate_aa(X, Z0, C0, np.ones(k),
+                                                            update_dictionary=False, **kw)
+        assert np.array_equal(C, C0) and not np.array_equal(Z, Z0) and n_iter == 3
+        want = orc.iterate_aa(X, Z0.copy(), C0.copy(), np.ones(k), update_dictionary=False, **kw)
+        assert abs(cost_w - want[3]) < 1e-9 * want[3]
+        Z, C, _, cost_d, n_iter, _, deltas = aa._iterate_aa(X, Z0, C0, np.ones(k),
+                                                            update_weights=False, **kw)
+        assert np.array_equal(Z, Z0) and not np.array_equal(C, C0) and len(deltas) == 4
+        want = orc.iterate_aa(X, Z0.copy(), C0.copy(), np.ones(k), update_weights=False, **kw)
+        assert abs(cost_d - want[3]) < 1e-9 * want[3]
