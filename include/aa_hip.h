@@ -222,6 +222,9 @@ typedef struct {
     double tolerance;
     int    criterion;          /* 0: abs_delta_f, 1: rel_delta_f (:177-197)                */
     int    require_monotonic;  /* :167-174                                                 */
+    double mono_tolerance;     /* tolerance of the monotonicity check: the reference uses
+                                  `tolerance`; float32 data pass max(tolerance, the float32
+                                  noise floor of the trace-form cost)                       */
     int    update_dictionary, update_weights;
     int    check_every;        /* iterations per host poll (>= 1)                          */
 } aa_iter_params;

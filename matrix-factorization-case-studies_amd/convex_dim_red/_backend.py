@@ -59,6 +59,7 @@ class IterParams(ctypes.Structure):
     """aa_iter_params: the loop controls of _iterate_aa (reference archetypal_analysis.py:534-541)."""
     _fields_ = [("max_outer", ctypes.c_int), ("tolerance", ctypes.c_double),
                 ("criterion", ctypes.c_int), ("require_monotonic", ctypes.c_int),
+                ("mono_tolerance", ctypes.c_double),
                 ("update_dictionary", ctypes.c_int), ("update_weights", ctypes.c_int),
                 ("check_every", ctypes.c_int)]
 
@@ -393,13 +394,15 @@ class Context(object):
         return costs
 
     def iterate(self, cost0, max_outer, tolerance, stopping_criterion, require_monotonic,
-                update_dictionary, update_weights, spg_kw, qp_kw, check_every=8):
+                update_dictionary, update_weights, spg_kw, qp_kw, check_every=8,
+                mono_tolerance=None):
         """Up to ``max_outer`` outer iterations with the monotonicity check and the stopping rule
         evaluated on the device (aa_iterate); returns (costs[2 * (n_iter + 1)], IterStats)."""
         crit = {"abs_delta_f": 0, "rel_delta_f": 1}.get(stopping_criterion)
         if crit is None:
             raise ValueError("unsupported stopping criterion '%s'" % stopping_criterion)
         ip = IterParams(int(max_outer), float(tolerance), crit, int(bool(require_monotonic)),
+                        float(tolerance if mono_tolerance is None else mono_tolerance),
                         int(bool(update_dictionary)), int(bool(update_weights)), int(check_every))
         sp, qp = spg_params(**spg_kw), qp_params(**qp_kw)
         costs = np.zeros(2 * int(max_outer))

@@ -278,6 +278,13 @@ def _iterate_on_device(ctx, label, weights, dictionary, alpha, delta, update_wei
         # check and stopping rule included; the host reads one status record per batch of
         # iterations (aa_iterate).  verbose: one batch per call so the table can be printed.
         stop_name = kwargs.get('stopping_criterion', 'abs_delta_f')
+        # float32 data (this build's throughput mode): the trace-form cost cancels tr(XX')/n
+        # down to the residual, so it carries ~eps_float32 * tr(XX')/n of noise per evaluation;
+        # an "increase" inside that band is not one (archetypal_analysis.py:167-174 compares
+        # float64 costs, where the band is below every sensible tolerance)
+        mono_tol = tolerance
+        if ctx.dtype_code == _backend.AA_F32:
+            mono_tol = max(tolerance, 8 * 6e-8 * ctx.data_trace() / weights.shape[0])
         n_iter = -1
         done = False
         while not done and n_iter + 1 < max_iterations:
@@ -286,7 +293,8 @@ def _iterate_on_device(ctx, label, weights, dictionary, alpha, delta, update_wei
             start_time = time.perf_counter()
             costs, st = ctx.iterate(new_cost, chunk, tolerance, stop_name, require_monotonic,
                                     update_dictionary, update_weights, dictionary_solver_kwargs,
-                                    weights_solver_kwargs, check_every=_DEVICE_LOOP_BATCH)
+                                    weights_solver_kwargs, check_every=_DEVICE_LOOP_BATCH,
+                                    mono_tolerance=mono_tol)
             elapsed = time.perf_counter() - start_time
             ran = max(st.reserved, 1)
             per_iter = elapsed / ran

@@ -355,6 +355,8 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
         else qp_matvec<KQ>(AsT, vl, k, out);
     };
 
+    unsigned long long st_total = 0ull;
+    int st_max = 0;
     long long pc_proj = 0, pc_mv = 0, pc_refills = 0, pc_trips = 0, pc_step = 0, pc_fin = 0;
     long long pc_lane_rounds = 0, pc_lane_calls = 0, pc_wavemax = 0;
     const long long pc_start = PROF ? clock64() : 0;
@@ -522,8 +524,9 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                     if (FULL || i < k) Z[row * ldz + i] = x[i];
                 if (finished) {
                     if (iters) iters[row] = n_iter;
-                    atomicAdd(&hdr->total_passes, (unsigned long long)n_iter);
-                    atomicMax(&hdr->max_passes, (unsigned long long)n_iter);
+                    st_total += (unsigned long long)n_iter;      // one atomic pair per wave at exit:
+                    st_max = n_iter > st_max ? n_iter : st_max;   // 2 x 100 000 atomics on one cache
+                                                                  // line cost more than the QPs
                 } else {
                     // hand the sample to the low-latency wave-per-sample kernel
                     const unsigned int slot = atomicAdd(&hdr->n_overflow, 1u);
@@ -538,6 +541,20 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                 active = false;
             }
             QP_TOC(pc_fin, tf0);
+        }
+    }
+    {   // wave totals (fixed-order butterfly), one atomic pair per wave
+        unsigned long long tot = st_total;
+        int mx = st_max;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            tot += __shfl_xor(tot, o, 64);
+            const int om = __shfl_xor(mx, o, 64);
+            mx = om > mx ? om : mx;
+        }
+        if (threadIdx.x == 0 && tot) {
+            atomicAdd(&hdr->total_passes, tot);
+            atomicMax(&hdr->max_passes, (unsigned long long)mx);
         }
     }
     if constexpr (PROF) {
@@ -745,6 +762,8 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
     const unsigned int wave_id =
         (unsigned int)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const unsigned int n_waves = gridDim.x * 4;
+    unsigned long long wv_total = 0ull;      // pass statistics of this wave: one atomic pair at exit
+    int wv_max = 0;
     for (unsigned int slot = wave_id; slot < count; slot += n_waves) {
         const long row = fresh ? (long)slot : (long)ovf_rows[slot];
 
@@ -836,11 +855,13 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             if (zslot) zslot[(size_t)slot * KQ + comp] = x;     // deferred commit (launch_qp_tail_fixup)
             else Z[row * ldz + comp] = x;
         }
-        if (lane == 0) {
-            if (iters) iters[row] = n_iter;
-            atomicAdd(&hdr->total_passes, (unsigned long long)n_iter);
-            atomicMax(&hdr->max_passes, (unsigned long long)n_iter);
-        }
+        if (lane == 0 && iters) iters[row] = n_iter;
+        wv_total += (unsigned long long)n_iter;
+        wv_max = n_iter > wv_max ? n_iter : wv_max;
+    }
+    if (lane == 0 && wv_total) {
+        atomicAdd(&hdr->total_passes, wv_total);
+        atomicMax(&hdr->max_passes, (unsigned long long)wv_max);
     }
 }
 
@@ -1037,6 +1058,7 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
     int q_left = 0;
     unsigned int q_ahead = 0u;                     // ticket of the chunk whose atomic is in flight
     bool have_ahead = false, drained = false;      // wave-uniform
+    int s_next = 0;                                // static assignment: next position of this wave's list
 
     for (long trip = 0; trip < (1L << 26); ++trip) {       // watchdog bound only
         // a wave that carries a long-running sample stops pulling work (its remaining rows idle
@@ -1223,6 +1245,15 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
             const bool need = nxt < 0 && !drained;
             const unsigned long long nbm = __ballot(need && r == 0);
             if (nbm != 0ull) {
+                if (QR_CHUNK == 0) {
+                    // static assignment, no atomics at all: wave w owns the list positions
+                    // w, w + W, w + 2W, ... (W waves).  The list is in longest-first order, so
+                    // every wave gets the same mix of long and short samples (its first one from
+                    // the W longest, its second from the next W, ...), and the four rows of the
+                    // wave share that list dynamically.
+                    q_base = 0;
+                    q_left = 4;
+                } else
                 if (q_left == 0) {
                     if (have_ahead) {                       // the chunk requested a while ago
                         const long t0 = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)q_ahead);
@@ -1245,8 +1276,13 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
                     }
                 }
                 const int rank = __popcll(nbm & ((1ull << rowshift) - 1ull));
-                if (need && rank < q_left) {
-                    const long idx = q_base + rank;
+                long idx = q_base + rank;
+                bool take = need && rank < q_left;
+                if (QR_CHUNK == 0) {
+                    idx = (long)blockIdx.x + (long)(s_next + rank) * (long)gridDim.x;
+                    take = need && idx < n;
+                }
+                if (take) {
                     nxt = perm ? (long)perm[idx] : idx;
 #pragma unroll
                     for (int q = 0; q < CPL; ++q) {
@@ -1258,6 +1294,11 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
                 const int served = __popcll(nbm) < q_left ? __popcll(nbm) : q_left;
                 q_base += served;
                 q_left -= served;
+                if (QR_CHUNK == 0) {
+                    s_next += __popcll(nbm);
+                    q_left = 0;
+                    if ((long)blockIdx.x + (long)s_next * (long)gridDim.x >= n) drained = true;
+                }
             }
         }
         if (!__any(active || nxt >= 0) && (drained || (q_left == 0 && !have_ahead && hot_wave))) break;
@@ -1288,9 +1329,9 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
 // Passes a sample may spend in the lane-per-sample kernel before it is handed to the
 // wave-per-sample kernel.
 int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
-int g_qp_row_waves = 3072;     // most waves of the row kernel (k_qp_row): 3 per SIMD
+int g_qp_row_waves = 2048;     // most waves of the row kernel (k_qp_row): 2 per SIMD, all resident
 int g_qp_row_hot = 24;         // passes after which a sample's wave takes issue priority
-int g_qp_row_chunk = 4;        // queue tickets a wave takes per atomic
+int g_qp_row_chunk = 0;        // queue tickets a wave takes per atomic; 0: static strided assignment, no queue
 int g_qp_refill_min = 64;      // idle lanes of a wave that trigger a refill (1..64); 64 = only
                                // when the whole wave is idle: a sample's start-up (strided row
                                // loads, a cold projection) is executed by the whole wave, and

@@ -1763,8 +1763,8 @@ __global__ void k_set_scalars(double *__restrict__ sc, double trace, double fnor
 // iteration, read by the host once per batch.
 // costs[2*it], costs[2*it + 1]: cost after the dictionary / weights update of iteration `it`.
 __global__ void k_iter_judge(int it, double cost0, const double *__restrict__ costs,
-                             IterState *__restrict__ st, double tol, int criterion, int require,
-                             int upd_dict, int upd_w, const double *__restrict__ scal)
+                             IterState *__restrict__ st, double tol, double mono_tol, int criterion,
+                             int require, int upd_dict, int upd_w, const double *__restrict__ scal)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (st->stop) return;
@@ -1779,13 +1779,13 @@ __global__ void k_iter_judge(int it, double cost0, const double *__restrict__ co
     }
     // archetypal_analysis.py:167-174, evaluated after each update against the cost the
     // iteration started from
-    if (upd_dict && require && c1 > old && fabs(c1 - old) > tol) {
+    if (upd_dict && require && c1 > old && fabs(c1 - old) > mono_tol) {
         st->stop = 1;
         st->error_stage = 1;
         st->stop_iter = it;
         return;
     }
-    if (upd_w && require && c2 > old && fabs(c2 - old) > tol) {
+    if (upd_w && require && c2 > old && fabs(c2 - old) > mono_tol) {
         st->stop = 1;
         st->error_stage = 2;
         st->stop_iter = it;
@@ -1830,7 +1830,7 @@ int launch_iter_judge(Ctx *c, int it, double cost0, const double *costs, IterSta
                       const aa_iter_params *ip)
 {
     hipLaunchKernelGGL(k_iter_judge, dim3(1), dim3(64), 0, c->stream, it, cost0, costs, st, ip->tolerance,
-                       ip->criterion, ip->require_monotonic, ip->update_dictionary, ip->update_weights,
+                       ip->mono_tolerance, ip->criterion, ip->require_monotonic, ip->update_dictionary, ip->update_weights,
                        (const double *)c->scalars.as<double>());
     hipLaunchKernelGGL(k_iter_snapshot, dim3(512), dim3(256), 0, c->stream, it, (const IterState *)st,
                        (const double *)c->Ct.as<double>(), (const double *)c->Zt.as<double>(),

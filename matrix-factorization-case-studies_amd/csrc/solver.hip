@@ -470,7 +470,7 @@ int aa_set_option(const char *name, int value)
         AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_row_waves must be >= 1");
         g_qp_row_waves = value;
     } else if (!strcmp(name, "qp_row_chunk")) {
-        AA_REQUIRE(value >= 1 && value <= 4096, AA_ERR_ARG, "qp_row_chunk must be in 1..4096");
+        AA_REQUIRE(value >= 0 && value <= 4096, AA_ERR_ARG, "qp_row_chunk must be in 0..4096");
         g_qp_row_chunk = value;
     } else if (!strcmp(name, "qp_row_hot")) {
         AA_REQUIRE(value >= 0, AA_ERR_ARG, "qp_row_hot must be >= 0");
