@@ -244,6 +244,23 @@ typedef struct {
 int aa_iterate(aa_ctx *ctx, const aa_iter_params *it, const aa_spg_params *spg,
                const aa_qp_params *qp, double cost0, double *costs, aa_iter_stats *stats);
 
+/* The alternating loop of _iterate_gpnh_convex_coding (gpnh_convex_coding.py:282-402) on the
+ * device, same loop control as aa_iterate.  Per iteration: Z'X (reduce-over-rows GEMM), the
+ * regularised normal equations (Z'Z/n + lambda_W GW) W' = Z'X/n (:213-226) solved by a Cholesky
+ * factorisation in one small kernel (the reference calls lstsq on the same k x k system; when
+ * the factorisation meets a pivot below 1e-13 of the largest diagonal entry the call returns
+ * with stats->error_stage = 3 and the caller falls back to its host lstsq path), X W
+ * (row-local GEMM), W'W, the GPNH penalty (:179-196), the cost (:317-330) and the n per-sample
+ * QPs (:254-279).  Factors set with aa_gpnh_set_factors; the dictionary is read back with
+ * aa_gpnh_get_dictionary. */
+typedef struct {
+    double lambda_W;
+    aa_iter_params loop;
+} aa_gpnh_params;
+int aa_gpnh_iterate(aa_ctx *ctx, const aa_gpnh_params *params, const aa_qp_params *qp,
+                    double *cost0, double *costs, aa_iter_stats *stats);
+int aa_gpnh_get_dictionary(aa_ctx *ctx, double *Wt /* k x p, row-major */, long ld);
+
 /* n_outer full outer iterations (dictionary, weights) without returning to the
  * caller; costs[2*i], costs[2*i+1] = cost after the dictionary / weights update of
  * iteration i.  delta == 0 only (no scale-factor update).  Replaces the loop body

@@ -550,8 +550,9 @@ class ArchetypalAnalysis(_BaseAA):
         self._check_hyper_parameters()
         shape_only = _ShapeOnly(n_samples)
 
-        with _backend.Context(dtype=self.dtype) as ctx:
-            ctx.set_data(data, form=_backend.FORM_DATA)
+        # the data matrix stays on the device between fits of the same array (the drivers' n_init
+        # restarts, bin/run_hadisst_aa.py:158-172): only the start factors travel
+        with _backend.resident_context(data, form=_backend.FORM_DATA, dtype=self.dtype) as ctx:
 
             def init_dictionary():
                 init = 'furthest_sum' if self.init is None else self.init
@@ -603,20 +604,27 @@ class ArchetypalAnalysis(_BaseAA):
         return self.weights
 
     def transform(self, data):
-        """Weights of new samples for the fitted archetypes, and their cost
-        (reference :1151-1199)."""
-        data = np.asarray(data, dtype=np.float64)
+        """Weights of new samples for the fitted archetypes, and their cost (reference
+        :1151-1199): per-sample QPs with A = (CX)(CX)', b_t = -(CX) x_t from fresh random
+        starting weights, ``max_iterations`` SPG passes at most, then 0.5 ||X - W (CX)||_F^2 / n.
+        One context, one upload: X (CX)' is the row-local GEMM, the QPs and the residual norm run
+        on the resident data (csrc/solver.hip: aa_gpnh_set_factors / _weights_update /
+        _residual_cost, which are the "data times a k x p dictionary" entry points)."""
+        data = np.asarray(data)
+        if data.dtype != np.float32:
+            data = np.asarray(data, dtype=np.float64)
         n_samples = data.shape[0]
         kw = dict(self.weights_solver_kwargs)
         kw['max_iterations'] = self.max_iterations            # reference :1194
-        CKCt = self.archetypes.dot(self.archetypes.T)
-        CK = self.archetypes.dot(data.T)
+        archetypes = np.asarray(self.archetypes, dtype=np.float64)
+        CKCt = archetypes.dot(archetypes.T)                   # k x k
         initial_weights = right_stochastic_matrix((n_samples, self.n_components),
                                                   random_state=self.random_state)
-        self.weights = _backend.qp_batch(CKCt, CK, initial_weights, "kn", **kw)
-        with _backend.Context(dtype=np.float64) as ctx:
+        with _backend.Context(dtype=np.float64 if data.dtype == np.float64 else self.dtype) as ctx:
             ctx.set_data(data, form=_backend.FORM_DATA)
-            ctx.gpnh_set_factors(self.n_components, W=self.archetypes.T, Z=self.weights)
+            ctx.gpnh_set_factors(self.n_components, W=archetypes.T, Z=initial_weights)   # X (CX)'
+            ctx.gpnh_weights_update(CKCt, **kw)
+            self.weights = ctx.gpnh_get_weights()
             cost = ctx.gpnh_residual_cost()
         return self.weights, cost
 

@@ -128,6 +128,78 @@ def _iterate_on_device(ctx, n_features, weights, dictionary, lambda_W, update_we
 
     dictionary = np.asarray(dictionary, dtype=np.float64)
     ctx.gpnh_set_factors(n_components, W=dictionary, Z=weights)
+    if _DEVICE_LOOP:
+        out = _device_loop(ctx, weights.shape[0], lambda_W, update_weights, update_dictionary,
+                           tolerance, max_iterations, verbose, require_monotonic,
+                           kwargs.get('stopping_criterion', 'abs_delta_f'), weights_solver_kwargs)
+        if out is not None:
+            return out
+        ctx.gpnh_set_factors(n_components, W=dictionary, Z=weights)      # singular system: host path
+    return _host_loop(ctx, n_features, weights, dictionary, lambda_W, update_weights,
+                      update_dictionary, tolerance, max_iterations, verbose, require_monotonic,
+                      has_converged, weights_solver_kwargs)
+
+
+_DEVICE_LOOP = True
+_DEVICE_LOOP_BATCH = 8          # outer iterations between two host polls of the device loop
+
+
+def _device_loop(ctx, n_samples, lambda_W, update_weights, update_dictionary, tolerance,
+                 max_iterations, verbose, require_monotonic, stop_name, weights_solver_kwargs):
+    """The loop of reference :334-399 on the device (csrc/solver.hip: aa_gpnh_iterate): Z'X, the
+    k x k regularised normal equations (Cholesky), X W, W'W, the penalty, the cost, the QPs, the
+    monotonicity check and the stopping rule; the host reads one status record per batch of
+    iterations.  Returns None when the normal equations turn out not to be positive definite
+    (an unused component): the caller then runs the host loop with numpy.linalg.lstsq, the
+    reference's solver."""
+    mono_tol = tolerance
+    if ctx.dtype_code == _backend.AA_F32:
+        mono_tol = max(tolerance, 8 * 6e-8 * ctx.data_trace() / n_samples)
+    iter_times, cost_deltas = [], []
+    if verbose:
+        print("*** GPNH convex coding: n_components = {:d} ***".format(ctx.k))
+        print('{:<12s} | {:<13s} | {:<13s} | {:<12s}'.format('Iteration', 'Cost', 'Cost delta', 'Time'))
+        print(100 * '-')
+    n_iter, new_cost, done = -1, None, False
+    while not done and n_iter + 1 < max_iterations:
+        budget = max_iterations - (n_iter + 1)
+        chunk = min(budget, _DEVICE_LOOP_BATCH) if verbose else budget
+        start_time = time.perf_counter()
+        cost0, costs, st = ctx.gpnh_iterate(lambda_W, chunk, tolerance, stop_name, require_monotonic,
+                                            update_dictionary, update_weights, weights_solver_kwargs,
+                                            check_every=_DEVICE_LOOP_BATCH, mono_tolerance=mono_tol)
+        elapsed = time.perf_counter() - start_time
+        if st.error_stage == 3:
+            return None
+        if st.error_stage:
+            raise RuntimeError('factorization cost increased after {} update'.format(
+                'dictionary' if st.error_stage == 1 else 'weights'))
+        per_iter = elapsed / max(st.reserved, 1)
+        starts = np.concatenate(([cost0], costs[1::2][:-1]))
+        finals = costs[1::2]
+        for j in range(st.n_iter + 1):
+            iter_times.append(per_iter)
+            cost_deltas.append(finals[j] - starts[j])
+            if verbose:
+                print('{:12d} | {: 12.6e} | {: 12.6e} | {: 12.6e}'.format(
+                    n_iter + 2 + j, finals[j], finals[j] - starts[j], per_iter))
+        n_iter += st.n_iter + 1
+        new_cost = st.cost
+        if st.converged:
+            if verbose:
+                print('*** Converged at iteration {:d} ***'.format(n_iter + 1))
+            done = True
+    weights = ctx.gpnh_get_weights()
+    dictionary = ctx.gpnh_get_dictionary()
+    return (weights, dictionary, new_cost, n_iter, np.mean(iter_times), cost_deltas)
+
+
+def _host_loop(ctx, n_features, weights, dictionary, lambda_W, update_weights, update_dictionary,
+               tolerance, max_iterations, verbose, require_monotonic, has_converged,
+               weights_solver_kwargs):
+    """One update at a time from the host, the dictionary solved with numpy.linalg.lstsq exactly
+    as the reference does (:213-226): the fallback for rank-deficient normal equations."""
+    n_samples, n_components = weights.shape
     GW = _gpnh_matrix(n_features, n_components)
     trace_XtX = ctx.data_trace()
     _, ZtZ, trace_WtXtZ = ctx.gpnh_reduce(want_ztx=False)
@@ -283,8 +355,8 @@ class GPNHConvexCoding(object):
                              'positive; got (tolerance=%r)' % self.tolerance)
         k = self.n_components
         whom = '_gpnh_convex_coding'
-        with _backend.Context(dtype=self.dtype) as ctx:
-            ctx.set_data(data)
+        # data resident across the drivers' n_init restarts (bin/run_jra55_pca_gpnh.py:123-136)
+        with _backend.resident_context(data, dtype=self.dtype) as ctx:
             if self.init == 'custom':
                 _check_init_weights(weights, (n_samples, k), whom + ' (input weights)')
                 _check_init_dictionary(dictionary, (n_features, k), whom + ' (input dictionary)')

@@ -238,9 +238,14 @@ int launch_dict_setup(Ctx *c, const aa_spg_params *sp, double fnorm);
 int launch_iter_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
                       const aa_iter_params *ip);
 int launch_cost_carry(Ctx *c, double *costs, int *slot, double cost0);
+int launch_gpnh_solve(Ctx *c, double lambda, int *ok_dev);
+int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter);
+int launch_gpnh_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
+                      const aa_iter_params *ip);
 enum { ST_INIT_F = 0, ST_ALPHA = 1, ST_LINESEARCH = 2, ST_BB = 3, ST_CONV = 4 };
 int launch_row_sqnorm_sum(Ctx *c, double *trace_out_host);
 int launch_distance_column(Ctx *c, long j_local, int owner_has_row, const double *xj_host, double *d_host);
+int launch_row_broadcast(Ctx *c, long j_local, bool own);   // multi-rank: row j -> wideScratch on every rank
 int launch_residual_cost(Ctx *c, const double *Ztall, const double *Wwide, const double *alpha_dev,
                          double *out_host);
 

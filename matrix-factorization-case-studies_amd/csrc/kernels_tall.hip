@@ -1764,13 +1764,14 @@ __global__ void k_set_scalars(double *__restrict__ sc, double trace, double fnor
 // costs[2*it], costs[2*it + 1]: cost after the dictionary / weights update of iteration `it`.
 __global__ void k_iter_judge(int it, double cost0, const double *__restrict__ costs,
                              IterState *__restrict__ st, double tol, double mono_tol, int criterion,
-                             int require, int upd_dict, int upd_w, const double *__restrict__ scal)
+                             int require, int upd_dict, int upd_w, const double *__restrict__ scal,
+                             int track_spg)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (st->stop) return;
     const double old = it == 0 ? cost0 : costs[2 * it - 1];
     const double c1 = costs[2 * it], c2 = costs[2 * it + 1];
-    if (upd_dict) {
+    if (upd_dict && track_spg) {
         // the SPG loop ends converged, at the function-evaluation cap, or at the iteration cap
         // (the warning of spg.py:278-281)
         int fl = (int)scal[SC_FLAGS];
@@ -1831,7 +1832,7 @@ int launch_iter_judge(Ctx *c, int it, double cost0, const double *costs, IterSta
 {
     hipLaunchKernelGGL(k_iter_judge, dim3(1), dim3(64), 0, c->stream, it, cost0, costs, st, ip->tolerance,
                        ip->mono_tolerance, ip->criterion, ip->require_monotonic, ip->update_dictionary, ip->update_weights,
-                       (const double *)c->scalars.as<double>());
+                       (const double *)c->scalars.as<double>(), 1);
     hipLaunchKernelGGL(k_iter_snapshot, dim3(512), dim3(256), 0, c->stream, it, (const IterState *)st,
                        (const double *)c->Ct.as<double>(), (const double *)c->Zt.as<double>(),
                        c->snapC.as<double>(), c->snapZ.as<double>(), (long)c->n_pad * c->KP);
@@ -1842,6 +1843,154 @@ int launch_iter_judge(Ctx *c, int it, double cost0, const double *costs, IterSta
 int launch_cost_carry(Ctx *c, double *costs, int *slot, double cost0)
 {
     hipLaunchKernelGGL(k_cost_carry, dim3(1), dim3(64), 0, c->stream, costs, slot, cost0);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+// ---------------------------------------------------------------- GPNH dictionary update
+// (Z'Z/n + lambda GW) W' = Z'X/n  (gpnh_convex_coding.py:213-226, GW of :296-300): every block
+// factorises the k x k system (Cholesky, in LDS) and solves it for its own 256 columns of the
+// right-hand side, one column per thread.  ok[0] = 1 when a pivot is not safely positive.
+__global__ __launch_bounds__(256) void k_gpnh_solve(const double *__restrict__ ZtZ /*[KP][KP]*/,
+                                                    const double *__restrict__ ZtX /*[KP][ld]*/,
+                                                    int ld, int p, int k, int KP, double n_samples,
+                                                    double lambda, double *__restrict__ Wt,
+                                                    float *__restrict__ WtF, int *__restrict__ ok)
+{
+    extern __shared__ double L[];                 // k x k, row-major, lower triangle
+    __shared__ double dmax_s;
+    __shared__ int bad;
+    const int t = threadIdx.x;
+    const double pref = k > 1 ? 4.0 / ((double)p * k * (k - 1)) : 0.0;
+    for (int e = t; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        L[e] = ZtZ[i * KP + j] / n_samples + lambda * pref * ((i == j ? (double)k : 0.0) - 1.0);
+    }
+    if (t == 0) bad = 0;
+    __syncthreads();
+    if (t == 0) {
+        double m = 0.0;
+        for (int i = 0; i < k; ++i) m = fmax(m, fabs(L[i * k + i]));
+        dmax_s = m;
+    }
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {                 // right-looking Cholesky
+        if (t == 0) {
+            const double d = L[j * k + j];
+            if (!(d > 1e-13 * dmax_s)) bad = 1;
+            L[j * k + j] = sqrt(d > 0.0 ? d : 1.0);
+        }
+        __syncthreads();
+        const double piv = L[j * k + j];
+        for (int i = j + 1 + t; i < k; i += 256) L[i * k + j] /= piv;
+        __syncthreads();
+        for (int e = t; e < (k - j - 1) * (k - j - 1); e += 256) {
+            const int i = j + 1 + e / (k - j - 1), q = j + 1 + e % (k - j - 1);
+            if (q <= i) L[i * k + q] -= L[i * k + j] * L[q * k + j];
+        }
+        __syncthreads();
+    }
+    if (bad) {
+        if (t == 0 && blockIdx.x == 0) ok[0] = 1;     // flag: not positive definite
+        return;
+    }
+    const int c = blockIdx.x * 256 + t;
+    if (c >= ld) return;
+    double y[AA_MAX_K];
+    for (int i = 0; i < k; ++i) {                 // L y = b
+        double v = c < p ? ZtX[(long)i * ld + c] / n_samples : 0.0;
+        for (int q = 0; q < i; ++q) v -= L[i * k + q] * y[q];
+        y[i] = v / L[i * k + i];
+    }
+    for (int i = k - 1; i >= 0; --i) {            // L' w = y
+        double v = y[i];
+        for (int q = i + 1; q < k; ++q) v -= L[q * k + i] * y[q];
+        y[i] = v / L[i * k + i];
+    }
+    for (int i = 0; i < KP; ++i) {
+        const double v = i < k ? y[i] : 0.0;
+        Wt[(long)i * ld + c] = v;
+        if (WtF) WtF[(long)i * ld + c] = (float)v;
+    }
+}
+
+// cost of gpnh_convex_coding.py:317-330 from the device-side pieces: tr(W'X'Z) in scal[slot],
+// Z'Z and W'W (KP x KP), the GPNH penalty (:179-196) from the Gram of the dictionary
+//   phi(W) = 2 / (k p (k - 1)) sum_{i<j} ||w_i - w_j||^2,  ||w_i - w_j||^2 = G_ii + G_jj - 2 G_ij
+__global__ __launch_bounds__(256) void k_gpnh_cost(const double *__restrict__ ZtZ,
+                                                   const double *__restrict__ WtW,
+                                                   const double *__restrict__ scal, int slot, int k,
+                                                   int KP, int p, double trace, double n_samples,
+                                                   double lambda, double *__restrict__ out,
+                                                   int *__restrict__ slot_counter)
+{
+    __shared__ double sm[256], sm2[256];
+    const int t = threadIdx.x;
+    double quad = 0.0, pen = 0.0;
+    for (int e = t; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        quad += ZtZ[i * KP + j] * WtW[j * KP + i];
+        if (j > i) pen += WtW[i * KP + i] + WtW[j * KP + j] - 2.0 * WtW[i * KP + j];
+    }
+    sm[t] = quad;
+    sm2[t] = pen;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            sm[t] += sm[t + o];
+            sm2[t] += sm2[t + o];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        double penalty = 0.0;
+        if (lambda != 0.0 && k > 1) penalty = lambda * (2.0 / ((double)k * p * (k - 1.0))) * sm2[0];
+        const int idx = slot_counter ? (*slot_counter)++ : 0;
+        out[idx] = 0.5 * (trace - 2.0 * scal[slot] + sm[0]) / n_samples + penalty;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_copy2(const IterState *__restrict__ st, int it,
+                                               const double *__restrict__ a, double *__restrict__ sa,
+                                               long na, const double *__restrict__ b,
+                                               double *__restrict__ sb, long nb)
+{
+    if (st && (!st->stop || st->stop_iter != it)) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < na; i += (long)gridDim.x * 256) sa[i] = a[i];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long)gridDim.x * 256) sb[i] = b[i];
+}
+
+int launch_gpnh_solve(Ctx *c, double lambda, int *ok_dev)
+{
+    const size_t lds = (size_t)c->k * c->k * sizeof(double);
+    hipLaunchKernelGGL(k_gpnh_solve, dim3((unsigned)((c->p_pad + 255) / 256)), dim3(256), lds, c->stream,
+                       (const double *)c->gramState.as<double>(), (const double *)c->ZtX.as<double>(),
+                       (int)c->p_pad, (int)c->p, c->k, c->KP, (double)c->n_global, lambda, c->P.as<double>(),
+                       c->dtype == AA_F32 ? c->Pw.as<float>() : (float *)nullptr, ok_dev);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter)
+{
+    const double *gs = c->gramState.as<double>();
+    hipLaunchKernelGGL(k_gpnh_cost, dim3(1), dim3(256), 0, c->stream, gs, gs + (size_t)c->KP * c->KP,
+                       (const double *)c->scalars.as<double>(), (int)SC_S1, c->k, c->KP, (int)c->p, c->trace,
+                       (double)c->n_global, lambda, out_dev, slot_counter);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+// GPNH flavour of launch_iter_judge: the snapshot keeps Z and the dictionary (W', wide)
+int launch_gpnh_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
+                      const aa_iter_params *ip)
+{
+    hipLaunchKernelGGL(k_iter_judge, dim3(1), dim3(64), 0, c->stream, it, cost0, costs, st, ip->tolerance,
+                       ip->mono_tolerance, ip->criterion, ip->require_monotonic, ip->update_dictionary,
+                       ip->update_weights, (const double *)c->scalars.as<double>(), 0 /* no SPG behind it */);
+    hipLaunchKernelGGL(k_copy2, dim3(256), dim3(256), 0, c->stream, (const IterState *)st, it,
+                       (const double *)c->Zt.as<double>(), c->snapZ.as<double>(), (long)c->n_pad * c->KP,
+                       (const double *)c->P.as<double>(), c->snapC.as<double>(), (long)c->KP * c->p_pad);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
@@ -2007,6 +2156,48 @@ int launch_row_sqnorm_sum(Ctx *c, double *trace_out_host)
     if ((c->world > 1 || c->force_comm)) AA_CHECK(comm_allreduce(c, out, 1, 0));
     AA_CHECK_HIP(hipMemcpyAsync(trace_out_host, out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return AA_OK;
+}
+
+// multi-rank FurthestSum: the owner of global row j publishes it to every rank WITHOUT leaving
+// the device: every rank fills a float64 buffer (the owner with its row, the others with zeros),
+// one sum all-reduce (x + 0 + ... + 0 is exact), and the result is converted back to the data
+// type in wideScratch, where k_distance_data expects x_j.
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_publish(const T *__restrict__ row, int own, long p_pad,
+                                                     double *__restrict__ out)
+{
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q < p_pad) out[q] = own ? (double)row[q] : 0.0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_collect(const double *__restrict__ in, long p_pad,
+                                                     T *__restrict__ out)
+{
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q < p_pad) out[q] = (T)in[q];
+}
+
+int launch_row_broadcast(Ctx *c, long j_local, bool own)
+{
+    // staging: the float64 buffer lives in the second half of wideScratch (>= 32 * p_pad doubles)
+    double *stage = c->wideScratch.as<double>() + (size_t)16 * c->p_pad;
+    const dim3 grid((unsigned)((c->p_pad + 255) / 256));
+    const long off = own ? j_local * c->p_pad : 0;
+    if (c->dtype == AA_F32)
+        hipLaunchKernelGGL(k_row_publish<float>, grid, dim3(256), 0, c->stream, c->X.as<float>() + off,
+                           own ? 1 : 0, c->p_pad, stage);
+    else
+        hipLaunchKernelGGL(k_row_publish<double>, grid, dim3(256), 0, c->stream, c->X.as<double>() + off,
+                           own ? 1 : 0, c->p_pad, stage);
+    AA_CHECK(comm_allreduce(c, stage, c->p_pad, 0));
+    if (c->dtype == AA_F32)
+        hipLaunchKernelGGL(k_row_collect<float>, grid, dim3(256), 0, c->stream, (const double *)stage, c->p_pad,
+                           c->wideScratch.as<float>());
+    else
+        hipLaunchKernelGGL(k_row_collect<double>, grid, dim3(256), 0, c->stream, (const double *)stage,
+                           c->p_pad, c->wideScratch.as<double>());
+    AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
 

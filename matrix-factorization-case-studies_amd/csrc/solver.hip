@@ -939,30 +939,9 @@ int aa_distance_column(aa_ctx *h, long j, double *d)
                                         reinterpret_cast<unsigned char *>(c->X.p) + (size_t)jl * c->p_pad * es,
                                         (size_t)c->p_pad * es, hipMemcpyDeviceToDevice, c->stream));
         } else {
-            // owner publishes the row through a sum all-reduce of a zero-filled buffer
-            std::vector<double> row(c->p_pad, 0.0);
-            if (own) {
-                std::vector<unsigned char> raw((size_t)c->p_pad * es);
-                AA_CHECK_HIP(hipMemcpy(raw.data(),
-                                       reinterpret_cast<unsigned char *>(c->X.p) + (size_t)jl * c->p_pad * es,
-                                       raw.size(), hipMemcpyDeviceToHost));
-                for (long q = 0; q < c->p_pad; ++q)
-                    row[q] = c->dtype == AA_F32 ? (double)reinterpret_cast<float *>(raw.data())[q]
-                                                : reinterpret_cast<double *>(raw.data())[q];
-            }
-            DevBuf tmp;
-            AA_CHECK(tmp.alloc(row.size() * sizeof(double)));
-            AA_CHECK_HIP(hipMemcpy(tmp.p, row.data(), row.size() * sizeof(double), hipMemcpyHostToDevice));
-            AA_CHECK(comm_allreduce(c, tmp.as<double>(), (long)row.size(), 0));
-            AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-            AA_CHECK_HIP(hipMemcpy(row.data(), tmp.p, row.size() * sizeof(double), hipMemcpyDeviceToHost));
-            tmp.release();
-            if (c->dtype == AA_F32) {
-                std::vector<float> rf(row.begin(), row.end());
-                AA_CHECK_HIP(hipMemcpy(c->wideScratch.p, rf.data(), rf.size() * sizeof(float), hipMemcpyHostToDevice));
-            } else {
-                AA_CHECK_HIP(hipMemcpy(c->wideScratch.p, row.data(), row.size() * sizeof(double), hipMemcpyHostToDevice));
-            }
+            // the owner publishes the row through a sum all-reduce of zero-filled buffers, all
+            // on the device (no host staging)
+            AA_CHECK(launch_row_broadcast(c, jl, own));
         }
         return launch_distance_column(c, jl, own ? 1 : 0, nullptr, d);
     }
@@ -1039,6 +1018,121 @@ int aa_gpnh_weights_update(aa_ctx *h, const double *WtW, const aa_qp_params *par
     AA_CHECK_HIP(hipSetDevice(c->device));
     return launch_qp(c, WtW, c->Gr.as<double>(), 1, c->KP, nullptr, c->Zt.as<double>(), c->KP, c->n, c->k,
                      params, nullptr, stats);
+}
+
+int aa_gpnh_get_dictionary(aa_ctx *h, double *Wt, long ld)
+{
+    AA_REQUIRE(h && Wt, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->gpnh_valid, AA_ERR_STATE, "no dictionary");
+    AA_REQUIRE(ld >= c->p, AA_ERR_ARG, "ld < p");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    AA_CHECK_HIP(hipMemcpy2D(Wt, (size_t)ld * sizeof(double), c->P.p, (size_t)c->p_pad * sizeof(double),
+                             (size_t)c->p * sizeof(double), (size_t)c->k, hipMemcpyDeviceToHost));
+    return AA_OK;
+}
+
+int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp, double *cost0_out,
+                    double *costs, aa_iter_stats *stats)
+{
+    AA_REQUIRE(h && gp && qp && costs && stats, AA_ERR_ARG, "null argument");
+    const aa_iter_params *ip = &gp->loop;
+    AA_REQUIRE(ip->max_outer >= 1 && ip->check_every >= 1, AA_ERR_ARG, "bad iteration counts");
+    AA_REQUIRE(ip->criterion == 0 || ip->criterion == 1, AA_ERR_ARG, "bad stopping criterion");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->have_state && c->gpnh_valid && c->form == AA_FORM_DATA, AA_ERR_STATE,
+               "aa_gpnh_iterate needs aa_gpnh_set_factors (dictionary and weights) first");
+    const int n_max = ip->max_outer, KP = c->KP;
+    const double lambda = gp->lambda_W;
+    size_t snap_bytes = (size_t)c->n_pad * KP * sizeof(double);
+    if ((size_t)KP * c->p_pad * sizeof(double) > snap_bytes) snap_bytes = (size_t)KP * c->p_pad * sizeof(double);
+    AA_CHECK(c->costDev.alloc((size_t)(2 * n_max + 64) * sizeof(double)));
+    AA_CHECK(c->costSlot.alloc(64));
+    AA_CHECK(c->iterState.alloc(sizeof(IterState)));
+    AA_CHECK(c->snapC.alloc(snap_bytes));
+    AA_CHECK(c->snapZ.alloc(snap_bytes));
+    AA_CHECK(c->qpIters.alloc((size_t)c->n * sizeof(int)));
+    AA_CHECK(ensure_trace(c));
+    for (int i = 0; i < c->k; ++i) c->alpha[i] = 1.0;            // the QP set-up scales by alpha
+    AA_CHECK(upload_alpha(c));
+    int *slot = c->costSlot.as<int>();
+    double *cd = c->costDev.as<double>();
+    IterState *st = c->iterState.as<IterState>();
+    AA_CHECK_HIP(hipMemsetAsync(slot, 0, sizeof(int), c->stream));
+    AA_CHECK_HIP(hipMemsetAsync(st, 0, sizeof(IterState), c->stream));
+    // Gram state: [0] = Z'Z, [1] = W'W; scal[SC_S1] = tr(W'X'Z) = <XW, Z>
+    AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
+    AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), dev_CKCt(c)));
+    AA_CHECK(launch_tall_dot_scaled(c, c->Gr.as<double>(), c->Zt.as<double>(), nullptr, SC_S1));
+    AA_CHECK(launch_gpnh_cost(c, lambda, cd + 2 * n_max + 8, nullptr));
+    double cost0 = 0.0;
+    AA_CHECK_HIP(hipMemcpyAsync(&cost0, cd + 2 * n_max + 8, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (cost0_out) *cost0_out = cost0;
+    c->grams_valid = false;          // the Gram state now holds GPNH products, not AA ones
+    c->ckz_valid = false;
+    c->host_grams_valid = false;
+
+    IterState hs;
+    memset(&hs, 0, sizeof(hs));
+    int done = 0;
+    while (done < n_max) {
+        const int batch = n_max - done < ip->check_every ? n_max - done : ip->check_every;
+        for (int b = 0; b < batch; ++b) {
+            if (ip->update_dictionary) {
+                AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), nullptr));
+                AA_CHECK(launch_gpnh_solve(c, lambda, &st->pad0));                      // W'
+                AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));   // X W
+                AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), dev_CKCt(c)));
+                AA_CHECK(launch_tall_dot_scaled(c, c->Gr.as<double>(), c->Zt.as<double>(), nullptr, SC_S1));
+                AA_CHECK(launch_gpnh_cost(c, lambda, cd, slot));
+            } else {
+                AA_CHECK(launch_cost_carry(c, cd, slot, cost0));
+            }
+            if (ip->update_weights) {
+                AA_CHECK(launch_qp(c, nullptr, c->Gr.as<double>(), 1, KP, nullptr, c->Zt.as<double>(), KP, c->n,
+                                   c->k, qp, c->qpIters.as<int>(), nullptr, dev_CKCt(c)));
+                c->qp_iters_valid = true;
+                AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
+                AA_CHECK(launch_tall_dot_scaled(c, c->Gr.as<double>(), c->Zt.as<double>(), nullptr, SC_S1));
+                AA_CHECK(launch_gpnh_cost(c, lambda, cd, slot));
+            } else {
+                AA_CHECK(launch_cost_carry(c, cd, slot, cost0));
+            }
+            AA_CHECK(launch_gpnh_judge(c, done + b, cost0, cd, st, ip));
+        }
+        done += batch;
+        AA_CHECK_HIP(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+        AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+        if (hs.stop || hs.pad0) break;
+    }
+    memset(stats, 0, sizeof(*stats));
+    stats->reserved = done;
+    if (hs.pad0) {                    // the normal equations were not positive definite
+        stats->error_stage = 3;
+        stats->n_iter = -1;
+        stats->cost = cost0;
+        return AA_OK;
+    }
+    const int last = hs.stop ? hs.stop_iter : n_max - 1;
+    AA_CHECK_HIP(hipMemcpy(costs, cd, (size_t)2 * (last + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    stats->n_iter = last;
+    stats->converged = hs.converged;
+    stats->error_stage = hs.error_stage;
+    stats->error_iter = hs.error_stage ? hs.stop_iter : -1;
+    stats->cost = costs[2 * last + 1];
+    if (hs.stop && hs.stop_iter < done - 1 && !hs.error_stage) {
+        // iterations behind the stopping one have run: restore its factors, rebuild X W
+        AA_CHECK_HIP(hipMemcpy(c->Zt.p, c->snapZ.p, (size_t)c->n_pad * KP * sizeof(double), hipMemcpyDeviceToDevice));
+        AA_CHECK_HIP(hipMemcpy(c->P.p, c->snapC.p, (size_t)KP * c->p_pad * sizeof(double), hipMemcpyDeviceToDevice));
+        AA_CHECK(launch_wide_to_T(c, c->P.as<double>(), operandT(c, c->P, c->Pw)));
+        AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));
+        c->qp_iters_valid = false;
+        AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    }
+    return AA_OK;
 }
 
 int aa_gpnh_residual_cost(aa_ctx *h, double *cost)
