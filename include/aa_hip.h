@@ -128,9 +128,20 @@ int aa_device_count(int *count);
  *                               lane-per-sample kernel followed by the wave-per-sample kernel
  *                               for the stragglers (round-1 default above 16384 samples);
  *                               3: the row kernel (wave-per-sample above k = 32)
- *   "qp_row_waves"      >= 1   most waves the row kernel runs with (default 3072: 3 per SIMD)
+ *   "qp_row_waves"      >= 1   most waves the row kernel runs with (default 2048: 2 per SIMD)
  *   "qp_row_hot"        >= 0   SPG passes after which the wave of a sample raises its issue
- *                               priority (also when the previous update needed twice as many) */
+ *                               priority (also when the previous update needed twice as many)
+ *   "qp_row_chunk"      0..4096 0 (default): the row kernel's waves own fixed, interleaved slices of
+ *                               the longest-first sample list (no queue); > 0: a global queue,
+ *                               this many tickets per atomic
+ *   "qp_row_long"       0..63  samples that needed at least this many passes in the previous
+ *                               update are solved by the wave-per-sample kernel on a side stream,
+ *                               concurrently with the row kernel (default 32; 0: no side stream)
+ *   "qp_row_cap"        >= 1   passes after which the row kernel hands a sample to the
+ *                               wave-per-sample kernel (default 48)
+ *   "fuse_finalize"     0|1    1 (default): fewer, fatter launches in the dictionary update (set-up
+ *                               kernel, scalar stages inside the finalize kernels, two-launch line
+ *                               search, x update inside the gradient kernel) */
 int aa_set_option(const char *name, int value);
 
 /* -------------------------------------------- stateless ops (unit-test surface) */

@@ -281,6 +281,8 @@ extern int g_qp_mode;             // kernels_qp.hip
 extern int g_qp_row_waves;        // kernels_qp.hip
 extern int g_qp_row_hot;          // kernels_qp.hip
 extern int g_qp_row_chunk;        // kernels_qp.hip
+extern int g_qp_row_long;         // kernels_qp.hip
+extern int g_qp_row_cap;          // kernels_qp.hip
 extern int g_qp_refill_min;       // kernels_qp.hip
 extern int g_qp_waves;            // kernels_qp.hip
 extern int g_qp_sort;             // kernels_qp.hip

@@ -110,7 +110,9 @@ struct QpHeader {
     unsigned int next_row;        // phase-1 work counter
     unsigned int n_overflow;      // samples handed to phase 2
     unsigned int next_overflow;   // phase-2 work counter
-    unsigned int pad;
+    unsigned int n_long;          // hybrid row/wave update: head of the sorted list that the
+                                  // wave-per-sample kernel takes (predicted-long samples)
+    unsigned int dbg_rounds, dbg_trips, dbg_waves, pad;   // qp_profile counters of the row kernel
 };
 
 __device__ __forceinline__ int qp_debug_wave_max(int v)   // maximum of v over the active lanes
@@ -736,7 +738,8 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
                                                  QpHeader *__restrict__ hdr,
                                                  const int *__restrict__ ovf_rows,
                                                  const QpCarry *__restrict__ ovf,
-                                                 double *__restrict__ zslot /*[slot][KQ] or null*/)
+                                                 double *__restrict__ zslot /*[slot][KQ] or null*/,
+                                                 const int *__restrict__ fresh_list = nullptr)
 {
     constexpr bool HALF = KQ == 32;
     // latency-bound waves: take issue priority over the bandwidth-bound GEMM waves they may
@@ -756,8 +759,9 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
     };
     const int mem = p.memory < 1 ? 1 : (p.memory > QP_MAXMEM ? QP_MAXMEM : p.memory);
     // n_fresh >= 0: process rows [0, n_fresh) from scratch; otherwise the overflow list
-    const bool fresh = n_fresh >= 0;
-    const unsigned int count = fresh ? (unsigned int)n_fresh : hdr->n_overflow;
+    // fresh_list: the first hdr->n_long entries of the sorted sample list, from scratch
+    const bool fresh = n_fresh >= 0 || fresh_list != nullptr;
+    const unsigned int count = fresh_list ? hdr->n_long : (fresh ? (unsigned int)n_fresh : hdr->n_overflow);
 
     const unsigned int wave_id =
         (unsigned int)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -765,7 +769,7 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
     unsigned long long wv_total = 0ull;      // pass statistics of this wave: one atomic pair at exit
     int wv_max = 0;
     for (unsigned int slot = wave_id; slot < count; slot += n_waves) {
-        const long row = fresh ? (long)slot : (long)ovf_rows[slot];
+        const long row = fresh_list ? (long)fresh_list[slot] : (fresh ? (long)slot : (long)ovf_rows[slot]);
 
         double x = live ? Z[row * ldz + comp] : 0.0;
         const double b = live ? -B[comp * stride_j + row * stride_t] * (bscale ? bscale[comp] : 1.0) : 0.0;
@@ -1009,9 +1013,15 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
                                                double *__restrict__ Z, int ldz, long n, int k,
                                                aa_qp_params p, int *__restrict__ iters,
                                                QpHeader *__restrict__ hdr,
-                                               const int *__restrict__ perm, int hot_passes, int prof, int QR_CHUNK)
+                                               const int *__restrict__ perm, int hot_passes, int prof, int QR_CHUNK,
+                                               int pass_cap, int *__restrict__ ovf_rows,
+                                               QpCarry *__restrict__ ovf)
 {
     constexpr int KQ = 16 * CPL;
+    // hybrid update: the first n_long samples of the sorted list (predicted long) are being
+    // solved by the wave-per-sample kernel on the side stream; this kernel takes the rest
+    const long list0 = perm ? (long)hdr->n_long : 0;
+    const long nq = n - list0;                     // entries of the list this kernel works off
     __shared__ __attribute__((aligned(16))) double vb[4][KQ];
     const int lane = threadIdx.x, r = lane & 15, rowid = lane >> 4, rowshift = lane & 48;
     const int comp0 = r * CPL;                     // this lane owns components comp0 .. comp0 + CPL - 1
@@ -1229,13 +1239,27 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
             const bool rinf_small = !qr_any(big, rowshift);
             n_iter += 1;
             const bool conv = (sqrt(r2) < p.epsilon_two) || rinf_small;
-            if (conv || n_feval > p.max_feval || n_iter >= p.max_iterations) {
+            const bool finished = conv || n_feval > p.max_feval || n_iter >= p.max_iterations;
+            if (finished || n_iter >= pass_cap) {
 #pragma unroll
                 for (int q = 0; q < CPL; ++q)
                     if (live[q]) Z[row * ldz + comp0 + q] = x[q];
-                if (r == 0 && iters) iters[row] = n_iter;
-                st_total += (unsigned long long)n_iter;
-                st_max = n_iter > st_max ? n_iter : st_max;
+                if (finished) {
+                    if (r == 0 && iters) iters[row] = n_iter;
+                    st_total += (unsigned long long)n_iter;
+                    st_max = n_iter > st_max ? n_iter : st_max;
+                } else if (r == 0) {
+                    // an unexpectedly long sample: hand it, with its SPG state, to the
+                    // wave-per-sample kernel (1 us per pass instead of ~3)
+                    const unsigned int slot = atomicAdd(&hdr->n_overflow, 1u);
+                    ovf_rows[slot] = (int)row;
+                    QpCarry cr;
+                    cr.alpha = alpha;
+                    cr.f = f;
+                    cr.n_iter = n_iter;
+                    cr.n_feval = n_feval;
+                    ovf[slot] = cr;
+                }
                 active = false;
             }
         }
@@ -1259,7 +1283,7 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
                         const long t0 = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)q_ahead);
                         have_ahead = false;
                         q_base = t0;
-                        q_left = t0 >= n ? 0 : (n - t0 < QR_CHUNK ? (int)(n - t0) : QR_CHUNK);
+                        q_left = t0 >= nq ? 0 : (nq - t0 < QR_CHUNK ? (int)(nq - t0) : QR_CHUNK);
                         if (q_left == 0) drained = true;
                     }
                     if (q_left == 0 && !drained && !hot_wave) {   // first trip (or after a hot phase)
@@ -1267,7 +1291,7 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
                         if (lane == 0) t1 = atomicAdd(&hdr->next_row, (unsigned int)QR_CHUNK);
                         const long t0 = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)t1);
                         q_base = t0;
-                        q_left = t0 >= n ? 0 : (n - t0 < QR_CHUNK ? (int)(n - t0) : QR_CHUNK);
+                        q_left = t0 >= nq ? 0 : (nq - t0 < QR_CHUNK ? (int)(nq - t0) : QR_CHUNK);
                         if (q_left == 0) drained = true;
                     }
                     if (q_left > 0 && !hot_wave) {          // request the chunk after this one
@@ -1276,10 +1300,10 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
                     }
                 }
                 const int rank = __popcll(nbm & ((1ull << rowshift) - 1ull));
-                long idx = q_base + rank;
+                long idx = list0 + q_base + rank;
                 bool take = need && rank < q_left;
                 if (QR_CHUNK == 0) {
-                    idx = (long)blockIdx.x + (long)(s_next + rank) * (long)gridDim.x;
+                    idx = list0 + (long)blockIdx.x + (long)(s_next + rank) * (long)gridDim.x;
                     take = need && idx < n;
                 }
                 if (take) {
@@ -1297,7 +1321,7 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
                 if (QR_CHUNK == 0) {
                     s_next += __popcll(nbm);
                     q_left = 0;
-                    if ((long)blockIdx.x + (long)s_next * (long)gridDim.x >= n) drained = true;
+                    if (list0 + (long)blockIdx.x + (long)s_next * (long)gridDim.x >= n) drained = true;
                 }
             }
         }
@@ -1320,9 +1344,9 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
         }
     }
     if (prof && r == 0) {                          // per row: Michelot rounds, trips of its wave
-        atomicAdd(&hdr->n_overflow, dbg_rounds);
-        if (lane == 0) atomicAdd(&hdr->next_overflow, dbg_trips);
-        if (lane == 0) atomicAdd(&hdr->pad, 1u);
+        atomicAdd(&hdr->dbg_rounds, dbg_rounds);
+        if (lane == 0) atomicAdd(&hdr->dbg_trips, dbg_trips);
+        if (lane == 0) atomicAdd(&hdr->dbg_waves, 1u);
     }
 }
 
@@ -1332,6 +1356,9 @@ int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
 int g_qp_row_waves = 2048;     // most waves of the row kernel (k_qp_row): 2 per SIMD, all resident
 int g_qp_row_hot = 24;         // passes after which a sample's wave takes issue priority
 int g_qp_row_chunk = 0;        // queue tickets a wave takes per atomic; 0: static strided assignment, no queue
+int g_qp_row_long = 32;        // hybrid: samples with >= this many passes in the previous update go to the
+                               // wave-per-sample kernel on the side stream (0: no side stream)
+int g_qp_row_cap = 48;         // passes after which the row kernel hands a sample to the wave-per-sample kernel
 int g_qp_refill_min = 64;      // idle lanes of a wave that trigger a refill (1..64); 64 = only
                                // when the whole wave is idle: a sample's start-up (strided row
                                // loads, a cold projection) is executed by the whole wave, and
@@ -1381,10 +1408,18 @@ __global__ __launch_bounds__(256) void k_qp_order_hist(const int *__restrict__ p
 __global__ __launch_bounds__(256) void k_qp_order_scatter(const int *__restrict__ prev_iters, long n,
                                                           const int *__restrict__ ghist,
                                                           int *__restrict__ gcursor,
-                                                          int *__restrict__ perm)
+                                                          int *__restrict__ perm,
+                                                          QpHeader *__restrict__ hdr, int long_from)
 {
     __shared__ int hist[QP_SORT_BUCKETS], cursor[QP_SORT_BUCKETS];
     const int t = threadIdx.x;
+    // samples whose previous update needed >= long_from passes: the head of the sorted list
+    if (hdr && blockIdx.x == 0 && t == 0) {
+        int m = 0;
+        if (long_from > 0)
+            for (int b = QP_SORT_BUCKETS - 1; b >= long_from && b >= 0; --b) m += ghist[b];
+        hdr->n_long = (unsigned int)m;
+    }
     if (t < QP_SORT_BUCKETS) hist[t] = 0;
     __syncthreads();
     const long r0 = (long)blockIdx.x * QP_SORT_ROWS_PER_BLOCK;
@@ -1422,6 +1457,8 @@ __global__ __launch_bounds__(256) void k_qp_setup(QpHeader *__restrict__ hdr, do
         hdr->next_row = 0u;
         hdr->n_overflow = 0u;
         hdr->next_overflow = 0u;
+        hdr->n_long = 0u;
+        hdr->dbg_rounds = hdr->dbg_trips = hdr->dbg_waves = 0u;
         hdr->pad = 0u;
     }
     for (int e = t; e < KQ * KQ; e += 256) {
@@ -1436,7 +1473,8 @@ __global__ __launch_bounds__(256) void k_qp_setup(QpHeader *__restrict__ hdr, do
 }
 
 // counting sort of the samples by their previous pass counts, longest first -> *perm_out
-static int qp_order_rows(Ctx *c, const int *iters_dev, long n, const int **perm_out)
+static int qp_order_rows(Ctx *c, const int *iters_dev, long n, const int **perm_out,
+                         QpHeader *hdr = nullptr, int long_from = 0)
 {
     AA_CHECK(c->qpPerm.alloc((size_t)n * sizeof(int) + 2 * QP_SORT_BUCKETS * sizeof(int)));
     int *pm = c->qpPerm.as<int>();
@@ -1445,7 +1483,7 @@ static int qp_order_rows(Ctx *c, const int *iters_dev, long n, const int **perm_
     const unsigned nblk = (unsigned)((n + QP_SORT_ROWS_PER_BLOCK - 1) / QP_SORT_ROWS_PER_BLOCK);
     hipLaunchKernelGGL(k_qp_order_hist, dim3(nblk), dim3(256), 0, c->stream, iters_dev, n, ghist);
     hipLaunchKernelGGL(k_qp_order_scatter, dim3(nblk), dim3(256), 0, c->stream, iters_dev, n,
-                       (const int *)ghist, gcursor, pm);
+                       (const int *)ghist, gcursor, pm, hdr, long_from);
     *perm_out = pm;
     return AA_OK;
 }
@@ -1513,21 +1551,42 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                       case 32: QPP(32); break; default: QPP(64); break; }
 #undef QPP
     } else if (row_mode) {
-        // samples ordered by their previous pass count, longest first: the long chains start
-        // at t = 0 (iters_dev still holds the counts of the previous update of this context)
+        // samples ordered by their previous pass count, longest first (iters_dev still holds the
+        // counts of the previous update of this context).  Hybrid: the head of the list -- the
+        // samples that needed >= g_qp_row_long passes last time, ~2 % of them but the whole
+        // critical path -- goes to the wave-per-sample kernel (1 us per pass) on the side stream,
+        // started at once; the row kernel (four samples per wave, ~3 us per pass but four times
+        // the throughput) works off the rest concurrently and hands samples that unexpectedly
+        // reach the pass cap to a second wave-per-sample launch.
         const int *perm = nullptr;
-        if (g_qp_sort && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid)
-            AA_CHECK(qp_order_rows(c, iters_dev, n, &perm));
+        const bool sorted = g_qp_sort && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid;
+        const bool hybrid = sorted && g_qp_row_long > 0 && c->stream2 && KW == 32 && p->memory <= 1;
+        if (sorted) AA_CHECK(qp_order_rows(c, iters_dev, n, &perm, hdr, hybrid ? g_qp_row_long : 0));
+        int cap = g_qp_row_cap < 1 ? 1 : g_qp_row_cap;
+        if (p->memory > 1 || p->max_iterations <= cap || KW != 32) cap = p->max_iterations;
+        if (hybrid) {
+            AA_CHECK_HIP(hipEventRecord(c->evFork, c->stream));
+            AA_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->evFork, 0));
+            hipLaunchKernelGGL(k_qp_wave<32>, dim3(512), dim3(256), 0, c->stream2, A2d, Btall, stride_j,
+                               stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
+                               (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr, perm);
+            AA_CHECK_HIP(hipEventRecord(c->evJoin, c->stream2));
+        }
         long waves = (n + 3) / 4;
         if (waves > g_qp_row_waves) waves = g_qp_row_waves;
         if (k <= 16)
             hipLaunchKernelGGL(k_qp_row<1>, dim3((unsigned)waves), dim3(64), 0, c->stream, A2d, KW, Btall,
                                stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr, perm,
-                               g_qp_row_hot, g_qp_profile, g_qp_row_chunk);
+                               g_qp_row_hot, g_qp_profile, g_qp_row_chunk, cap, ovf_rows, ovf);
         else
             hipLaunchKernelGGL(k_qp_row<2>, dim3((unsigned)waves), dim3(64), 0, c->stream, A2d, KW, Btall,
                                stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr, perm,
-                               g_qp_row_hot, g_qp_profile, g_qp_row_chunk);
+                               g_qp_row_hot, g_qp_profile, g_qp_row_chunk, cap, ovf_rows, ovf);
+        if (hybrid) AA_CHECK_HIP(hipStreamWaitEvent(c->stream, c->evJoin, 0));
+        if (cap < p->max_iterations)
+            hipLaunchKernelGGL(k_qp_wave<32>, dim3(1024), dim3(256), 0, c->stream, A2d, Btall, stride_j,
+                               stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
+                               (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr);
     } else if (wave_only) {
         long blocks = (n + 3) / 4;
         if (blocks > 2048) blocks = 2048;
@@ -1601,10 +1660,12 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         stats->total_passes = (long)h.total_passes;
         stats->max_passes = (int)h.max_passes;
         stats->reserved = (int)h.n_overflow;
-        if (g_qp_profile && row_mode && h.pad)
+        if (g_qp_profile && row_mode && h.dbg_waves)
             fprintf(stderr, "[qp_profile] row kernel: %u waves, %.1f trips per wave, %.2f Michelot rounds per "
-                    "row and trip, %.2f passes per sample\n", h.pad, (double)h.next_overflow / h.pad,
-                    (double)h.n_overflow / (4.0 * h.next_overflow), (double)h.total_passes / (double)n);
+                    "row and trip, %.2f passes per sample, %u predicted-long samples on the side stream, "
+                    "%u handed over at the pass cap\n", h.dbg_waves, (double)h.dbg_trips / h.dbg_waves,
+                    (double)h.dbg_rounds / (4.0 * h.dbg_trips), (double)h.total_passes / (double)n, h.n_long,
+                    h.n_overflow);
         if (g_qp_profile && !row_mode) {
             QpDebug d;
             AA_CHECK_HIP(hipMemcpy(&d, base + 64, sizeof(d), hipMemcpyDeviceToHost));

@@ -472,6 +472,12 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "qp_row_chunk")) {
         AA_REQUIRE(value >= 0 && value <= 4096, AA_ERR_ARG, "qp_row_chunk must be in 0..4096");
         g_qp_row_chunk = value;
+    } else if (!strcmp(name, "qp_row_long")) {
+        AA_REQUIRE(value >= 0 && value < 64, AA_ERR_ARG, "qp_row_long must be in 0..63");
+        g_qp_row_long = value;
+    } else if (!strcmp(name, "qp_row_cap")) {
+        AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_row_cap must be >= 1");
+        g_qp_row_cap = value;
     } else if (!strcmp(name, "qp_row_hot")) {
         AA_REQUIRE(value >= 0, AA_ERR_ARG, "qp_row_hot must be >= 0");
         g_qp_row_hot = value;

@@ -466,3 +466,29 @@ def test_restarts_keep_the_data_resident(cdr, orc, c2_problem):
     cdr.release_device_cache()
     assert _backend._resident["ctx"] is None
     print("restarts: %d fits %.2f s resident vs %.2f s with per-fit upload" % (n_init, t_cached, t_plain))
+
+
+# ------------------------------------------------------------------ more than one GPU (C5)
+def test_two_ranks_match_one_rank(cdr):
+    """libaa_hip itself on two GPUs: two processes (one per GPU, launched with
+    torch.distributed.run before any of them touches a GPU), X row-sharded, RCCL all-reduce on the
+    k x p / k x k products, against the single-rank run of the same problem.  Skipped on a box
+    with one GPU (the development pool); the driver's multi-GPU tier picks it up."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from convex_dim_red import _backend
+    if _backend.require_gpu() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tools", "two_rank_check.py")]
+    out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         timeout=420, universal_newlines=True)
+    assert out.returncode == 0 and "MULTI_RANK_OK world=2" in out.stdout, out.stdout[-3000:]

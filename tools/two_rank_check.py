@@ -1,0 +1,102 @@
+"""Shard-count invariance of libaa_hip's multi-rank path on real GPUs: run under
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P tools/two_rank_check.py
+
+Every rank loads its row shard, the ranks build an RCCL communicator (unique id through a file),
+run production outer iterations and a FurthestSum distance column; rank 0 then solves the
+unsharded problem on its own GPU with a single-rank context and compares: costs and factors
+agree to rounding (the partition only changes summation orders).  Prints MULTI_RANK_OK."""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_R, "matrix-factorization-case-studies_amd"))
+sys.path.insert(0, _R)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import bench  # noqa: E402
+from convex_dim_red import _backend  # noqa: E402
+
+
+def main():
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n, p, k = 6001, 300, 7
+    rng = np.random.RandomState(0)
+    B = rng.standard_normal((k, p))
+    Zt = rng.uniform(size=(n, k)) ** 4
+    Zt /= Zt.sum(axis=1, keepdims=True)
+    X = Zt.dot(B) + 0.05 * rng.standard_normal((n, p))
+    C0 = rng.uniform(size=(k, n)); C0 /= C0.sum(axis=1, keepdims=True)
+    Z0 = rng.uniform(size=(n, k)); Z0 /= Z0.sum(axis=1, keepdims=True)
+    bounds = np.linspace(0, n, world + 1).astype(np.int64)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    share = os.path.join(tempfile.gettempdir(), "aa_two_rank_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+    if rank == 0:
+        os.makedirs(share, exist_ok=True)
+    results = {}
+    for dtype, tol in (("float64", 1e-11), ("float32", 2e-5)):
+        Xd = X.astype(np.float32) if dtype == "float32" else X
+        ctx = _backend.Context(dtype=dtype, device=local)
+        uid_path = None
+        if world > 1:
+            uid, uid_path = bench.exchange_unique_id(rank, world, _backend)
+            ctx.comm_init(uid, rank, world)
+        ctx.set_data(np.ascontiguousarray(Xd[lo:hi]), n_global=n, row_offset=lo)
+        ctx.set_state(np.ascontiguousarray(C0[:, lo:hi]), Z0[lo:hi], np.ones(k))
+        cost0 = ctx.prepare()
+        costs = ctx.outer_iterations(6, dict(max_iterations=1), {})
+        dcol = ctx.distance_column(n // 2 + 3)
+        Cs, Zs, _ = ctx.get_state()
+        ctx.allreduce_host([0.0])                       # all ranks done before the communicator goes
+        ctx.close()
+        np.savez(os.path.join(share, "r%d_%s.npz" % (rank, dtype)), C=Cs, Z=Zs, d=dcol, costs=costs, cost0=cost0)
+        if uid_path and rank == 0:
+            try:
+                os.remove(uid_path)
+            except OSError:
+                pass
+        results[dtype] = tol
+    if rank != 0:
+        return
+    for dtype, tol in results.items():
+        deadline = time.time() + 120
+        parts = []
+        for r in range(world):
+            path = os.path.join(share, "r%d_%s.npz" % (r, dtype))
+            while not os.path.exists(path) and time.time() < deadline:
+                time.sleep(0.05)
+            time.sleep(0.1)
+            parts.append(np.load(path))
+        Xd = X.astype(np.float32) if dtype == "float32" else X
+        with _backend.Context(dtype=dtype, device=local) as ctx:
+            ctx.set_data(Xd)
+            ctx.set_state(C0, Z0, np.ones(k))
+            c0 = ctx.prepare()
+            want = ctx.outer_iterations(6, dict(max_iterations=1), {})
+            wd = ctx.distance_column(n // 2 + 3)
+            wC, wZ, _ = ctx.get_state()
+        C = np.concatenate([q["C"] for q in parts], axis=1)
+        Z = np.concatenate([q["Z"] for q in parts], axis=0)
+        d = np.concatenate([q["d"] for q in parts])
+        for q in parts:                                  # every rank holds the same replicated scalars
+            assert np.array_equal(q["costs"], parts[0]["costs"]) and q["cost0"] == parts[0]["cost0"]
+        rel = np.abs(parts[0]["costs"] - want).max() / abs(c0)
+        print("%s: %d ranks vs 1: cost0 rel diff %.2e, costs %.2e, C %.2e, Z %.2e, distance column %.2e"
+              % (dtype, world, abs(parts[0]["cost0"] - c0) / abs(c0), rel, np.abs(C - wC).max(),
+                 np.abs(Z - wZ).max(), np.abs(d - wd).max()), flush=True)
+        assert rel < tol and abs(parts[0]["cost0"] - c0) < tol * abs(c0)
+        assert np.abs(C - wC).max() < (1e-9 if dtype == "float64" else 1e-4)
+        assert np.abs(Z - wZ).max() < (1e-6 if dtype == "float64" else 1e-2)
+        assert np.abs(d - wd).max() < (1e-9 if dtype == "float64" else 1e-3)
+        assert np.all(C >= 0) and np.allclose(C.sum(axis=1), 1, rtol=0, atol=1e-12)
+    print("MULTI_RANK_OK world=%d" % world, flush=True)
+
+
+if __name__ == "__main__":
+    main()
