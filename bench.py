@@ -158,8 +158,9 @@ def main():
     ap.add_argument("--k", type=int, default=N_COMPONENTS)
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8000)
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-sample", type=int, default=25000)     # n = 25 000 fallback
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-f64", action="store_true", help="skip the float64 (reference dtype) leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -204,6 +205,14 @@ def main():
     elapsed = time.perf_counter() - t0                     # host has read the last cost: device idle
     elapsed = float(ctx.allreduce_host([elapsed], "max")[0])
 
+    # the loop the estimators run (aa_iterate: the same updates plus the device-side monotonicity
+    # check / stopping rule / conditional snapshot after every iteration, host polling every 8),
+    # timed on the same state: tolerance 0 never fires, so exactly `steps` iterations run
+    t0 = time.perf_counter()
+    _, st_loop = ctx.iterate(float(costs[-1]), args.steps, 0.0, "abs_delta_f", False, True, True, spg_kw, qp_kw)
+    elapsed_loop = time.perf_counter() - t0
+    elapsed_loop = float(ctx.allreduce_host([elapsed_loop], "max")[0])
+
     # dominant kernels, timed live with HIP events on the solver's stream: every launch of the
     # two pass kernels inside 10 further outer iterations is bracketed by an event pair
     # (in context, i.e. with the clocks and cache state the timed region has; a back-to-back
@@ -232,12 +241,20 @@ def main():
     # inside this process, so the last committed measurement of the same configuration is
     # reported (profiles/pmc_traffic.json) -- null when there is none for this shape.
     traffic = None
+    traffic_note = "no PMC measurement committed for this shape / these kernels"
     try:
+        import hashlib
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pmc = json.load(fh)
+        with open(os.path.join(ROOT, "matrix-factorization-case-studies_amd", "csrc", "kernels_gemm.hip"), "rb") as fh:
+            sha = hashlib.sha1(fh.read()).hexdigest()
+        # only a measurement of THESE kernels (same source file) on THIS shape is reported
         if (pmc.get("n"), pmc.get("p"), pmc.get("k"), pmc.get("n_gpus")) == (n, p, k, world) \
-                and pmc.get("dtype") == args.dtype:
+                and pmc.get("dtype") == args.dtype and pmc.get("kernels_gemm_sha1") == sha:
             traffic = 0.5 * (pmc["reduce_rows_bytes"] + pmc["row_local_bytes"])
+            traffic_note = ("profiles/pmc_traffic.json (kernels_gemm.hip sha1 %s): reduce_rows %.4g B, "
+                            "row_local %.4g B per launch" % (sha[:12], pmc["reduce_rows_bytes"],
+                                                             pmc["row_local_bytes"]))
     except (OSError, ValueError, KeyError):
         pass
 
@@ -267,7 +284,7 @@ def main():
                                % (n, p, k, world),
                    "parallelism": "rows/%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                      "kernel": "k_reduce_rows_f32 / k_row_local_f32_ws (mean of the two pass kernels, event pairs around every launch in 10 outer iterations)",
                      "ms_reduce_rows": ms_reduce, "ms_row_local": ms_local,
                      "launches_timed": [n_reduce, n_local],
@@ -277,6 +294,11 @@ def main():
         "mfma_frac_outer_iteration": flops_alg / world / (elapsed / args.steps) / (MFMA_F32_PEAK_TFLOPS * 1e12),
         "cost": {"initial": cost0, "final_trace_form": trace_cost, "final_residual_form": recon,
                  "after_each_update_last": [float(costs[-2]), float(costs[-1])]},
+        "estimator_loop": {"value": args.steps / elapsed_loop, "unit": "it/s",
+                           "ms_per_step": 1e3 * elapsed_loop / args.steps,
+                           "what": "aa_iterate, the loop ArchetypalAnalysis.fit_transform runs (device-side "
+                                   "monotonicity check + stopping rule + snapshot per iteration), %d iterations"
+                                   % (st_loop.n_iter + 1)},
         "qp": {"mean_passes_per_sample": qp_stats.total_passes / float(n_loc),
                "max_passes": qp_stats.max_passes, "samples_finished_by_wave_kernel": qp_stats.reserved},
         "datagen_s": t_gen,
@@ -302,13 +324,47 @@ def main():
                       % ("serial C" if base["used_c"] else "NumPy", ns, args.cpu_steps,
                          base["seconds"], base["its_sample"], ns, ns, n),
             "phase_seconds": base["timings"],
+            "phase_note": "dictionary = spg() on C (7 GEMM passes per SPG iteration + sort-based row "
+                          "projections), gram = the four refresh GEMMs, weights = the n per-sample QPs",
         }
+        # the same sample through the float64 path (the reference dtype): separates the float32
+        # rounding of the two big contractions from everything else
+        with _backend.Context(dtype="float64", device=local_rank) as c3:
+            c3.set_data(base["X"])
+            c3.set_state(base["C"], base["Z"], np.ones(k))
+            c3.prepare()
+            dcosts = c3.outer_iterations(1 + args.cpu_steps, spg_kw, qp_kw)
         result["parity_on_sample"] = {
             "what": "cost after %d outer iterations from the same start, first %d rows" % (1 + args.cpu_steps, ns),
             "oracle_cost": base["cost"], "hip_cost": float(gcosts[-1]),
             "rel_diff": abs(float(gcosts[-1]) - base["cost"]) / base["cost"],
+            "hip_cost_float64": float(dcosts[-1]),
+            "rel_diff_float64": abs(float(dcosts[-1]) - base["cost"]) / base["cost"],
+            "note": "float64 leg: the HIP path in the reference dtype against the oracle (algorithmic "
+                    "restatements only); the float32 leg adds the rounding of X, of the MFMA operands "
+                    "and of the fp32 accumulation",
         }
         result["parity_converged"] = converged_parity(k, p, args.dtype, local_rank, spg_kw, qp_kw)
+    if world == 1 and args.dtype == "float32" and not args.no_f64:
+        # the reference dtype (the estimators' default) on the same workload: X as float64 (3.3 GB)
+        Xd = X.astype(np.float64)
+        with _backend.Context(dtype="float64", device=local_rank) as c4:
+            c4.set_data(Xd)
+            c4.set_state(C0, Z0, np.ones(k))
+            c4.prepare()
+            c4.outer_iterations(args.warmup, spg_kw, qp_kw)
+            n64 = max(10, args.steps // 2)
+            t0 = time.perf_counter()
+            c64 = c4.outer_iterations(n64, spg_kw, qp_kw)
+            t64 = time.perf_counter() - t0
+            c4.gemm_timing(True)
+            c4.outer_iterations(5, spg_kw, qp_kw)
+            r64, nr64, l64, nl64 = c4.gemm_timing(False)
+        del Xd
+        result["float64"] = {"value": n64 / t64, "unit": "it/s", "ms_per_step": 1e3 * t64 / n64, "steps": n64,
+                             "ms_reduce_rows": r64, "ms_row_local": l64,
+                             "hbm_frac": float(n) * p * 8 / (0.5 * (r64 + l64) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "cost_last": float(c64[-1])}
     print(json.dumps(result))
 
 

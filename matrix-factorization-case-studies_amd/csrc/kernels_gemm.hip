@@ -28,6 +28,27 @@ namespace aa {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// XCD-aware (column group, row slab) of a block.  Workgroups are dealt round-robin over the 8
+// XCDs (blocks b and b + 8 share one; MI355X_MICROARCH.md, Workgroup dispatch), and every XCD
+// has its own L2.  With the natural map (column group = blockIdx.x) all blocks of a column
+// group sit on one XCD, so each of the 8 XCDs pulls the WHOLE tall operand through its L2
+// (8 x 25.6 MB at the headline size: the 1.19x traffic of round 1).  Here the blocks of one row
+// slab -- which read the same rows of the tall operand -- are given linear ids that agree
+// modulo 8, so every slab of the tall operand is fetched by one XCD only.  Placement is a speed
+// matter only: any map that is a bijection is correct.
+__device__ __forceinline__ void xcd_aware_block(int &colgroup, int &slab)
+{
+    const int ncg = (int)gridDim.x, nsl = (int)gridDim.y;
+    colgroup = (int)blockIdx.x;
+    slab = (int)blockIdx.y;
+    if (nsl % 8 == 0) {
+        const int b = (int)blockIdx.x + ncg * (int)blockIdx.y;   // dispatch order: x fastest
+        const int q = b >> 3, r = b & 7;
+        slab = r + 8 * (q / ncg);
+        colgroup = q % ncg;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // reduce over rows, float32 MFMA.
 // grid = (ceil(p_pad/512), nslab); block = 4 waves; wave w owns the 128-column
@@ -44,10 +65,12 @@ __global__ __launch_bounds__(256) void k_reduce_rows_f32(const float *__restrict
 {
     constexpr int KP = 32 * NCT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c0 = (blockIdx.x * 4 + wave) * 128;
+    int colgroup, slab;
+    xcd_aware_block(colgroup, slab);
+    const int c0 = (colgroup * 4 + wave) * 128;
     if (c0 >= p_pad) return;   // wave-uniform; the kernel has no barriers
     const int h = lane >> 5, j = lane & 31;
-    const long r_begin = (long)blockIdx.y * rows_per_slab;
+    const long r_begin = (long)slab * rows_per_slab;
     long r_end = r_begin + rows_per_slab;
     if (r_end > n_pad) r_end = n_pad;
 
@@ -98,7 +121,7 @@ __global__ __launch_bounds__(256) void k_reduce_rows_f32(const float *__restrict
 
     // D layout (32x32): column = lane&31 (-> 4 data columns c0+4j+m), row (component)
     // = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    float *out = partial + (size_t)blockIdx.y * KP * p_pad;
+    float *out = partial + (size_t)slab * KP * p_pad;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -157,10 +180,12 @@ __global__ __launch_bounds__(256) void k_reduce_rows_f64_mfma(const double *__re
 {
     constexpr int KP = 16 * NT, U = 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c0 = (blockIdx.x * 4 + wave) * 64;
+    int colgroup, slab;
+    xcd_aware_block(colgroup, slab);
+    const int c0 = (colgroup * 4 + wave) * 64;
     if (c0 >= p_pad) return;   // wave-uniform; the kernel has no barriers
     const int lc = lane & 15, lr = lane >> 4;
-    const long r_begin = (long)blockIdx.y * rows_per_slab;
+    const long r_begin = (long)slab * rows_per_slab;
     long r_end = r_begin + rows_per_slab;
     if (r_end > n_pad) r_end = n_pad;
 
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(256) void k_reduce_rows_f64_mfma(const double *__re
     }
 #undef RD_LOAD
 #undef RD_COMPUTE
-    double *out = partial + (size_t)blockIdx.y * KP * p_pad;
+    double *out = partial + (size_t)slab * KP * p_pad;
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll

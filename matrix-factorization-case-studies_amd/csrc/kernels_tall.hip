@@ -748,36 +748,65 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
     // xupd: x <- x + lambda d for the rows of this block (the accepted SPG step, spg.py:208-222;
     // d is read for <d, g_new> anyway)
     const double lam = xupd ? scalw[SC_LAMBDA] : 0.0;
-    for (long r0 = rb + 16 * wave; r0 < re; r0 += 64) {
+    // Two 16-row tiles (r0 and r0 + 64) per step, every load of both -- the A operands, and H,
+    // d, x of the epilogue -- issued before the first MFMA: with one tile in flight a wave waited
+    // out a full memory latency three times per 16 rows (35 us per launch).
+    for (long r0 = rb + 16 * wave; r0 < re; r0 += 128) {
         if (r0 >= n) break;                           // wave-uniform
-        f64x4 acc[T];
+        const bool two = (r0 + 64 < re) && (r0 + 64 < n);   // wave-uniform
+        double gv[2][S], hv[2][T][4], dv[2][T][4], xv[2][T][4];
 #pragma unroll
-        for (int ti = 0; ti < T; ++ti) acc[ti] = (f64x4){0.0, 0.0, 0.0, 0.0};
-        double gv[S];
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) continue;
+            const long ru = r0 + 64 * u;
 #pragma unroll
-        for (int s = 0; s < S; ++s) gv[s] = Graw[(r0 + lc) * KP + 4 * s + lr];   // rows < n_pad
-#pragma unroll
-        for (int s = 0; s < S; ++s)
+            for (int s = 0; s < S; ++s) gv[u][s] = Graw[(ru + lc) * KP + 4 * s + lr];   // rows < n_pad
 #pragma unroll
             for (int ti = 0; ti < T; ++ti)
-                acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(gv[s], mreg[ti][s], acc[ti], 0, 0, 0);
 #pragma unroll
-        for (int ti = 0; ti < T; ++ti)
+                for (int reg = 0; reg < 4; ++reg) {
+                    const long e = (ru + lr + 4 * reg) * KP + 16 * ti + lc;   // < (n_pad + slack) * KP
+                    hv[u][ti][reg] = H[e];
+                    dv[u][ti][reg] = d ? d[e] : 0.0;
+                    xv[u][ti][reg] = xupd ? xupd[e] : 0.0;
+                }
+        }
+        f64x4 acc[2][T];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const long r = r0 + lr + 4 * reg;
-                const int comp = 16 * ti + lc;
-                if (r < n && comp < k) {
-                    const long e = r * KP + comp;
-                    const double ge = (acc[ti][reg] - H[e] * al[ti]) * scale;
-                    gout[e] = ge;
-                    if (d) {
-                        const double de = d[e];
-                        dot += de * ge;
-                        if (xupd) xupd[e] = xupd[e] + lam * de;
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int ti = 0; ti < T; ++ti) acc[u][ti] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) continue;
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int ti = 0; ti < T; ++ti)
+                    acc[u][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(gv[u][s], mreg[ti][s], acc[u][ti], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) continue;
+            const long ru = r0 + 64 * u;
+#pragma unroll
+            for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const long r = ru + lr + 4 * reg;
+                    const int comp = 16 * ti + lc;
+                    if (r < n && comp < k) {
+                        const long e = r * KP + comp;
+                        const double ge = (acc[u][ti][reg] - hv[u][ti][reg] * al[ti]) * scale;
+                        gout[e] = ge;
+                        if (d) {
+                            const double de = dv[u][ti][reg];
+                            dot += de * ge;
+                            if (xupd) xupd[e] = xv[u][ti][reg] + lam * de;
+                        }
                     }
                 }
-            }
+        }
     }
     if (partial) {
         // fixed-order block sum of the per-thread dot products -> one value per block,

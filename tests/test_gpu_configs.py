@@ -146,10 +146,15 @@ def test_c2_hadisst_shape_to_tolerance(cdr, orc, c2_problem, dtype, rtol):
                                    dictionary_solver_kwargs=dict(max_iterations=1),
                                    stopping_criterion="abs_delta_f", dtype=dtype)
         W = m.fit_transform(Xh, dictionary=C0.copy(), weights=Z0.copy(), alpha=np.ones(k))
-    # the rule fires where |delta cost| crosses 1e-4: the iteration may move by rounding, the
-    # cost then moves by less than the tolerance
-    assert abs(m.n_iter - wit) <= (1 if dtype == "float64" else 3)
-    assert abs(m.cost - wcost) < max(rtol * wcost, 2e-4)
+    # the rule fires where |delta cost| crosses 1e-4 on a flat stretch of the cost curve, and the
+    # QPs of this shape end at the function-evaluation cap (see the fixed-iteration test): the
+    # stopping iteration of the oracle itself moves when X changes by one ulp
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Xp = ulp_perturbed(Xd)
+        twin = orc.iterate_aa(Xp, Z0.copy(), C0.copy(), np.ones(k), trace_XXt=(Xp * Xp).sum(), **kw)
+    assert abs(m.n_iter - wit) <= max(1, 2 * abs(twin[4] - wit))
+    assert abs(m.cost - wcost) < max(rtol * wcost, 2e-4, 20 * abs(twin[3] - wcost))
     if m.n_iter == wit:
         assert abs(m.cost - wcost) < rtol * wcost
     assert np.array_equal(m.dictionary.argmax(axis=1), wC.argmax(axis=1))

@@ -5,7 +5,7 @@
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f64 > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
   echo "pmc $C exit=$?"
 done
 cd $GRAFT_REPO_ROOT
@@ -26,7 +26,10 @@ import json
 def pick(C, key):
     c = [v for k, v in res[C].items() if key in k]
     return max(c) if c else None
+import hashlib, subprocess
+sha = hashlib.sha1(open("matrix-factorization-case-studies_amd/csrc/kernels_gemm.hip", "rb").read()).hexdigest()
 out = {"n": 100000, "p": 4096, "k": 32, "n_gpus": 1, "dtype": "float32",
+       "kernels_gemm_sha1": sha,
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/gpu_pmc.sh); bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 per dispatch (FETCH_SIZE doubled: gfx950 reports half of 16-B/lane streaming reads, MI355X_MICROARCH.md section HBM; the 8-B/lane operand reads of k_reduce_rows_f32 are uncalibrated)",
        "algorithmic_bytes": 100000 * 4096 * 4}
 for name, key in (("reduce_rows", "k_reduce_rows_f32"), ("row_local", "k_row_local_f32")):
