@@ -119,6 +119,12 @@ struct ProjState {          // per projection, device memory
     double mx[AA_MAX_K];          // column maxima of the current projection
     int shrunk[AA_MAX_K];         // the support has started to shrink (oscillation guard)
     double warm[4][AA_MAX_K];     // final thresholds of the previous projection of each kind
+    // multi-rank list projection: a rank whose candidate list did not fit, or a union too long
+    // for the solver, leaves a column unconverged.  The host checks that right away only while
+    // the lists of that kind of projection are not known to be short; otherwise the check is
+    // deferred to the next point where the host reads device state anyway (sticky flag).
+    int overflow_sticky;          // set when any column of any projection was left unconverged
+    int list_max[4];              // longest gathered list (over the columns) of the last projection per kind
 };
 
 struct IterState {          // aa_iterate: device-side loop status
@@ -191,6 +197,7 @@ struct Ctx {
     int tallBlocks = 0;                        // blocks of the tall reductions
     int projPassHint[4] = {0, 0, 0, 0};        // Michelot passes the last projection of each kind needed
     bool projWarm[4] = {false, false, false, false};   // ProjState::warm[kind] is valid
+    bool projListShort[4] = {false, false, false, false};   // multi-rank: gathered lists of this kind were <= a quarter of the solver's capacity at the last poll
     bool x_feasible = false;                   // dictionary known to be on the simplex
     bool products_valid = false;               // P (= CX) and Gr (= C XX' or C K) match Ct
     bool ckz_valid = false;                    // gramState's C K Z matches Ct and H
@@ -245,7 +252,8 @@ int launch_gpnh_judge(Ctx *c, int it, double cost0, const double *costs, IterSta
 enum { ST_INIT_F = 0, ST_ALPHA = 1, ST_LINESEARCH = 2, ST_BB = 3, ST_CONV = 4 };
 int launch_row_sqnorm_sum(Ctx *c, double *trace_out_host);
 int launch_distance_column(Ctx *c, long j_local, int owner_has_row, const double *xj_host, double *d_host);
-int launch_row_broadcast(Ctx *c, long j_local, bool own);   // multi-rank: row j -> wideScratch on every rank
+int launch_row_broadcast(Ctx *c, long j_local, bool own);
+int proj_poll_multirank(Ctx *c);   // multi-rank: read the deferred overflow flag / list lengths (host sync point)   // multi-rank: row j -> wideScratch on every rank
 int launch_residual_cost(Ctx *c, const double *Ztall, const double *Wwide, const double *alpha_dev,
                          double *out_host);
 
@@ -269,6 +277,7 @@ int launch_simplex_rows_generic(hipStream_t s, const double *in, double *out, lo
 extern int g_use_graph;           // solver.hip
 extern int g_proj_mode;           // kernels_tall.hip
 extern int g_fuse_finalize;       // kernels_tall.hip
+extern int g_proj_check_always;   // kernels_tall.hip
 extern int g_proj_list_cap;       // kernels_tall.hip
 extern int g_row_local_variant;   // kernels_gemm.hip
 extern int g_row_local_waves;     // kernels_gemm.hip

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
 // host then falls back to the iterative passes from the lower bound.
 __global__ __launch_bounds__(256) void k_proj_solve_gathered(const double *__restrict__ gathered,
                                                              int world, int cap, int KP,
-                                                             ProjState *__restrict__ ps)
+                                                             ProjState *__restrict__ ps, int mode)
 {
     __shared__ double u[PROJ_LDS_CAP];
     __shared__ double rs[4];
@@ -480,6 +480,8 @@ __global__ __launch_bounds__(256) void k_proj_solve_gathered(const double *__res
         ps->t[comp] = th;
         ps->cnt[comp] = (double)prev;
         ps->shrunk[comp] = conv;
+        if (!conv) atomicOr(&ps->overflow_sticky, 1);
+        atomicMax(&ps->list_max[mode & 3], overflow ? (1 << 30) : total);
     }
 }
 
@@ -1254,10 +1256,12 @@ __global__ __launch_bounds__(1024) void k_linesearch_fin(const double *__restric
     for (int e = t; e < 2 * GS; e += 1024) {
         double s4[4] = {0.0, 0.0, 0.0, 0.0};
         int b = 0;
-        for (; b + 3 < nb; b += 4) {
-            const double v0 = partial[(size_t)b * 2 * GS + e], v1 = partial[(size_t)(b + 1) * 2 * GS + e];
-            const double v2 = partial[(size_t)(b + 2) * 2 * GS + e], v3 = partial[(size_t)(b + 3) * 2 * GS + e];
-            s4[0] += v0; s4[1] += v1; s4[2] += v2; s4[3] += v3;
+        for (; b + 15 < nb; b += 16) {              // sixteen loads in flight per thread
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(b + u) * 2 * GS + e];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s4[u & 3] += v[u];
         }
         for (; b < nb; ++b) s4[b & 3] += partial[(size_t)b * 2 * GS + e];
         gram[GS + e] = ((s4[0] + s4[1]) + s4[2]) + s4[3];
@@ -1555,6 +1559,7 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
 static int g_proj_hard_cap = 200;
 
 int g_proj_mode = 0;        // 0: candidate lists, 1: iterative full passes
+int g_proj_check_always = 0; // multi-rank: 1 = check every list projection for overflow at once (host sync)
 int g_fuse_finalize = 1;    // 1: second reduction stages run in the last block of their producer (single rank)
 int g_proj_list_cap = 2048; // multi-rank: most candidates per rank and column in the list all-reduce
                             // (the union must fit the solver's LDS: effective cap = min(this, 2048 / world))
@@ -1580,6 +1585,26 @@ static int proj_iterative_passes(Ctx *c, const double *wsrc, int mode, long rpb,
         batch = 3;
     }
     c->projPassHint[mode] = hdr[1];
+    return AA_OK;
+}
+
+// multi-rank: deferred overflow check of the list projections and refresh of the "lists are
+// short" hints.  Called wherever the host synchronises anyway.
+int proj_poll_multirank(Ctx *c)
+{
+    if (!(c->world > 1 || c->force_comm) || !c->proj.p) return AA_OK;
+    ProjState *ps = c->proj.as<ProjState>();
+    int h[5] = {0, 0, 0, 0, 0};
+    AA_CHECK_HIP(hipMemcpyAsync(h, &ps->overflow_sticky, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    AA_REQUIRE(h[0] == 0, AA_ERR_STATE,
+               "multi-rank projection: a candidate list outgrew the gather buffer between two polls "
+               "(set option proj_check=1 or proj_mode=1)");
+    // "short": even if every candidate of a column sat on ONE rank, twice as many would still fit
+    // that rank's slot of the gather buffer
+    int cap = g_proj_list_cap;
+    if (cap * c->world > PROJ_LDS_CAP) cap = PROJ_LDS_CAP / c->world;
+    for (int m = 0; m < 4; ++m) c->projListShort[m] = c->projWarm[m] && h[1 + m] > 0 && 2 * h[1 + m] <= cap;
     return AA_OK;
 }
 
@@ -1626,18 +1651,26 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
                                (const int *)c->projSegCnt.as<int>(), nseg, segcap, ps,
                                gl + (size_t)c->rank * slot, cap, (int)stride);
             AA_CHECK(comm_allreduce(c, gl, (long)c->world * (long)slot, 0));
+            AA_CHECK_HIP(hipMemsetAsync(&ps->list_max[mode & 3], 0, sizeof(int), c->stream));
             hipLaunchKernelGGL(k_proj_solve_gathered, dim3(c->k), dim3(256), 0, c->stream,
-                               (const double *)gl, c->world, cap, c->KP, ps);
-            // did every column fit and converge?  (identical on all ranks)
-            int conv[AA_MAX_K];
-            AA_CHECK_HIP(hipMemcpyAsync(conv, ps->shrunk, (size_t)c->k * sizeof(int),
-                                        hipMemcpyDeviceToHost, c->stream));
-            AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-            bool all = true;
-            for (int i = 0; i < c->k; ++i) all = all && conv[i] != 0;
-            if (!all) {
-                hipLaunchKernelGGL(k_proj_fallback_init, dim3(1), dim3(64), 0, c->stream, ps, c->k);
-                AA_CHECK(proj_iterative_passes(c, wsrc, mode, rpb, 6));
+                               (const double *)gl, c->world, cap, c->KP, ps, mode);
+            // did every column fit and converge?  (identical on all ranks)  Checked at once --
+            // a host synchronisation -- only while this kind of projection is not known to have
+            // short lists; after that the sticky device flag is read at the next poll
+            // (proj_poll_multirank), and a missed overflow is an error there, never a wrong result
+            if (!c->projListShort[mode & 3] || g_proj_check_always) {
+                int conv[AA_MAX_K];
+                AA_CHECK_HIP(hipMemcpyAsync(conv, ps->shrunk, (size_t)c->k * sizeof(int),
+                                            hipMemcpyDeviceToHost, c->stream));
+                AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+                bool all = true;
+                for (int i = 0; i < c->k; ++i) all = all && conv[i] != 0;
+                if (!all) {
+                    hipLaunchKernelGGL(k_proj_fallback_init, dim3(1), dim3(64), 0, c->stream, ps, c->k);
+                    AA_CHECK_HIP(hipMemsetAsync(&ps->overflow_sticky, 0, sizeof(int), c->stream));   // handled
+                    AA_CHECK(proj_iterative_passes(c, wsrc, mode, rpb, 6));
+                }
+                AA_CHECK(proj_poll_multirank(c));
             }
         }
         AA_CHECK_HIP(hipGetLastError());

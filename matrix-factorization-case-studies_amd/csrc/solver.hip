@@ -370,6 +370,7 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
             AA_CHECK_HIP(hipMemcpyAsync(sc.data(), c->scalars.p, SC_COUNT * sizeof(double),
                                         hipMemcpyDeviceToHost, c->stream));
             AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+            AA_CHECK(proj_poll_multirank(c));
             flags = (int)sc[SC_FLAGS];
             if (flags & (AA_SPG_FLAG_CONVERGED | AA_SPG_FLAG_MAX_FEVAL)) break;
         }
@@ -450,6 +451,8 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "proj_mode")) {
         AA_REQUIRE(value == 0 || value == 1, AA_ERR_ARG, "proj_mode must be 0 or 1");
         g_proj_mode = value;
+    } else if (!strcmp(name, "proj_check")) {
+        g_proj_check_always = value != 0;
     } else if (!strcmp(name, "fuse_finalize")) {
         g_fuse_finalize = value != 0;
     } else if (!strcmp(name, "qp_overlap_tail")) {
@@ -672,6 +675,7 @@ int aa_set_state(aa_ctx *h, int k, const double *C, long ldc, const double *Z, c
     for (int m = 0; m < 4; ++m) {
         c->projWarm[m] = false;
         c->projPassHint[m] = 0;
+        c->projListShort[m] = false;
     }
     return AA_OK;
 }
@@ -824,6 +828,7 @@ int aa_outer_iterations(aa_ctx *h, int n_outer, const aa_spg_params *spg, const 
         AA_CHECK_HIP(hipMemcpyAsync(costs, c->costDev.p, (size_t)2 * n_outer * sizeof(double),
                                     hipMemcpyDeviceToHost, c->stream));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    AA_CHECK(proj_poll_multirank(c));
     return AA_OK;
 }
 
@@ -875,6 +880,7 @@ int aa_iterate(aa_ctx *h, const aa_iter_params *ip, const aa_spg_params *spg, co
         done += batch;
         AA_CHECK_HIP(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
         AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+        AA_CHECK(proj_poll_multirank(c));
         if (hs.stop) break;
     }
     const int last = hs.stop ? hs.stop_iter : n_max - 1;

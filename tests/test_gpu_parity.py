@@ -562,6 +562,9 @@ def test_rccl_path_single_rank(cdr, orc):
                 ctx.set_state(C, Z, np.ones(k))
                 c0 = ctx.prepare()
                 costs = ctx.outer_iterations(3, dict(max_iterations=1), {})
+                # second call: the multi-rank path now knows its candidate lists are short and
+                # defers the overflow check of each projection to the poll at the end of the call
+                costs = np.concatenate([costs, ctx.outer_iterations(3, dict(max_iterations=1), {})])
                 d = ctx.distance_column(5)
                 Cf, Zf, _ = ctx.get_state()
                 total = ctx.allreduce_host([1.5, 2.5])
