@@ -122,12 +122,11 @@ int aa_device_count(int *count);
  *                               stream while Z'X is accumulated (float32 data); the rows it
  *                               changes enter Z'X as a rank-m correction.  Default 0: measured
  *                               neutral, the stragglers run 2x slower next to the GEMM
- *   "qp_mode"           0..3   0 (default): the row kernel (16 lanes per sample, four samples
- *                               per wave, samples run to completion) for k <= 32, one wave per
- *                               sample for 32 < k <= 64; 1: one wave per sample; 2: the
- *                               lane-per-sample kernel followed by the wave-per-sample kernel
- *                               for the stragglers (round-1 default above 16384 samples);
- *                               3: the row kernel (wave-per-sample above k = 32)
+ *   "qp_mode"           0..3   0 (default), k <= 32: up to 16384 samples per GPU the row kernel
+ *                               (16 lanes per sample, four samples per wave, samples run to
+ *                               completion), above that the lane-per-sample kernel followed by the
+ *                               wave-per-sample kernel for the stragglers; k > 32: one wave per
+ *                               sample.  1: one wave per sample; 2: lane + wave; 3: row kernel
  *   "qp_row_waves"      >= 1   most waves the row kernel runs with (default 2048: 2 per SIMD)
  *   "qp_row_hot"        >= 0   SPG passes after which the wave of a sample raises its issue
  *                               priority (also when the previous update needed twice as many)
@@ -136,9 +135,10 @@ int aa_device_count(int *count);
  *                               this many tickets per atomic
  *   "qp_row_long"       0..63  samples that needed at least this many passes in the previous
  *                               update are solved by the wave-per-sample kernel on a side stream,
- *                               concurrently with the row kernel (default 32; 0: no side stream)
+ *                               concurrently with the row kernel (default 0: no side stream; measured
+ *                               slower -- the two kernels take each other's issue slots)
  *   "qp_row_cap"        >= 1   passes after which the row kernel hands a sample to the
- *                               wave-per-sample kernel (default 48)
+ *                               wave-per-sample kernel (default: never)
  *   "fuse_finalize"     0|1    1 (default): fewer, fatter launches in the dictionary update (set-up
  *                               kernel, scalar stages inside the finalize kernels, two-launch line
  *                               search, x update inside the gradient kernel) */

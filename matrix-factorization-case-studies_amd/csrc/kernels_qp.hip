@@ -1069,6 +1069,7 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
     unsigned int q_ahead = 0u;                     // ticket of the chunk whose atomic is in flight
     bool have_ahead = false, drained = false;      // wave-uniform
     int s_next = 0;                                // static assignment: next position of this wave's list
+    const long long t_start = prof ? clock64() : 0;
 
     for (long trip = 0; trip < (1L << 26); ++trip) {       // watchdog bound only
         // a wave that carries a long-running sample stops pulling work (its remaining rows idle
@@ -1347,6 +1348,17 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
         atomicAdd(&hdr->dbg_rounds, dbg_rounds);
         if (lane == 0) atomicAdd(&hdr->dbg_trips, dbg_trips);
         if (lane == 0) atomicAdd(&hdr->dbg_waves, 1u);
+        if (lane == 0) {
+            // QpDebug area (byte 64 of the scratch): [0] max cycles of a wave, [1] its trips packed,
+            // [2] max trips of a wave, [3] sum of cycles, [4] cycles of the wave with most trips
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(hdr) + 64);
+            const unsigned long long cyc = (unsigned long long)(clock64() - t_start);
+            atomicMax(&dbg[0], cyc);
+            atomicMax(&dbg[2], (unsigned long long)dbg_trips);
+            atomicAdd(&dbg[3], cyc);
+            atomicMax(&dbg[4], ((unsigned long long)dbg_trips << 40) | (cyc & ((1ull << 40) - 1ull)));
+            atomicMax(&dbg[1], (cyc << 20) | (unsigned long long)(dbg_trips & 0xfffffu));
+        }
     }
 }
 
@@ -1356,9 +1368,9 @@ int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
 int g_qp_row_waves = 2048;     // most waves of the row kernel (k_qp_row): 2 per SIMD, all resident
 int g_qp_row_hot = 24;         // passes after which a sample's wave takes issue priority
 int g_qp_row_chunk = 0;        // queue tickets a wave takes per atomic; 0: static strided assignment, no queue
-int g_qp_row_long = 32;        // hybrid: samples with >= this many passes in the previous update go to the
+int g_qp_row_long = 0;         // hybrid: samples with >= this many passes in the previous update go to the
                                // wave-per-sample kernel on the side stream (0: no side stream)
-int g_qp_row_cap = 48;         // passes after which the row kernel hands a sample to the wave-per-sample kernel
+int g_qp_row_cap = 1 << 30;        // passes after which the row kernel hands a sample to the wave-per-sample kernel
 int g_qp_refill_min = 64;      // idle lanes of a wave that trigger a refill (1..64); 64 = only
                                // when the whole wave is idle: a sample's start-up (strided row
                                // loads, a cold projection) is executed by the whole wave, and
@@ -1499,9 +1511,14 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     AA_REQUIRE(n < (1L << 31), AA_ERR_ARG, "QP: too many samples");
     // few samples (small shards of a multi-GPU run): the chip has more wave slots than
     // samples, so one wave per sample beats the >= pass-cap trips of the lane kernel
-    // default: the row kernel (16 lanes per sample) for k <= 32, one wave per sample above
-    const bool row_mode = KQ <= 32 && (g_qp_mode == 0 || g_qp_mode == 3);
-    const bool wave_only = !row_mode && (KQ > 32 || g_qp_mode == 1 || g_qp_mode == 3);
+    // default (qp_mode 0), k <= 32: up to 16384 samples per GPU (small problems, shards of a
+    // multi-GPU run) the row kernel -- 16 lanes per sample, run to completion (0.70 ms per outer
+    // iteration at 12 500 rows against 0.79 one wave per sample and 0.81 lane + wave); above that
+    // the lane-per-sample kernel followed by the wave-per-sample kernel for the stragglers
+    // (2.22 ms at 100 000 rows against 2.36 for the row kernel, whose longest chain -- 242 passes
+    // at ~3.3 us -- then sets the time).  k > 32: one wave per sample.
+    const bool row_mode = KQ <= 32 && (g_qp_mode == 3 || (g_qp_mode == 0 && n <= 16384));
+    const bool wave_only = !row_mode && (KQ > 32 || g_qp_mode == 1 || g_qp_mode == 3);   // else: lane + wave
     const int KW = KQ > 32 ? 64 : 32;              // A padding of the wave and row kernels
     // spg.py:310 allocates f_mem of any length; the kernels keep it in registers
     AA_REQUIRE(p->memory <= (row_mode ? QR_MAXMEM : QP_MAXMEM), AA_ERR_ARG,
@@ -1559,6 +1576,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         // the throughput) works off the rest concurrently and hands samples that unexpectedly
         // reach the pass cap to a second wave-per-sample launch.
         const int *perm = nullptr;
+        if (g_qp_profile) AA_CHECK_HIP(hipMemsetAsync(base + 64, 0, 64, c->stream));
         const bool sorted = g_qp_sort && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid;
         const bool hybrid = sorted && g_qp_row_long > 0 && c->stream2 && KW == 32 && p->memory <= 1;
         if (sorted) AA_CHECK(qp_order_rows(c, iters_dev, n, &perm, hdr, hybrid ? g_qp_row_long : 0));
@@ -1660,6 +1678,15 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         stats->total_passes = (long)h.total_passes;
         stats->max_passes = (int)h.max_passes;
         stats->reserved = (int)h.n_overflow;
+        if (g_qp_profile && row_mode && h.dbg_waves) {
+            unsigned long long d5[5];
+            AA_CHECK_HIP(hipMemcpy(d5, base + 64, sizeof(d5), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[qp_profile] row kernel waves: slowest %.0f kcycles (its trips %llu), mean %.0f kcycles; "
+                    "most trips %llu (that wave: %.0f kcycles = %.0f cycles per trip)\n",
+                    (double)(d5[1] >> 20) / 1e3, d5[1] & 0xfffffull, (double)d5[3] / h.dbg_waves / 1e3,
+                    d5[4] >> 40, (double)(d5[4] & ((1ull << 40) - 1ull)) / 1e3,
+                    (double)(d5[4] & ((1ull << 40) - 1ull)) / (double)(d5[4] >> 40));
+        }
         if (g_qp_profile && row_mode && h.dbg_waves)
             fprintf(stderr, "[qp_profile] row kernel: %u waves, %.1f trips per wave, %.2f Michelot rounds per "
                     "row and trip, %.2f passes per sample, %u predicted-long samples on the side stream, "

@@ -153,8 +153,12 @@ def test_c2_hadisst_shape_to_tolerance(cdr, orc, c2_problem, dtype, rtol):
         warnings.simplefilter("ignore")
         Xp = ulp_perturbed(Xd)
         twin = orc.iterate_aa(Xp, Z0.copy(), C0.copy(), np.ones(k), trace_XXt=(Xp * Xp).sum(), **kw)
-    assert abs(m.n_iter - wit) <= max(1, 2 * abs(twin[4] - wit))
-    assert abs(m.cost - wcost) < max(rtol * wcost, 2e-4, 20 * abs(twin[3] - wcost))
+    # (the oracle's cost deltas of its last iterations are within a factor ~2 of the tolerance:
+    # the crossing moves by an iteration or two with the last bits of the QP solutions)
+    assert abs(m.n_iter - wit) <= max(3, 2 * abs(twin[4] - wit))
+    assert abs(m.cost - wcost) < max(rtol * wcost, 3e-4, 20 * abs(twin[3] - wcost))
+    near_end = np.abs(np.asarray(wdeltas)[-3:])
+    assert near_end.max() < 1e-3                         # flat stretch: that is why
     if m.n_iter == wit:
         assert abs(m.cost - wcost) < rtol * wcost
     assert np.array_equal(m.dictionary.argmax(axis=1), wC.argmax(axis=1))
