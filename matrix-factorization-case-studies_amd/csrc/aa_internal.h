@@ -288,6 +288,7 @@ extern int g_reduce_rows_blocks;  // kernels_gemm.hip
 extern int g_qp_pass_cap;         // kernels_qp.hip
 extern int g_qp_mode;             // kernels_qp.hip
 extern int g_qp_row_waves;        // kernels_qp.hip
+extern int g_qp_matvec;           // kernels_qp.hip
 extern int g_qp_row_hot;          // kernels_qp.hip
 extern int g_qp_row_chunk;        // kernels_qp.hip
 extern int g_qp_row_long;         // kernels_qp.hip

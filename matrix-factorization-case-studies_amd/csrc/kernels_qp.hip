@@ -299,6 +299,52 @@ __device__ __forceinline__ void qp_matvec_mfma(const double (&Breg)[KQ / 16][KQ 
     for (int i = 0; i < KQ; ++i) out[i] = abuf[i * QP_AS + lane];
 }
 
+// Mat-vec of the lane kernel through the SCALAR unit (KQ >= 16, default): A is the same for all
+// 64 samples of the wave, so its entries travel as SGPR operands of v_fma_f64 -- s_load_dwordx16
+// from the constant address space, 16 entries per chunk, two chunks in flight ahead of the one
+// being consumed -- and the vector v of this lane's sample never leaves its registers: no LDS
+// round trip, no cross-lane traffic, 1024 FMAs.  7 100 cycles per mat-vec against 17 800 for the
+// MFMA + LDS form above (tools/probes/sgpr_matvec_probe.hip; the VALU floor is 4 096).
+//   * the pointer passes through an empty asm with an SGPR constraint: without it LICM hoists all
+//     1024 scalar loads out of the trip loop and spills 2 000 SGPRs into VGPR lanes;
+//   * the sched_barriers keep the machine scheduler from clustering the loads of all chunks.
+// v_j = x_j for a lane whose sample is starting (g = A x + b), else the search direction
+// d_j = max(x_j - alpha_d g_j - td, 0) - x_j recomputed from the registers it is defined by.
+typedef const __attribute__((address_space(4))) double *qp_cptr_t;
+template <int KQ>
+__device__ __forceinline__ void qp_matvec_sgpr(const double *__restrict__ A, const double (&x)[KQ],
+                                               const double (&g)[KQ], double alpha_d, double td,
+                                               bool use_x, double (&out)[KQ])
+{
+    constexpr int CH = 16, D = 2, NCH = KQ * KQ / CH, CPR = KQ / CH;
+    qp_cptr_t Ap = (qp_cptr_t)(unsigned long long)A;
+    asm volatile("" : "+s"(Ap));
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) out[i] = 0.0;
+    double buf[D + 1][CH];
+#pragma unroll
+    for (int q = 0; q < D; ++q)
+#pragma unroll
+        for (int e = 0; e < CH; ++e) buf[q][e] = Ap[q * CH + e];
+    double vj = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + D < NCH) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) buf[(c + D) % (D + 1)][e] = Ap[(c + D) * CH + e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int j = c / CPR, i0 = (c % CPR) * CH;
+        if (c % CPR == 0) {
+            const double dj = fmax(x[j] - alpha_d * g[j] - td, 0.0) - x[j];
+            vj = use_x ? x[j] : dj;
+        }
+#pragma unroll
+        for (int e = 0; e < CH; ++e) out[i0 + e] = fma(buf[c % (D + 1)][e], vj, out[i0 + e]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // PROF: cycle accounting compiled in (aa_set_option("qp_profile", 1)); the counters cost
 // registers, so the production instantiation has none of it.
 // Components k..KQ-1 are padding.  Their x is 0 and their gradient is held at QP_PAD = 1e300
@@ -307,7 +353,7 @@ __device__ __forceinline__ void qp_matvec_mfma(const double (&Breg)[KQ / 16][KQ 
 // loop needs no `component < k` predicate at all (32 wave-uniform predicates that hipcc kept
 // in SGPR pairs, spilled, and branched on).  Only the start-up and the final store test i < k.
 #define QP_PAD 1e300
-template <int KQ, bool FULL, bool PROF>
+template <int KQ, bool FULL, bool PROF, bool SGMV>
 __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][KQ]*/,
                                            const double *__restrict__ B, long stride_j,
                                            long stride_t, const double *__restrict__ bscale,
@@ -318,10 +364,11 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                                            int g_refill, QpDebug *__restrict__ dbg,
                                            const int *__restrict__ perm)
 {
-    constexpr bool MFMA = KQ >= 16;
+    constexpr bool SG = SGMV && KQ >= 16;              // mat-vec through the scalar unit
+    constexpr bool MFMA = KQ >= 16 && !SG;
     constexpr int VS = MFMA ? QP_VS : 64;              // row stride of the direction buffer
-    __shared__ __attribute__((aligned(16))) double AsT[MFMA ? 2 : KQ * KQ];
-    __shared__ double vbuf[KQ * VS];
+    __shared__ __attribute__((aligned(16))) double AsT[(MFMA || SG) ? 2 : KQ * KQ];
+    __shared__ double vbuf[SG ? 64 : KQ * VS];
     __shared__ double abuf[MFMA ? KQ * QP_AS : 1];
     const int lane = threadIdx.x;
     double Breg[MFMA ? KQ / 16 : 1][MFMA ? KQ / 4 : 1];
@@ -331,8 +378,10 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
 #pragma unroll
             for (int s = 0; s < KQ / 4; ++s)
                 Breg[nt][s] = A[(16 * nt + (lane & 15)) * KQ + 4 * s + (lane >> 4)];
-    } else {
+    } else if constexpr (!SG) {
         for (int e = threadIdx.x; e < KQ * KQ; e += 64) AsT[(e % KQ) * KQ + e / KQ] = A[e];
+        Breg[0][0] = 0.0;
+    } else {
         Breg[0][0] = 0.0;
     }
     __syncthreads();
@@ -349,11 +398,15 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
     // the step: x - alpha g against x - g), each the warm start of the next one of its kind
     typename QpMask<KQ>::type support = 0, support_r = 0;
     const int mem = p.memory < 1 ? 1 : (p.memory > QP_MAXMEM ? QP_MAXMEM : p.memory);
+    if constexpr (!SG) {
 #pragma unroll
-    for (int i = 0; i < KQ; ++i) vl[i * VS] = 0.0;
+        for (int i = 0; i < KQ; ++i) vl[i * VS] = 0.0;
+    }
+    bool starting_mv = false;                          // this lane's mat-vec input is x (start-up)
 
     auto matvec = [&](double (&out)[KQ]) {            // out = A v, v = this lane's LDS column
-        if constexpr (MFMA) qp_matvec_mfma<KQ>(Breg, vbuf, abuf, lane, out);
+        if constexpr (SG) qp_matvec_sgpr<KQ>(A, x, g, alpha_d, td, starting_mv, out);
+        else if constexpr (MFMA) qp_matvec_mfma<KQ>(Breg, vbuf, abuf, lane, out);
         else qp_matvec<KQ>(AsT, vl, k, out);
     };
 
@@ -389,8 +442,10 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                 support_r = support;
 #pragma unroll
                 for (int i = 0; i < KQ; ++i) x[i] = (FULL || i < k) ? fmax(x[i] - t0, 0.0) : 0.0;
+                if constexpr (!SG) {
 #pragma unroll
-                for (int i = 0; i < KQ; ++i) vl[i * VS] = x[i];
+                    for (int i = 0; i < KQ; ++i) vl[i * VS] = x[i];
+                }
             } else {
                 exhausted = true;   // queue drained: this lane idles
             }
@@ -427,13 +482,14 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
 #pragma unroll
             for (int i = 0; i < KQ; ++i) {
                 const double di = fmax(x[i] - alpha_d * g[i] - td, 0.0) - x[i];
-                vl[i * VS] = di;                 // to LDS for the mat-vec; recomputed below
+                if constexpr (!SG) vl[i * VS] = di;   // to LDS for the mat-vec; recomputed below
                 delta = fma(di, g[i], delta);
                 dd = fma(di, di, dd);
             }
         }
         QP_TOC(pc_proj, tp0);
         QP_TIC(tm1);
+        starting_mv = starting;
         matvec(Ad);                                    // collective (idle lanes: stale columns)
         QP_TOC(pc_mv, tm1);
         QP_TIC(ts0);
@@ -1365,6 +1421,7 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
 // Passes a sample may spend in the lane-per-sample kernel before it is handed to the
 // wave-per-sample kernel.
 int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
+int g_qp_matvec = 1;           // lane kernel mat-vec: 1 scalar-unit broadcast (SGPR operands), 0 f64 MFMA + LDS
 int g_qp_row_waves = 2048;     // most waves of the row kernel (k_qp_row): 2 per SIMD, all resident
 int g_qp_row_hot = 24;         // passes after which a sample's wave takes issue priority
 int g_qp_row_chunk = 0;        // queue tickets a wave takes per atomic; 0: static strided assignment, no queue
@@ -1632,10 +1689,15 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
             AA_CHECK(qp_order_rows(c, iters_dev, n, &perm));
         QpDebug *dbgp = g_qp_profile ? reinterpret_cast<QpDebug *>(base + 64) : (QpDebug *)nullptr;
         if (dbgp) AA_CHECK_HIP(hipMemsetAsync(dbgp, 0, sizeof(QpDebug), c->stream));
-#define QPL3(KQV, FULLV, PROFV)                                                               \
-    hipLaunchKernelGGL((k_qp<KQV, FULLV, PROFV>), grid, dim3(64), 0, c->stream, Ad, Btall, stride_j,  \
+#define QPL4(KQV, FULLV, PROFV, SGV)                                                          \
+    hipLaunchKernelGGL((k_qp<KQV, FULLV, PROFV, SGV>), grid, dim3(64), 0, c->stream, Ad, Btall, stride_j,  \
                        stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf,  \
                        g_qp_refill_min, dbgp, perm)
+#define QPL3(KQV, FULLV, PROFV)                                                               \
+    do {                                                                                      \
+        if (g_qp_matvec == 1 && KQV >= 16) QPL4(KQV, FULLV, PROFV, true);                     \
+        else QPL4(KQV, FULLV, PROFV, false);                                                  \
+    } while (0)
 #define QPL(KQV)                                                                              \
     do {                                                                                      \
         if (dbgp) { if (k == KQV) QPL3(KQV, true, true); else QPL3(KQV, false, true); }       \
@@ -1643,6 +1705,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     } while (0)
         switch (KQ) { case 4: QPL(4); break; case 8: QPL(8); break; case 16: QPL(16); break;
                       default: QPL(32); break; }
+#undef QPL4
 #undef QPL3
 #undef QPL
         if (cap < p->max_iterations) {

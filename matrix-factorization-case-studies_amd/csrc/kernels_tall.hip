@@ -1267,9 +1267,33 @@ __global__ __launch_bounds__(1024) void k_linesearch_fin(const double *__restric
         gram[GS + e] = ((s4[0] + s4[1]) + s4[2]) + s4[3];
     }
     __syncthreads();
+    // tr(M (PQ' + QP')) and tr(M QQ') in one sweep and one tree (fixed order)
+    __shared__ double smt2[256];
     double tr1 = 0.0, tr2 = 0.0;
-    tr1 = block_trace_MG_n(M, gram + GS, k, KP, false, smt) + block_trace_MG_n(M, gram + GS, k, KP, true, smt);
-    tr2 = block_trace_MG_n(M, gram + 2 * GS, k, KP, false, smt);
+    {
+        double a1 = 0.0, a2 = 0.0;
+        if (t < 256)
+            for (int e = t; e < k * k; e += 256) {
+                const int i = e / k, j = e % k;
+                const double m = M[i * KP + j];
+                a1 += m * (gram[GS + j * KP + i] + gram[GS + i * KP + j]);
+                a2 += m * gram[2 * GS + j * KP + i];
+            }
+        if (t < 256) {
+            smt[t] = a1;
+            smt2[t] = a2;
+        }
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (t < o) {
+                smt[t] += smt[t + o];
+                smt2[t] += smt2[t + o];
+            }
+            __syncthreads();
+        }
+        tr1 = smt[0];
+        tr2 = smt2[0];
+    }
     if (t == 0) {
         linesearch_thread0(sc, sp, tr1, tr2);
         if (cost_out) {

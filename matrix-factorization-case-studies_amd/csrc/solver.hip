@@ -475,6 +475,9 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "qp_row_chunk")) {
         AA_REQUIRE(value >= 0 && value <= 4096, AA_ERR_ARG, "qp_row_chunk must be in 0..4096");
         g_qp_row_chunk = value;
+    } else if (!strcmp(name, "qp_matvec")) {
+        AA_REQUIRE(value == 0 || value == 1, AA_ERR_ARG, "qp_matvec must be 0 or 1");
+        g_qp_matvec = value;
     } else if (!strcmp(name, "qp_row_long")) {
         AA_REQUIRE(value >= 0 && value < 64, AA_ERR_ARG, "qp_row_long must be in 0..63");
         g_qp_row_long = value;
