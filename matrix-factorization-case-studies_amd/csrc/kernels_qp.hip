@@ -1421,7 +1421,9 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
 // Passes a sample may spend in the lane-per-sample kernel before it is handed to the
 // wave-per-sample kernel.
 int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
-int g_qp_matvec = 1;           // lane kernel mat-vec: 1 scalar-unit broadcast (SGPR operands), 0 f64 MFMA + LDS
+int g_qp_matvec = 0;           // lane kernel mat-vec: 0 f64 MFMA + LDS (default), 1 scalar-unit broadcast (SGPR
+                               // operands; 7 100 against 17 800 cycles in isolation, but 2 % slower inside the
+                               // kernel: 256 VGPRs + 97 AGPRs + spilled SGPRs)
 int g_qp_row_waves = 2048;     // most waves of the row kernel (k_qp_row): 2 per SIMD, all resident
 int g_qp_row_hot = 24;         // passes after which a sample's wave takes issue priority
 int g_qp_row_chunk = 0;        // queue tickets a wave takes per atomic; 0: static strided assignment, no queue

@@ -1623,12 +1623,13 @@ int proj_poll_multirank(Ctx *c)
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
     AA_REQUIRE(h[0] == 0, AA_ERR_STATE,
                "multi-rank projection: a candidate list outgrew the gather buffer between two polls "
-               "(set option proj_check=1 or proj_mode=1)");
+               "(set option proj_check=1 or proj_mode=1) [flag %d, longest lists %d %d %d %d]", h[0], h[1],
+               h[2], h[3], h[4]);
     // "short": even if every candidate of a column sat on ONE rank, twice as many would still fit
     // that rank's slot of the gather buffer
     int cap = g_proj_list_cap;
     if (cap * c->world > PROJ_LDS_CAP) cap = PROJ_LDS_CAP / c->world;
-    for (int m = 0; m < 4; ++m) c->projListShort[m] = c->projWarm[m] && h[1 + m] > 0 && 2 * h[1 + m] <= cap;
+    for (int m = 0; m < 4; ++m) c->projListShort[m] = c->projWarm[m] && h[1 + m] > 0 && h[1 + m] <= cap / 2;
     return AA_OK;
 }
 
