@@ -221,6 +221,22 @@ int aa_dictionary_update(aa_ctx *ctx, const aa_spg_params *params, aa_spg_stats 
  * refresh at :640-643 (:501-503). */
 int aa_weights_update(aa_ctx *ctx, const aa_qp_params *params, aa_qp_stats *stats);
 
+/* Driver-side preprocessing on the device (bin/run_hadisst_aa.py:133-146 weight_and_flatten_data,
+ * :196-209 NaN-column removal and training / validation split; the same steps in
+ * bin/run_jra55_pca_gpnh.py).  `raw` is the flattened field, n_total x p_full, row-major
+ * (float64 or float32, NaN = missing), `col_weight[p_full]` the latitude weight of every flattened
+ * column (NULL: 1).  Columns with a NaN in ANY of the n_total rows are dropped, the others are
+ * multiplied by their weight, and rows [row0, row0 + n) become the context's data matrix exactly
+ * as after aa_set_data (data form).  valid[p_full] receives 1 / 0 per column, *p_valid the
+ * number of columns kept.  The raw field crosses PCIe once; weighting, the NaN scan and the
+ * compaction run on the GPU. */
+int aa_set_data_weighted(aa_ctx *ctx, const void *raw, int host_dtype, long n_total, long p_full,
+                         long ld, const double *col_weight, long row0, long n,
+                         unsigned char *valid, long *p_valid);
+/* The resident data matrix back on the host as float64 (n x p, row stride ld): tests, and the
+ * few host-side uses of the data the estimators have (GPNH 'random' initialisation). */
+int aa_get_data(aa_ctx *ctx, double *out, long ld);
+
 /* The alternating loop of _iterate_aa / _iterate_kernel_aa (archetypal_analysis.py:586-663,
  * :455-524) for delta == 0, with the monotonicity check (:167-174) and the stopping rule
  * (:177-197, :663) evaluated ON THE DEVICE after every iteration: the host enqueues

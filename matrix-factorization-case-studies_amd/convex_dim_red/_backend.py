@@ -101,6 +101,10 @@ _SIGNATURES = {
     "aa_set_data": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_long,
                                    ctypes.c_int, ctypes.c_long, ctypes.c_long]),
     "aa_data_trace": (ctypes.c_int, [_vp, _dp]),
+    "aa_set_data_weighted": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_long,
+                                            _dp, ctypes.c_long, ctypes.c_long,
+                                            ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_long)]),
+    "aa_get_data": (ctypes.c_int, [_vp, _dp, ctypes.c_long]),
     "aa_set_state": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp, _dp]),
     "aa_get_state": (ctypes.c_int, [_vp, _dp, ctypes.c_long, _dp, _dp]),
     "aa_set_alpha": (ctypes.c_int, [_vp, _dp]),
@@ -341,6 +345,33 @@ class Context(object):
         _check(self.lib.aa_set_data(self.h, X.ctypes.data_as(_vp), host, n, p, p, form,
                                     n if n_global is None else n_global, row_offset))
         self.n, self.p = n, p
+
+    def set_data_weighted(self, raw, col_weights=None, row0=0, n=None):
+        """Driver preprocessing on the device (aa_set_data_weighted): ``raw`` is the flattened
+        n_total x p_full field with NaN for missing values; returns the boolean mask of the
+        columns kept (no NaN in any row).  Rows [row0, row0 + n) become the data matrix."""
+        raw = np.asarray(raw)
+        if raw.dtype == np.float32:
+            host = AA_F32
+        else:
+            raw = np.asarray(raw, dtype=np.float64)
+            host = AA_F64
+        raw = np.ascontiguousarray(raw)
+        n_total, p_full = raw.shape
+        n = n_total - row0 if n is None else n
+        w = None if col_weights is None else _c64(np.broadcast_to(col_weights, (p_full,)))
+        valid = np.zeros(p_full, dtype=np.uint8)
+        pv = ctypes.c_long(0)
+        _check(self.lib.aa_set_data_weighted(
+            self.h, raw.ctypes.data_as(_vp), host, n_total, p_full, p_full, None if w is None else _ptr(w),
+            int(row0), int(n), valid.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), ctypes.byref(pv)))
+        self.n, self.p = int(n), int(pv.value)
+        return valid.astype(bool)
+
+    def get_data(self):
+        out = np.empty((self.n, self.p))
+        _check(self.lib.aa_get_data(self.h, _ptr(out), self.p))
+        return out
 
     def data_trace(self):
         t = ctypes.c_double(0)

@@ -24,6 +24,7 @@ from sklearn.utils import check_array, check_random_state
 
 from . import _backend
 from .furthest_sum import furthest_sum, furthest_sum_from_columns
+from .preprocessing import DeviceData
 from .simplex_projection import simplex_project_rows  # noqa: F401  (reference re-export)
 from .spg import quad_simplex_spg, spg  # noqa: F401
 from .stochastic_matrices import right_stochastic_matrix
@@ -543,7 +544,9 @@ class ArchetypalAnalysis(_BaseAA):
 
     def _aa(self, data, dictionary=None, weights=None, alpha=None,
             update_dictionary=True, update_weights=True, update_scale_factors=True, **kwargs):
-        data = np.asarray(data)
+        on_device = isinstance(data, DeviceData)      # preprocessed on the GPU (preprocessing.py)
+        if not on_device:
+            data = np.asarray(data)
         n_samples = data.shape[0]
         if self.n_components is None:
             self.n_components = data.shape[1]
@@ -552,7 +555,8 @@ class ArchetypalAnalysis(_BaseAA):
 
         # the data matrix stays on the device between fits of the same array (the drivers' n_init
         # restarts, bin/run_hadisst_aa.py:158-172): only the start factors travel
-        with _backend.resident_context(data, form=_backend.FORM_DATA, dtype=self.dtype) as ctx:
+        with (data.borrow() if on_device else
+              _backend.resident_context(data, form=_backend.FORM_DATA, dtype=self.dtype)) as ctx:
 
             def init_dictionary():
                 init = 'furthest_sum' if self.init is None else self.init
@@ -610,9 +614,11 @@ class ArchetypalAnalysis(_BaseAA):
         One context, one upload: X (CX)' is the row-local GEMM, the QPs and the residual norm run
         on the resident data (csrc/solver.hip: aa_gpnh_set_factors / _weights_update /
         _residual_cost, which are the "data times a k x p dictionary" entry points)."""
-        data = np.asarray(data)
-        if data.dtype != np.float32:
-            data = np.asarray(data, dtype=np.float64)
+        on_device = isinstance(data, DeviceData)
+        if not on_device:
+            data = np.asarray(data)
+            if data.dtype != np.float32:
+                data = np.asarray(data, dtype=np.float64)
         n_samples = data.shape[0]
         kw = dict(self.weights_solver_kwargs)
         kw['max_iterations'] = self.max_iterations            # reference :1194
@@ -620,8 +626,13 @@ class ArchetypalAnalysis(_BaseAA):
         CKCt = archetypes.dot(archetypes.T)                   # k x k
         initial_weights = right_stochastic_matrix((n_samples, self.n_components),
                                                   random_state=self.random_state)
-        with _backend.Context(dtype=np.float64 if data.dtype == np.float64 else self.dtype) as ctx:
-            ctx.set_data(data, form=_backend.FORM_DATA)
+        if on_device:
+            manager = data.borrow()
+        else:
+            manager = _backend.Context(dtype=np.float64 if data.dtype == np.float64 else self.dtype)
+        with manager as ctx:
+            if not on_device:
+                ctx.set_data(data, form=_backend.FORM_DATA)
             ctx.gpnh_set_factors(self.n_components, W=archetypes.T, Z=initial_weights)   # X (CX)'
             ctx.gpnh_weights_update(CKCt, **kw)
             self.weights = ctx.gpnh_get_weights()

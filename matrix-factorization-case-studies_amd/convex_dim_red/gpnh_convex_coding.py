@@ -21,6 +21,7 @@ from sklearn.utils import check_array, check_random_state
 
 from . import _backend
 from .furthest_sum import furthest_sum_from_columns
+from .preprocessing import DeviceData
 from .stochastic_matrices import right_stochastic_matrix
 from .validation_utils import check_unit_axis_sums, check_array_shape
 
@@ -340,7 +341,9 @@ class GPNHConvexCoding(object):
 
     def _gpnh_convex_coding(self, data, dictionary=None, weights=None,
                             update_dictionary=True, update_weights=True, **kwargs):
-        data = np.asarray(data)
+        on_device = isinstance(data, DeviceData)      # preprocessed on the GPU (preprocessing.py)
+        if not on_device:
+            data = np.asarray(data)
         n_samples, n_features = data.shape
         if self.n_components is None:
             self.n_components = n_features
@@ -356,7 +359,9 @@ class GPNHConvexCoding(object):
         k = self.n_components
         whom = '_gpnh_convex_coding'
         # data resident across the drivers' n_init restarts (bin/run_jra55_pca_gpnh.py:123-136)
-        with _backend.resident_context(data, dtype=self.dtype) as ctx:
+        with (data.borrow() if on_device else _backend.resident_context(data, dtype=self.dtype)) as ctx:
+            if on_device:
+                data = data.to_host() if self.init != 'custom' and update_dictionary else data
             if self.init == 'custom':
                 _check_init_weights(weights, (n_samples, k), whom + ' (input weights)')
                 _check_init_dictionary(dictionary, (n_features, k), whom + ' (input dictionary)')

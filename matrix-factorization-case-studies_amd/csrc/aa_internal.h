@@ -245,6 +245,11 @@ int launch_dict_setup(Ctx *c, const aa_spg_params *sp, double fnorm);
 int launch_iter_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
                       const aa_iter_params *ip);
 int launch_cost_carry(Ctx *c, double *costs, int *slot, double cost0);
+int launch_col_has_nan(Ctx *c, const void *raw_dev, int host_dtype, long ld, long n_total, long p_full,
+                       unsigned char *flags_dev);
+int launch_gather_weight(Ctx *c, const void *raw_dev, int host_dtype, long ld, long row0, long n,
+                         const int *idx_dev, long p_valid, const double *w_dev);
+int launch_data_to_double(Ctx *c, double *out_dev);
 int launch_gpnh_solve(Ctx *c, double lambda, int *ok_dev);
 int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter);
 int launch_gpnh_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,

@@ -1090,13 +1090,13 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
         if (W < 8) W = 8;                                 // the B slab loader assumes >= 512 threads
         if (W > wmax) W = wmax;
         const size_t lds = ((size_t)2 * c->KP * 128 + (size_t)W * 32 * 64) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[64] = {false};                 // the attribute is per device
+        if (!attr_set[c->device & 63]) {
             AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_local_f32_ws<1>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_local_f32_ws<2>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+            attr_set[c->device & 63] = true;
         }
         dim3 grid((unsigned)((tiles + W - 1) / W)), blk((unsigned)(64 * W));
         if (nct == 1)
@@ -1162,13 +1162,13 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
             if (W < 8) W = 8;
             if (W > wmax) W = wmax;
             const size_t lds = ((size_t)2 * c->KP * 66 + (size_t)W * 32 * 34) * sizeof(double);
-            static bool attr_set64 = false;
-            if (!attr_set64) {
+            static bool attr_set64[64] = {false};               // the attribute is per device
+            if (!attr_set64[c->device & 63]) {
                 AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_local_f64_ws<2>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_local_f64_ws<4>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set64 = true;
+                attr_set64[c->device & 63] = true;
             }
             dim3 gw((unsigned)((tiles + W - 1) / W)), bw((unsigned)(64 * W));
             if (nt == 2)

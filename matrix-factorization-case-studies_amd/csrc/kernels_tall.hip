@@ -1845,6 +1845,91 @@ __global__ void k_set_scalars(double *__restrict__ sc, double trace, double fnor
     }
 }
 
+// ---------------------------------------------------------------- driver preprocessing
+// flags[c] = 1 when column c of the raw field holds a NaN in any row (run_hadisst_aa.py:201)
+template <typename T>
+__global__ __launch_bounds__(256) void k_col_has_nan(const T *__restrict__ raw, long ld, long n_total,
+                                                     long p_full, unsigned char *__restrict__ flags)
+{
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= p_full) return;
+    int bad = 0;
+    for (long r = 0; r < n_total; ++r) {
+        const T v = raw[r * ld + c];
+        bad |= (v != v) ? 1 : 0;
+    }
+    flags[c] = (unsigned char)bad;
+}
+
+// X[r][j] = raw[row0 + r][idx[j]] * w[idx[j]]   (weights * da, then valid_data[:n_training], :133-146,:202-208)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void k_gather_weight(const TI *__restrict__ raw, long ld, long row0,
+                                                       long n, const int *__restrict__ idx, long p_valid,
+                                                       const double *__restrict__ w, TO *__restrict__ X,
+                                                       long ldx)
+{
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    const long r = blockIdx.y;
+    if (j >= p_valid || r >= n) return;
+    const int src = idx[j];
+    const double v = (double)raw[(row0 + r) * ld + src] * (w ? w[src] : 1.0);
+    X[r * ldx + j] = (TO)v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_data_to_double(const T *__restrict__ X, long ldx, long n, long p,
+                                                        double *__restrict__ out)
+{
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    const long r = blockIdx.y;
+    if (j < p && r < n) out[r * p + j] = (double)X[r * ldx + j];
+}
+
+int launch_col_has_nan(Ctx *c, const void *raw_dev, int host_dtype, long ld, long n_total, long p_full,
+                       unsigned char *flags_dev)
+{
+    const dim3 grid((unsigned)((p_full + 255) / 256));
+    if (host_dtype == AA_F32)
+        hipLaunchKernelGGL(k_col_has_nan<float>, grid, dim3(256), 0, c->stream,
+                           reinterpret_cast<const float *>(raw_dev), ld, n_total, p_full, flags_dev);
+    else
+        hipLaunchKernelGGL(k_col_has_nan<double>, grid, dim3(256), 0, c->stream,
+                           reinterpret_cast<const double *>(raw_dev), ld, n_total, p_full, flags_dev);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_gather_weight(Ctx *c, const void *raw_dev, int host_dtype, long ld, long row0, long n,
+                         const int *idx_dev, long p_valid, const double *w_dev)
+{
+    const dim3 grid((unsigned)((p_valid + 255) / 256), (unsigned)n);
+#define GW(TI, TO)                                                                                  \
+    hipLaunchKernelGGL((k_gather_weight<TI, TO>), grid, dim3(256), 0, c->stream,                     \
+                       reinterpret_cast<const TI *>(raw_dev), ld, row0, n, idx_dev, p_valid, w_dev,  \
+                       c->X.as<TO>(), c->p_pad)
+    if (host_dtype == AA_F32) {
+        if (c->dtype == AA_F32) GW(float, float); else GW(float, double);
+    } else {
+        if (c->dtype == AA_F32) GW(double, float); else GW(double, double);
+    }
+#undef GW
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_data_to_double(Ctx *c, double *out_dev)
+{
+    const dim3 grid((unsigned)((c->p + 255) / 256), (unsigned)c->n);
+    if (c->dtype == AA_F32)
+        hipLaunchKernelGGL(k_data_to_double<float>, grid, dim3(256), 0, c->stream, c->X.as<float>(), c->p_pad,
+                           c->n, c->p, out_dev);
+    else
+        hipLaunchKernelGGL(k_data_to_double<double>, grid, dim3(256), 0, c->stream, c->X.as<double>(), c->p_pad,
+                           c->n, c->p, out_dev);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
 // ---------------------------------------------------------------- device-side loop control
 // Status record of aa_iterate (device memory): written by one thread after every outer
 // iteration, read by the host once per batch.

@@ -642,6 +642,105 @@ int aa_set_data(aa_ctx *h, const void *X, int host_dtype, long n, long p, long l
     return AA_OK;
 }
 
+int aa_set_data_weighted(aa_ctx *h, const void *raw, int host_dtype, long n_total, long p_full, long ld,
+                         const double *col_weight, long row0, long n, unsigned char *valid, long *p_valid)
+{
+    AA_REQUIRE(h && raw && valid && p_valid, AA_ERR_ARG, "null argument");
+    AA_REQUIRE(host_dtype == AA_F32 || host_dtype == AA_F64, AA_ERR_ARG, "bad host dtype");
+    AA_REQUIRE(n_total >= 1 && p_full >= 1 && ld >= p_full && p_full < (1L << 31), AA_ERR_ARG,
+               "bad shape n_total=%ld p_full=%ld ld=%ld", n_total, p_full, ld);
+    AA_REQUIRE(row0 >= 0 && n >= 1 && row0 + n <= n_total, AA_ERR_ARG, "bad row block [%ld, %ld) of %ld", row0,
+               row0 + n, n_total);
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->world == 1 && !c->force_comm, AA_ERR_ARG, "preprocessing entry point is single-rank");
+    const size_t hes = host_dtype == AA_F32 ? 4 : 8;
+    DevBuf draw, dflag, didx, dw;
+    int rc = draw.alloc((size_t)n_total * p_full * hes);
+    if (rc == AA_OK) rc = dflag.alloc((size_t)p_full);
+    if (rc != AA_OK) { draw.release(); dflag.release(); return rc; }
+    hipError_t e = hipMemcpy2D(draw.p, (size_t)p_full * hes, raw, (size_t)ld * hes, (size_t)p_full * hes,
+                               (size_t)n_total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = launch_col_has_nan(c, draw.p, host_dtype, p_full, n_total, p_full, dflag.as<unsigned char>());
+        if (rc == AA_OK) e = hipStreamSynchronize(c->stream);
+    }
+    std::vector<unsigned char> flags((size_t)p_full);
+    if (rc == AA_OK && e == hipSuccess) e = hipMemcpy(flags.data(), dflag.p, (size_t)p_full, hipMemcpyDeviceToHost);
+    std::vector<int> idx;
+    if (rc == AA_OK && e == hipSuccess) {
+        idx.reserve((size_t)p_full);
+        for (long q = 0; q < p_full; ++q) {
+            valid[q] = flags[(size_t)q] ? 0 : 1;
+            if (!flags[(size_t)q]) idx.push_back((int)q);
+        }
+        *p_valid = (long)idx.size();
+        if (idx.empty()) {
+            set_error("every column of the field holds a NaN");
+            rc = AA_ERR_ARG;
+        }
+    }
+    if (rc == AA_OK && e == hipSuccess) {
+        const long p = (long)idx.size();
+        c->form = AA_FORM_DATA;
+        c->n = n;
+        c->p = p;
+        c->n_pad = round_up(n, 128);
+        c->p_pad = round_up(p, 128);
+        c->n_global = n;
+        c->row_offset = 0;
+        c->X.release();
+        rc = c->X.alloc((size_t)(c->n_pad + AA_SLACK_ROWS) * c->p_pad * esize(c));
+        if (rc == AA_OK) rc = didx.alloc(idx.size() * sizeof(int));
+        if (rc == AA_OK && col_weight) rc = dw.alloc((size_t)p_full * sizeof(double));
+        if (rc == AA_OK) e = hipMemcpy(didx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (rc == AA_OK && e == hipSuccess && col_weight)
+            e = hipMemcpy(dw.p, col_weight, (size_t)p_full * sizeof(double), hipMemcpyHostToDevice);
+        if (rc == AA_OK && e == hipSuccess)
+            rc = launch_gather_weight(c, draw.p, host_dtype, p_full, row0, n, didx.as<int>(), p,
+                                      col_weight ? dw.as<double>() : (const double *)nullptr);
+        if (rc == AA_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        c->have_data = rc == AA_OK && e == hipSuccess;
+        c->have_trace = false;
+        c->k = 0;
+        c->KP = 0;
+        c->have_state = false;
+        c->grams_valid = false;
+    }
+    draw.release();
+    dflag.release();
+    didx.release();
+    dw.release();
+    if (rc == AA_OK && e != hipSuccess) {
+        set_error("aa_set_data_weighted: %s", hipGetErrorString(e));
+        rc = AA_ERR_HIP;
+    }
+    return rc;
+}
+
+int aa_get_data(aa_ctx *h, double *out, long ld)
+{
+    AA_REQUIRE(h && out, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->have_data, AA_ERR_STATE, "no data");
+    AA_REQUIRE(ld >= c->p, AA_ERR_ARG, "ld < p");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    DevBuf tmp;
+    AA_CHECK(tmp.alloc((size_t)c->n * c->p * sizeof(double)));
+    int rc = launch_data_to_double(c, tmp.as<double>());
+    hipError_t e = hipSuccess;
+    if (rc == AA_OK) e = hipStreamSynchronize(c->stream);
+    if (rc == AA_OK && e == hipSuccess)
+        e = hipMemcpy2D(out, (size_t)ld * sizeof(double), tmp.p, (size_t)c->p * sizeof(double),
+                        (size_t)c->p * sizeof(double), (size_t)c->n, hipMemcpyDeviceToHost);
+    tmp.release();
+    if (rc == AA_OK && e != hipSuccess) {
+        set_error("aa_get_data: %s", hipGetErrorString(e));
+        rc = AA_ERR_HIP;
+    }
+    return rc;
+}
+
 int aa_data_trace(aa_ctx *h, double *trace)
 {
     AA_REQUIRE(h && trace, AA_ERR_ARG, "null argument");
@@ -818,6 +917,7 @@ int aa_outer_iterations(aa_ctx *h, int n_outer, const aa_spg_params *spg, const 
         }
         e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
         for (int p = 0; p < pairs && e == hipSuccess; ++p) e = hipGraphLaunch(ge, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);    // the replays are still in flight
         if (ge) (void)hipGraphExecDestroy(ge);
         (void)hipGraphDestroy(g);
         if (e != hipSuccess) {
@@ -1200,9 +1300,16 @@ int aa_quad_simplex_spg_batch(int device, const double *A, const double *B, long
     AA_REQUIRE(n >= 0 && k >= 1 && k <= AA_MAX_K, AA_ERR_ARG, "bad n=%ld k=%d", n, k);
     AA_REQUIRE(stride_j >= 1 && stride_t >= 1, AA_ERR_ARG, "bad strides");
     if (n == 0) return AA_OK;
-    aa_ctx *h = nullptr;
-    AA_CHECK(aa_ctx_create(&h, device, AA_F64));
+    // one scratch context per device for the stateless entry points, kept for the life of the
+    // process: creating and destroying a context (two streams, events, allocations) per call
+    // cost 8 ms -- more than the QPs of every unit-test-sized problem
+    static aa_ctx *scratch[64] = {nullptr};
+    AA_REQUIRE(device >= 0 && device < 64, AA_ERR_ARG, "device %d out of range", device);
+    if (!scratch[device]) AA_CHECK(aa_ctx_create(&scratch[device], device, AA_F64));
+    aa_ctx *h = scratch[device];
+    AA_CHECK_HIP(hipSetDevice(device));
     Ctx *c = &h->c;
+    c->qp_iters_valid = false;
     DevBuf dB, dZ, dI;
     const size_t extent = (size_t)((k - 1) * stride_j + (n - 1) * stride_t + 1);
     int rc = dB.alloc(extent * sizeof(double));
@@ -1232,7 +1339,6 @@ int aa_quad_simplex_spg_batch(int device, const double *A, const double *B, long
     dB.release();
     dZ.release();
     dI.release();
-    aa_ctx_destroy(h);
     return rc;
 }
 

@@ -501,3 +501,62 @@ def test_two_ranks_match_one_rank(cdr):
     out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          timeout=420, universal_newlines=True)
     assert out.returncode == 0 and "MULTI_RANK_OK world=2" in out.stdout, out.stdout[-3000:]
+
+
+# ------------------------------------------------------------------ driver preprocessing
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_driver_preprocessing_on_device(cdr, orc, dtype):
+    """bin/run_hadisst_aa.py:112-146,196-209 -- latitude weights, flattening, removal of the grid
+    points that are missing at any time, training / validation split -- done by NumPy exactly as
+    the driver does it, against weight_and_flatten_on_device; then the same fit from the
+    device-resident block and from the host array."""
+    rng = np.random.RandomState(7)
+    n_time, n_lat, n_lon, k = 90, 6, 8, 3
+    lat = np.linspace(-75.0, 75.0, n_lat)
+    field = rng.standard_normal((n_time, n_lat, n_lon))
+    land = rng.uniform(size=(n_lat, n_lon)) < 0.2                  # always missing
+    field[:, land] = np.nan
+    field[rng.randint(n_time), 2, 3] = np.nan                      # missing once: dropped as well
+    weights = (np.cos(np.deg2rad(lat)).clip(0.0, 1.0) ** 0.5)[:, np.newaxis]     # 'scos', (lat, 1)
+    # the driver's NumPy path
+    flat = (weights * field).reshape(n_time, n_lat * n_lon)
+    missing = np.any(np.isnan(flat), axis=0)
+    valid_data = flat[:, np.logical_not(missing)]
+    n_train = int(np.ceil(0.9 * n_time))
+    training, validation = valid_data[:n_train], valid_data[n_train:]
+    raw = field.astype(np.float32) if dtype == "float32" else field
+    tol = 0 if dtype == "float64" else 1e-6
+    with cdr.weight_and_flatten_on_device(raw, weights, rows=slice(0, n_train), dtype=dtype) as dev, \
+            cdr.weight_and_flatten_on_device(raw, weights, rows=slice(n_train, None), dtype=dtype) as dval:
+        assert np.array_equal(dev.valid, np.logical_not(missing)) and dev.valid.sum() < n_lat * n_lon
+        assert dev.shape == training.shape and dval.shape == validation.shape
+        assert np.abs(dev.to_host() - training).max() <= tol * np.abs(training).max()
+        assert np.abs(dval.to_host() - validation).max() <= tol * np.abs(training).max()
+        kw = dict(init="random", tolerance=1e-6, max_iterations=40, dtype=dtype,
+                  dictionary_solver_kwargs=dict(max_iterations=1))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            a = cdr.ArchetypalAnalysis(k, random_state=0, **kw)
+            Wa = a.fit_transform(dev)
+            b = cdr.ArchetypalAnalysis(k, random_state=0, **kw)
+            Wb = b.fit_transform(dev.to_host().astype(np.float32) if dtype == "float32" else training)
+            assert a.cost == b.cost and a.n_iter == b.n_iter and np.array_equal(Wa, Wb)
+            assert np.array_equal(a.archetypes, b.archetypes)
+            # out-of-sample weights of the validation block (the driver's CV branch, :213-245)
+            Wv_dev, cv_dev = a.transform(dval)
+            Wv_host, cv_host = b.transform(dval.to_host())
+        assert Wv_dev.shape == (n_time - n_train, k)
+        assert abs(cv_dev - cv_host) <= 1e-12 * abs(cv_host) + (0 if dtype == "float64" else 1e-6 * abs(cv_host))
+        # archetypes back on the grid, as the drivers do with the mask
+        grid = np.full((k, n_lat * n_lon), np.nan)
+        grid[:, dev.valid] = a.archetypes
+        assert np.isnan(grid[:, missing]).all() and np.isfinite(grid[:, ~missing]).all()
+    if dtype == "float64":
+        g = cdr.GPNHConvexCoding(k, lambda_W=0.5, init="random", random_state=0, tolerance=1e-6,
+                                 max_iterations=30, weights_solver_kwargs=dict(max_iterations=1))
+        with cdr.weight_and_flatten_on_device(raw, weights, rows=slice(0, n_train)) as dev:
+            Zg = g.fit_transform(dev)
+        g2 = cdr.GPNHConvexCoding(k, lambda_W=0.5, init="random", random_state=0, tolerance=1e-6,
+                                  max_iterations=30, weights_solver_kwargs=dict(max_iterations=1))
+        Zh = g2.fit_transform(training)
+        assert g.cost == g2.cost and np.array_equal(Zg, Zh)
