@@ -241,7 +241,8 @@ int aa_get_data(aa_ctx *ctx, double *out, long ld);
  * :455-524) for delta == 0, with the monotonicity check (:167-174) and the stopping rule
  * (:177-197, :663) evaluated ON THE DEVICE after every iteration: the host enqueues
  * `check_every` iterations at a time and reads one small status record per batch instead of
- * synchronising three times per iteration.  When the rule fires at iteration j the factors of
+ * synchronising three times per iteration (delta != 0 included: the k-vector scale-factor
+ * update of :243-258 is one more small kernel).  When the rule fires at iteration j the factors of
  * iteration j are kept (a conditional device-side snapshot), the iterations that were already
  * enqueued behind it are discarded, and the context is left consistent with iteration j. */
 typedef struct {
@@ -254,12 +255,16 @@ typedef struct {
                                   noise floor of the trace-form cost)                       */
     int    update_dictionary, update_weights;
     int    check_every;        /* iterations per host poll (>= 1)                          */
+    double delta;              /* != 0 (with a scale-factor solver passed to aa_iterate): the
+                                  scale-factor update of archetypal_analysis.py:590-609 opens
+                                  every iteration, as a k-dimensional SPG in one small kernel  */
 } aa_iter_params;
 
 typedef struct {
     int    n_iter;             /* 0-based index of the last iteration (reference n_iter)   */
     int    converged;          /* the stopping rule fired                                  */
-    int    error_stage;        /* 0 none, 1 / 2: cost increased after dictionary / weights */
+    int    error_stage;        /* 0 none, 1 / 2 / 3: cost increased after the dictionary / weights /
+                                  scale-factor update                                        */
     int    error_iter;
     int    spg_flags;          /* OR of the dictionary SPG's AA_SPG_FLAG_* over iterations */
     int    reserved;
@@ -269,7 +274,8 @@ typedef struct {
 /* cost0: cost of the prepared state (aa_prepare); costs: 2 * max_outer entries, filled for the
  * iterations kept.  Returns AA_OK also when error_stage != 0 (the caller raises). */
 int aa_iterate(aa_ctx *ctx, const aa_iter_params *it, const aa_spg_params *spg,
-               const aa_qp_params *qp, double cost0, double *costs, aa_iter_stats *stats);
+               const aa_qp_params *qp, const aa_spg_params *scale_spg /* NULL: no scale factors */,
+               double cost0, double *costs, aa_iter_stats *stats);
 
 /* The alternating loop of _iterate_gpnh_convex_coding (gpnh_convex_coding.py:282-402) on the
  * device, same loop control as aa_iterate.  Per iteration: Z'X (reduce-over-rows GEMM), the

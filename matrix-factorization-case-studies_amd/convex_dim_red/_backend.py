@@ -63,7 +63,7 @@ class IterParams(ctypes.Structure):
                 ("criterion", ctypes.c_int), ("require_monotonic", ctypes.c_int),
                 ("mono_tolerance", ctypes.c_double),
                 ("update_dictionary", ctypes.c_int), ("update_weights", ctypes.c_int),
-                ("check_every", ctypes.c_int)]
+                ("check_every", ctypes.c_int), ("delta", ctypes.c_double)]
 
 
 class IterStats(ctypes.Structure):
@@ -117,7 +117,7 @@ _SIGNATURES = {
     "aa_outer_iterations": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(SPGParams),
                                            ctypes.POINTER(QPParams), _dp]),
     "aa_iterate": (ctypes.c_int, [_vp, ctypes.POINTER(IterParams), ctypes.POINTER(SPGParams),
-                                  ctypes.POINTER(QPParams), ctypes.c_double, _dp,
+                                  ctypes.POINTER(QPParams), ctypes.POINTER(SPGParams), ctypes.c_double, _dp,
                                   ctypes.POINTER(IterStats)]),
     "aa_reconstruction_cost": (ctypes.c_int, [_vp, _dp]),
     "aa_get_archetypes": (ctypes.c_int, [_vp, _dp, ctypes.c_long]),
@@ -437,7 +437,7 @@ class Context(object):
 
     def iterate(self, cost0, max_outer, tolerance, stopping_criterion, require_monotonic,
                 update_dictionary, update_weights, spg_kw, qp_kw, check_every=8,
-                mono_tolerance=None):
+                mono_tolerance=None, delta=0.0, scale_kw=None):
         """Up to ``max_outer`` outer iterations with the monotonicity check and the stopping rule
         evaluated on the device (aa_iterate); returns (costs[2 * (n_iter + 1)], IterStats)."""
         crit = {"abs_delta_f": 0, "rel_delta_f": 1}.get(stopping_criterion)
@@ -445,11 +445,14 @@ class Context(object):
             raise ValueError("unsupported stopping criterion '%s'" % stopping_criterion)
         ip = IterParams(int(max_outer), float(tolerance), crit, int(bool(require_monotonic)),
                         float(tolerance if mono_tolerance is None else mono_tolerance),
-                        int(bool(update_dictionary)), int(bool(update_weights)), int(check_every))
+                        int(bool(update_dictionary)), int(bool(update_weights)), int(check_every),
+                        float(delta))
         sp, qp = spg_params(**spg_kw), qp_params(**qp_kw)
+        ssp = spg_params(**scale_kw) if (scale_kw is not None and delta != 0) else None
         costs = np.zeros(2 * int(max_outer))
         st = IterStats()
         _check(self.lib.aa_iterate(self.h, ctypes.byref(ip), ctypes.byref(sp), ctypes.byref(qp),
+                                   None if ssp is None else ctypes.byref(ssp),
                                    float(cost0), _ptr(costs), ctypes.byref(st)))
         return costs[:2 * (st.n_iter + 1)], st
 
@@ -509,7 +512,7 @@ class Context(object):
         gp = GPNHParams(float(lambda_W), IterParams(
             int(max_outer), float(tolerance), crit, int(bool(require_monotonic)),
             float(tolerance if mono_tolerance is None else mono_tolerance),
-            int(bool(update_dictionary)), int(bool(update_weights)), int(check_every)))
+            int(bool(update_dictionary)), int(bool(update_weights)), int(check_every), 0.0))
         qp = qp_params(**qp_kw)
         costs = np.zeros(2 * int(max_outer))
         st = IterStats()

@@ -33,6 +33,7 @@ from .validation_utils import check_array_shape, check_stochastic_matrix
 INTEGER_TYPES = (numbers.Integral, np.integer)
 INITIALIZATION_METHODS = (None, 'random', 'furthest_sum',)
 _DEVICE_LOOP_BATCH = 8          # outer iterations between two host polls of the device loop
+_DEVICE_LOOP = True
 
 
 # ----------------------------------------------------------------------------
@@ -274,10 +275,12 @@ def _iterate_on_device(ctx, label, weights, dictionary, alpha, delta, update_wei
             'Iteration', 'Cost', 'Cost delta', 'Time'))
         print(80 * '-')
 
-    if not (update_scale_factors and delta != 0):
-        # delta == 0 (every driver configuration): the loop runs on the device, monotonicity
-        # check and stopping rule included; the host reads one status record per batch of
-        # iterations (aa_iterate).  verbose: one batch per call so the table can be printed.
+    if _DEVICE_LOOP:
+        # the loop runs on the device, monotonicity check and stopping rule included (and, for
+        # delta != 0, the k-vector scale-factor SPG of reference :243-258 as one small kernel);
+        # the host reads one status record per batch of iterations (aa_iterate).  verbose: one
+        # batch per call so the table can be printed.
+        scale_on = bool(update_scale_factors and delta != 0)
         stop_name = kwargs.get('stopping_criterion', 'abs_delta_f')
         # float32 data (this build's throughput mode): the trace-form cost cancels tr(XX')/n
         # down to the residual, so it carries ~eps_float32 * tr(XX')/n of noise per evaluation;
@@ -295,7 +298,8 @@ def _iterate_on_device(ctx, label, weights, dictionary, alpha, delta, update_wei
             costs, st = ctx.iterate(new_cost, chunk, tolerance, stop_name, require_monotonic,
                                     update_dictionary, update_weights, dictionary_solver_kwargs,
                                     weights_solver_kwargs, check_every=_DEVICE_LOOP_BATCH,
-                                    mono_tolerance=mono_tol)
+                                    mono_tolerance=mono_tol, delta=delta if scale_on else 0.0,
+                                    scale_kw=scale_factors_solver_kwargs if scale_on else None)
             elapsed = time.perf_counter() - start_time
             ran = max(st.reserved, 1)
             per_iter = elapsed / ran
@@ -303,7 +307,7 @@ def _iterate_on_device(ctx, label, weights, dictionary, alpha, delta, update_wei
                 _warn_from_spg_flags(st)
             if st.error_stage:
                 raise RuntimeError('factorization cost increased after {} update'.format(
-                    'dictionary' if st.error_stage == 1 else 'weights'))
+                    {1: 'dictionary', 2: 'weights', 3: 'scale factors'}[st.error_stage]))
             starts = np.concatenate(([new_cost], costs[1::2][:-1]))
             finals = costs[1::2]
             for j in range(st.n_iter + 1):
@@ -318,9 +322,11 @@ def _iterate_on_device(ctx, label, weights, dictionary, alpha, delta, update_wei
                 if verbose:
                     print('*** Converged at iteration {:d} ***'.format(n_iter + 1))
                 done = True
-        dictionary, weights, _ = ctx.get_state()
+        dictionary, weights, alpha = ctx.get_state()
         return (weights, dictionary, alpha, new_cost, n_iter, np.mean(iter_times), cost_deltas)
 
+    # the same loop driven from the host one update at a time (scale factors with the generic
+    # host spg): kept as the cross-check of the device loop (tests set _DEVICE_LOOP = False)
     n_iter = -1
     for n_iter in range(max_iterations):
         start_time = time.perf_counter()

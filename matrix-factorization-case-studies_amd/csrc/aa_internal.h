@@ -185,7 +185,7 @@ struct Ctx {
     DevBuf proj;                               // ProjState
     DevBuf projList, projSegCnt;               // candidate lists of the column projection
     DevBuf Mdev, alphaDev;                     // KP*KP, KP
-    DevBuf iterState, snapC, snapZ;            // aa_iterate: status record, factors at the stopping iteration
+    DevBuf iterState, snapC, snapZ, snapAlpha; // aa_iterate: status record, factors at the stopping iteration
     DevBuf qpIters;                            // n ints: pass counts of the latest weights update
     DevBuf qpPerm;                             // n ints: sample order of the lane kernel
     bool qp_iters_valid = false;               // qpIters belongs to the current rows / state
@@ -245,6 +245,8 @@ int launch_dict_setup(Ctx *c, const aa_spg_params *sp, double fnorm);
 int launch_iter_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
                       const aa_iter_params *ip);
 int launch_cost_carry(Ctx *c, double *costs, int *slot, double cost0);
+int launch_scale_factors(Ctx *c, const aa_spg_params *sp, double delta_box, int it, double cost0,
+                         const double *costs, const int *slot, IterState *st, double mono_tol, int require);
 int launch_col_has_nan(Ctx *c, const void *raw_dev, int host_dtype, long ld, long n_total, long p_full,
                        unsigned char *flags_dev);
 int launch_gather_weight(Ctx *c, const void *raw_dev, int host_dtype, long ld, long row0, long n,

@@ -1930,6 +1930,166 @@ int launch_data_to_double(Ctx *c, double *out_dev)
     return AA_OK;
 }
 
+// ---------------------------------------------------------------- scale factors (delta != 0)
+// _update_kernel_aa_scale_factors (archetypal_analysis.py:243-258): spg() (spg.py:46-283) on the
+// k-vector alpha with the box projection clip(alpha, 1 - delta, 1 + delta), objective and gradient
+// (:220-240) from the k x k Gram state:
+//   f(a)  = 0.5 (tr - 2 a . diag(CKZ) + sum_ij a_i a_j ZtZ_ij CKCt_ij) / k     (n_samples = CKZ.shape[1] = k)
+//   df(a) = diag(ZtZ diag(a) CKCt - CKZ) / k
+// One wave, lane = component; the two k x k coefficient matrices sit in LDS.  Every quirk of the
+// generic spg() is kept: f_mem starts as zeros (spg.py:153), sigma_one is an absolute bound
+// (:28), alpha0 = None derives the first step from the projected gradient (:178-189).
+// Afterwards (archetypal_analysis.py:596-609) the cost with the new scale factors is compared
+// with the cost the iteration started from; a violation stops the device loop (stage 3).
+__device__ __forceinline__ double sf_wsum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double sf_wmax(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_scale_factors_spg(const double *__restrict__ state /*ZtZ|CKCt|CKZ*/,
+                                                          double *__restrict__ alpha, int k, int KP,
+                                                          double trace, double n_global, double delta_box,
+                                                          aa_spg_params sp, int it, double cost0,
+                                                          const double *__restrict__ costs,
+                                                          const int *__restrict__ slot,
+                                                          IterState *__restrict__ st, double mono_tol,
+                                                          int require)
+{
+    extern __shared__ double lds[];               // B1 [k][k+1] | B2 [k][k+1] | xs [64]
+    const int i = threadIdx.x, ldb = k + 1;
+    double *B1 = lds, *B2 = lds + (size_t)k * ldb, *xs = lds + (size_t)2 * k * ldb;
+    const int GS = KP * KP;
+    const double *ZtZ = state, *CKCt = state + GS, *CKZ = state + 2 * GS;
+    for (int e = i; e < k * k; e += 64) {
+        const int r = e / k, q = e % k;
+        B1[r * ldb + q] = ZtZ[r * KP + q] * CKCt[r * KP + q];
+        B2[r * ldb + q] = ZtZ[r * KP + q] * CKCt[q * KP + r];
+    }
+    const bool live = i < k;
+    const double ci = live ? CKZ[i * KP + i] : 0.0;
+    const double lo = 1.0 - delta_box, hi = 1.0 + delta_box, kd = (double)k;
+    __syncthreads();
+    auto matvec = [&](const double *B, double xv) -> double {     // (B x)_i, x spread over the lanes
+        __syncthreads();
+        xs[i] = live ? xv : 0.0;
+        __syncthreads();
+        double s = 0.0;
+        if (live)
+            for (int q = 0; q < k; ++q) s = fma(B[i * ldb + q], xs[q], s);
+        return s;
+    };
+    auto fval = [&](double xv) -> double {
+        const double m = matvec(B1, xv);
+        return 0.5 * (trace - 2.0 * sf_wsum(live ? xv * ci : 0.0) + sf_wsum(live ? xv * m : 0.0)) / kd;
+    };
+    auto grad = [&](double xv) -> double {
+        const double m = matvec(B2, xv);                            // every lane joins the barriers
+        return live ? (m - ci) / kd : 0.0;
+    };
+    auto proj = [&](double v) -> double { return fmin(fmax(lo, v), hi); };
+
+    double x = live ? proj(alpha[i]) : 0.0;                         // spg.py:147-148
+    double a_step = sp.alpha0;                                      // < 0: None
+    bool a_set = sp.alpha0 >= 0.0;
+    const int mem = sp.memory < 1 ? 1 : (sp.memory > 16 ? 16 : sp.memory);
+    double fmem[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) fmem[q] = 0.0;
+    double f_old = fval(x);
+    int n_feval = 1, flags = 0;
+    bool converged = false;
+    double g = grad(x);
+    int n_iter = 0;
+    for (n_iter = 0; n_iter < sp.max_iterations; ++n_iter) {
+        if (!a_set) {                                               // spg.py:178-189
+            const double ainv = sf_wmax(live ? fabs(proj(x - g) - x) : 0.0);
+            a_step = fabs(ainv) > 1e-12 ? 1.0 / ainv : 1.0;
+            a_set = true;
+        }
+        const double d = live ? proj(x - a_step * g) - x : 0.0;     // :191-194
+#pragma unroll
+        for (int q = 15; q > 0; --q)
+            if (q < mem) fmem[q] = fmem[q - 1];
+        fmem[0] = f_old;
+        double f_max = fmem[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q)
+            if (q < mem && fmem[q] >= f_max) f_max = fmem[q];
+        const double dlt = sf_wsum(d * g);
+        double lam = 1.0;
+        double xn = x + d;
+        double f_new = fval(xn);
+        n_feval += 1;
+        int guard = 0;
+        while (f_new > f_max + sp.gamma * lam * dlt && guard < 200) {           // :214-229
+            const double tmp = -0.5 * lam * lam * dlt / (f_new - f_old - lam * dlt);
+            lam = (sp.sigma_one <= tmp && tmp <= sp.sigma_two * lam) ? tmp : 0.5 * lam;
+            xn = x + lam * d;
+            f_new = fval(xn);
+            n_feval += 1;
+            ++guard;
+            if (fabs(lam) < sp.lambda_min) {
+                flags |= AA_SPG_FLAG_LAMBDA_MIN;
+                break;
+            }
+        }
+        const double gn = grad(xn);                                 // :232-244
+        const double sksk = lam * lam * sf_wsum(d * d);
+        const double beta = lam * sf_wsum(d * (gn - g));
+        a_step = beta <= 0.0 ? sp.alpha_max : fmin(sp.alpha_max, fmax(sp.alpha_min, sksk / beta));
+        x = xn;
+        g = gn;
+        f_old = fval(x);
+        n_feval += 1;
+        const double res = live ? proj(x - g) - x : 0.0;            // :246-266
+        const double rn = sqrt(sf_wsum(res * res));
+        converged = rn < sp.epsilon_two;
+        if (sp.use_infinity_norm) converged = converged || sf_wmax(fabs(res)) < sp.epsilon_one;
+        if (converged) break;
+        if (n_feval > sp.max_feval) {
+            flags |= AA_SPG_FLAG_MAX_FEVAL;
+            break;
+        }
+    }
+    if (!converged && !(flags & AA_SPG_FLAG_MAX_FEVAL)) flags |= AA_SPG_FLAG_MAX_ITER;   // :278-281
+    if (i < KP) alpha[i] = live ? x : 0.0;
+    // cost with the new scale factors (archetypal_analysis.py:601-609); padding lanes carry 0
+    const double m2 = matvec(B2, x);
+    const double cost = 0.5 * (trace - 2.0 * sf_wsum(live ? x * ci : 0.0) + sf_wsum(live ? x * m2 : 0.0)) / n_global;
+    if (i == 0 && st) {
+        st->spg_flags |= flags;
+        if (!st->stop) {
+            const int s0 = slot ? *slot : 0;
+            const double old = s0 == 0 ? cost0 : costs[s0 - 1];
+            if (require && cost > old && fabs(cost - old) > mono_tol) {
+                st->stop = 1;
+                st->error_stage = 3;
+                st->stop_iter = it;
+            }
+        }
+    }
+}
+
+int launch_scale_factors(Ctx *c, const aa_spg_params *sp, double delta_box, int it, double cost0,
+                         const double *costs, const int *slot, IterState *st, double mono_tol, int require)
+{
+    const size_t lds = ((size_t)2 * c->k * (c->k + 1) + 64) * sizeof(double);
+    hipLaunchKernelGGL(k_scale_factors_spg, dim3(1), dim3(64), lds, c->stream,
+                       (const double *)c->gramState.as<double>(), c->alphaDev.as<double>(), c->k, c->KP,
+                       c->trace, (double)c->n_global, delta_box, *sp, it, cost0, costs, slot, st, mono_tol,
+                       require);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
 // ---------------------------------------------------------------- device-side loop control
 // Status record of aa_iterate (device memory): written by one thread after every outer
 // iteration, read by the host once per batch.
@@ -1982,9 +2142,12 @@ __global__ __launch_bounds__(256) void k_iter_snapshot(int it, const IterState *
                                                        const double *__restrict__ Ct,
                                                        const double *__restrict__ Zt,
                                                        double *__restrict__ snapC,
-                                                       double *__restrict__ snapZ, long elems)
+                                                       double *__restrict__ snapZ, long elems,
+                                                       const double *__restrict__ alpha,
+                                                       double *__restrict__ snapAlpha, int KP)
 {
     if (!st->stop || st->stop_iter != it) return;
+    if (blockIdx.x == 0 && (int)threadIdx.x < KP) snapAlpha[threadIdx.x] = alpha[threadIdx.x];
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < elems; i += (long)gridDim.x * 256) {
         snapC[i] = Ct[i];
         snapZ[i] = Zt[i];
@@ -2007,7 +2170,8 @@ int launch_iter_judge(Ctx *c, int it, double cost0, const double *costs, IterSta
                        (const double *)c->scalars.as<double>(), 1);
     hipLaunchKernelGGL(k_iter_snapshot, dim3(512), dim3(256), 0, c->stream, it, (const IterState *)st,
                        (const double *)c->Ct.as<double>(), (const double *)c->Zt.as<double>(),
-                       c->snapC.as<double>(), c->snapZ.as<double>(), (long)c->n_pad * c->KP);
+                       c->snapC.as<double>(), c->snapZ.as<double>(), (long)c->n_pad * c->KP,
+                       (const double *)c->alphaDev.as<double>(), c->snapAlpha.as<double>(), c->KP);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }

@@ -541,7 +541,7 @@ int aa_ctx_destroy(aa_ctx *h)
     comm_destroy(c);
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->redPartial,
-                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->iterState, &c->snapC, &c->snapZ, &c->qpIters, &c->qpPerm,
+                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->iterState, &c->snapC, &c->snapZ, &c->snapAlpha, &c->qpIters, &c->qpPerm,
                      &c->qpStats};
     for (DevBuf *b : all) b->release();
     for (int w = 0; w < 2; ++w)
@@ -936,7 +936,7 @@ int aa_outer_iterations(aa_ctx *h, int n_outer, const aa_spg_params *spg, const 
 }
 
 int aa_iterate(aa_ctx *h, const aa_iter_params *ip, const aa_spg_params *spg, const aa_qp_params *qp,
-               double cost0, double *costs, aa_iter_stats *stats)
+               const aa_spg_params *scale_spg, double cost0, double *costs, aa_iter_stats *stats)
 {
     AA_REQUIRE(h && ip && spg && qp && costs && stats, AA_ERR_ARG, "null argument");
     AA_REQUIRE(ip->max_outer >= 1 && ip->check_every >= 1, AA_ERR_ARG, "bad iteration counts");
@@ -951,17 +951,27 @@ int aa_iterate(aa_ctx *h, const aa_iter_params *ip, const aa_spg_params *spg, co
     AA_CHECK(c->iterState.alloc(sizeof(IterState)));
     AA_CHECK(c->snapC.alloc(tall_bytes));
     AA_CHECK(c->snapZ.alloc(tall_bytes));
+    AA_CHECK(c->snapAlpha.alloc(64 * sizeof(double)));
     int *slot = c->costSlot.as<int>();
     double *cd = c->costDev.as<double>();
     IterState *st = c->iterState.as<IterState>();
     AA_CHECK_HIP(hipMemsetAsync(slot, 0, sizeof(int), c->stream));
     AA_CHECK_HIP(hipMemsetAsync(st, 0, sizeof(IterState), c->stream));
+    const bool scale = scale_spg != nullptr && ip->delta != 0.0;
+    if (scale) AA_REQUIRE(scale_spg->memory <= 16, AA_ERR_ARG, "spg memory > 16 unsupported");
     IterState hs;
     memset(&hs, 0, sizeof(hs));
     int done = 0;
     while (done < n_max) {
         const int batch = n_max - done < ip->check_every ? n_max - done : ip->check_every;
         for (int b = 0; b < batch; ++b) {
+            if (scale) {
+                // archetypal_analysis.py:590-609: the Gram state of the previous weights refresh
+                // (Z'Z, C K C', C K Z) is what the k-vector problem is made of
+                AA_CHECK(ensure_ckz(c));
+                AA_CHECK(launch_scale_factors(c, scale_spg, ip->delta, done + b, cost0, cd, slot, st,
+                                              ip->mono_tolerance, ip->require_monotonic));
+            }
             if (ip->update_dictionary) {
                 bool recorded = false;
                 AA_CHECK(dictionary_update(c, spg, nullptr, true, cd, slot, &recorded));
@@ -995,6 +1005,13 @@ int aa_iterate(aa_ctx *h, const aa_iter_params *ip, const aa_spg_params *spg, co
     stats->spg_flags = hs.spg_flags;
     stats->reserved = done;                      /* iterations enqueued (>= n_iter + 1) */
     stats->cost = costs[2 * last + 1];
+    const bool restore = hs.stop && hs.stop_iter < done - 1 && !hs.error_stage;
+    if (scale) {                                 /* the host copy of alpha follows the device's */
+        std::vector<double> a(c->KP, 1.0);
+        AA_CHECK_HIP(hipMemcpy(a.data(), restore ? c->snapAlpha.p : c->alphaDev.p, (size_t)c->KP * sizeof(double),
+                               hipMemcpyDeviceToHost));
+        for (int i = 0; i < c->k; ++i) c->alpha[i] = a[i];
+    }
     if (hs.stop && hs.stop_iter < done - 1 && !hs.error_stage) {
         // iterations behind the stopping one have run: restore its factors and rebuild the
         // products from them (four passes over the data, once per fit)
