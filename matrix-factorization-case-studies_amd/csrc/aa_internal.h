@@ -172,6 +172,7 @@ struct Ctx {
     DevBuf wideScratch;                        // KP x max(p_pad, n_pad) double
     // reduction scratch
     DevBuf partial;                            // GEMM split-row partials
+    DevBuf rlPartial;                          // row-local GEMM split over column chunks (short, wide data)
     DevBuf redPartial;                         // tall/wide reduction partials
     DevBuf gramOut;                            // up to 4 KPxKP results
     DevBuf gramState;                          // [3][KP*KP] on the device: Z'Z | C K C' | C K Z

@@ -246,12 +246,21 @@ __global__ __launch_bounds__(256) void k_reduce_rows_f64_mfma(const double *__re
 // row-local: D[m = row][n = component].  Block = 64 rows (a wave per 16), both operands
 // staged through LDS in 32-column tiles with coalesced 16-byte loads, register-prefetched one
 // tile ahead; LDS row stride 34 doubles => conflict-free fragment reads.
+// Short, wide matrices (n = 1610, p = 25 000: the HadISST shape) have too few 64-row blocks to
+// fill the chip (26 of them: 0.7 ms per pass for 322 MB), so the contraction is also split over
+// blockIdx.y: chunk `col_chunk` columns per block, partial results to out + blockIdx.y * n_pad *
+// KP, summed in a fixed order by k_sum_chunks.  col_chunk = p_pad and gridDim.y = 1: unsplit.
 template <int NT>
 __global__ __launch_bounds__(256) void k_row_local_f64_mfma(const double *__restrict__ X, long ldx,
                                                             const double *__restrict__ B, int p_pad,
-                                                            double *__restrict__ out, long n_pad)
+                                                            double *__restrict__ out, long n_pad,
+                                                            int col_chunk)
 {
     constexpr int KP = 16 * NT, TC = 32, LS = 34;
+    const int c_begin = (int)blockIdx.y * col_chunk;
+    int c_end = c_begin + col_chunk;
+    if (c_end > p_pad) c_end = p_pad;
+    out += (size_t)blockIdx.y * n_pad * KP;
     constexpr int NB = KP * 16 / 256;                 // B chunks per thread and tile
     __shared__ __attribute__((aligned(16))) double xs[64 * LS];
     __shared__ __attribute__((aligned(16))) double bs[KP * LS];
@@ -287,11 +296,11 @@ __global__ __launch_bounds__(256) void k_row_local_f64_mfma(const double *__rest
             *reinterpret_cast<f64x2g *>(bs + (cid >> 4) * LS + 2 * (cid & 15)) = sb[e];
         }
     };
-    load_tile(0);
-    for (int c0 = 0; c0 < p_pad; c0 += TC) {
+    if (c_begin < c_end) load_tile(c_begin);
+    for (int c0 = c_begin; c0 < c_end; c0 += TC) {
         store_tile();
         __syncthreads();
-        if (c0 + TC < p_pad) load_tile(c0 + TC);
+        if (c0 + TC < c_end) load_tile(c0 + TC);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < TC / 4; ++s) {
@@ -308,6 +317,17 @@ __global__ __launch_bounds__(256) void k_row_local_f64_mfma(const double *__rest
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
             out[(r0 + wave * 16 + lr + 4 * reg) * KP + 16 * nt + lc] = acc[nt][reg];
+}
+
+// out[e] = sum over the column chunks of partial[s][e], s in increasing order (deterministic)
+__global__ __launch_bounds__(256) void k_sum_chunks(const double *__restrict__ partial, long elems,
+                                                    int nsplit, double *__restrict__ out)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems) return;
+    double s = partial[e];
+    for (int q = 1; q < nsplit; ++q) s += partial[(size_t)q * elems + e];
+    out[e] = s;
 }
 
 // row-local, float64, "wave-streaming" form (the structure of k_row_local_f32_ws): a block is
@@ -1178,12 +1198,35 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
                 hipLaunchKernelGGL(k_row_local_f64_ws<4>, gw, bw, lds, c->stream, c->X.as<double>(), c->p_pad,
                                    B, (int)c->p_pad, out_tall, c->n_pad, W);
         } else if (g_f64_mfma) {
+            // few row blocks (short, wide data): split the contraction over column chunks too
+            const long rblocks = c->n_pad / 64;
+            int nsplit = 1;
+            if (rblocks < 192) {
+                nsplit = (int)((512 + rblocks - 1) / rblocks);
+                const int max_split = (int)(c->p_pad / 256);       // >= 256 columns per chunk
+                if (nsplit > max_split) nsplit = max_split;
+                if (nsplit < 1) nsplit = 1;
+            }
+            int chunk = (int)c->p_pad;
+            double *dst = out_tall;
+            if (nsplit > 1) {
+                chunk = (int)round_up((c->p_pad + nsplit - 1) / nsplit, 32);
+                nsplit = (int)((c->p_pad + chunk - 1) / chunk);
+                AA_CHECK(c->rlPartial.alloc((size_t)nsplit * c->n_pad * c->KP * sizeof(double)));
+                dst = c->rlPartial.as<double>();
+            }
+            dim3 g2((unsigned)rblocks, (unsigned)nsplit);
             if (c->KP == 32)
-                hipLaunchKernelGGL(k_row_local_f64_mfma<2>, grid, block, 0, c->stream, c->X.as<double>(),
-                                   c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
+                hipLaunchKernelGGL(k_row_local_f64_mfma<2>, g2, block, 0, c->stream, c->X.as<double>(),
+                                   c->p_pad, B, (int)c->p_pad, dst, c->n_pad, chunk);
             else
-                hipLaunchKernelGGL(k_row_local_f64_mfma<4>, grid, block, 0, c->stream, c->X.as<double>(),
-                                   c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
+                hipLaunchKernelGGL(k_row_local_f64_mfma<4>, g2, block, 0, c->stream, c->X.as<double>(),
+                                   c->p_pad, B, (int)c->p_pad, dst, c->n_pad, chunk);
+            if (nsplit > 1) {
+                const long elems = c->n_pad * c->KP;
+                hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
+                                   (const double *)dst, elems, nsplit, out_tall);
+            }
         } else if (c->KP == 32)
             hipLaunchKernelGGL(k_row_local_f64<32>, grid, block, 0, c->stream, c->X.as<double>(),
                                c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
