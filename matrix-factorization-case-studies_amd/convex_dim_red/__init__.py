@@ -15,8 +15,9 @@ from .spg import spg
 from .stochastic_matrices import left_stochastic_matrix, right_stochastic_matrix
 from ._backend import release_device_cache
 from .preprocessing import DeviceData, weight_and_flatten_on_device
+from .restarts import fit_restarts
 
 __all__ = ["ArchetypalAnalysis", "KernelAA", "GPNHConvexCoding", "furthest_sum",
            "gap_statistic", "simplex_project_rows", "simplex_project_columns", "spg",
            "left_stochastic_matrix", "right_stochastic_matrix", "release_device_cache",
-           "DeviceData", "weight_and_flatten_on_device"]
+           "DeviceData", "weight_and_flatten_on_device", "fit_restarts"]

@@ -587,6 +587,8 @@ class ArchetypalAnalysis(_BaseAA):
                 lambda: _initialize_kernel_aa_weights(shape_only, self.n_components,
                                                       init=self.init,
                                                       random_state=self.random_state))
+            if kwargs.get('_draw_only', False):      # restarts.fit_restarts: start factors only
+                return dictionary, weights, alpha
             self.weights = weights.copy()
             self.dictionary = dictionary.copy()
             self.alpha = alpha.copy()

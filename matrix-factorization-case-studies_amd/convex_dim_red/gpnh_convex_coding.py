@@ -375,6 +375,8 @@ class GPNHConvexCoding(object):
                 dictionary = self._initial_dictionary(ctx, data, kwargs)
                 weights = self._initial_weights(n_samples)
 
+            if kwargs.get('_draw_only', False):      # restarts.fit_restarts: start factors only
+                return dictionary, weights
             self.weights = weights.copy()
             self.dictionary = np.array(dictionary, dtype=np.float64)
 

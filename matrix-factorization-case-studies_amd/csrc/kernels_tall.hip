@@ -1203,7 +1203,7 @@ __device__ void scalar_stage_simple(int stage, double *__restrict__ sc, const aa
 template <int KP>
 __global__ __launch_bounds__(256) void k_gram_wide_pq(const double *__restrict__ P,
                                                       const double *__restrict__ Q, int ld,
-                                                      double *__restrict__ partial)
+                                                      double *__restrict__ partial, int cols_per_block)
 {
     constexpr int JT = KP * KP / 256;
     constexpr int TPI = KP / JT;
@@ -1211,11 +1211,15 @@ __global__ __launch_bounds__(256) void k_gram_wide_pq(const double *__restrict__
     constexpr int GS = KP * KP;
     __shared__ double As[KP][CW + 1], Bs[KP][CW + 1];
     const int t = threadIdx.x, i = t / TPI, j0 = (t % TPI) * JT;
-    const int c0 = blockIdx.x * 128;
+    // a block walks cols_per_block columns (a multiple of 128; at most 64 blocks, so the one-block
+    // finalize behind it reads at most 64 partial Grams however wide the data are)
+    const int c0 = blockIdx.x * cols_per_block;
+    int span = ld - c0;
+    if (span > cols_per_block) span = cols_per_block;
     double acc1[JT], acc2[JT];
 #pragma unroll
     for (int q = 0; q < JT; ++q) acc1[q] = acc2[q] = 0.0;
-    for (int cc = 0; cc < 128; cc += CW) {
+    for (int cc = 0; cc < span; cc += CW) {
         for (int e = t; e < KP * CW; e += 256) {
             As[e / CW][e % CW] = P[(long)(e / CW) * ld + c0 + cc + e % CW];
             Bs[e / CW][e % CW] = Q[(long)(e / CW) * ld + c0 + cc + e % CW];
@@ -2376,17 +2380,19 @@ int launch_gram_wide(Ctx *c, const double *A, const double *B, double *out_dev)
 // cost_slot: optional recording of the cost after the dictionary update
 int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, int *cost_slot)
 {
-    const int nb = (int)(c->p_pad / 128);
+    const long chunks = c->p_pad / 128;
+    const int cpb = (int)((chunks + 63) / 64) * 128;          // columns per block: <= 64 blocks
+    const int nb = (int)((c->p_pad + cpb - 1) / cpb);
     double *part = c->redPartial.as<double>();
     double *ckct = c->gramState.as<double>() + (size_t)c->KP * c->KP;
     if (c->KP == 32)
         hipLaunchKernelGGL(k_gram_wide_pq<32>, dim3(nb), dim3(256), 0, c->stream,
                            (const double *)c->P.as<double>(), (const double *)c->Q.as<double>(),
-                           (int)c->p_pad, part);
+                           (int)c->p_pad, part, cpb);
     else
         hipLaunchKernelGGL(k_gram_wide_pq<64>, dim3(nb), dim3(256), 0, c->stream,
                            (const double *)c->P.as<double>(), (const double *)c->Q.as<double>(),
-                           (int)c->p_pad, part);
+                           (int)c->p_pad, part, cpb);
     hipLaunchKernelGGL(k_linesearch_fin, dim3(1), dim3(1024), 0, c->stream, (const double *)part, nb, c->KP,
                        c->gramOut.as<double>(), (const double *)c->Mdev.as<double>(),
                        c->scalars.as<double>(), *sp, c->k, ckct, (double)c->n_global, cost_out, cost_slot);

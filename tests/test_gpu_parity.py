@@ -957,8 +957,16 @@ def test_scale_factors_on_device_match_host_spg(cdr, orc, form):
     # stretch of the cost curve -- 23 iterations in the reference, 26 with the last bits of alpha
     # rounded differently -- and alpha, which converges slowly, then differs by 1e-4: that tier is
     # covered by test_iterate_aa_traces_golden at the matching tolerance.)
+    for skw, tol in ((dict(max_iterations=2), 1e-11), ({}, 2e-6)):
+        # two SPG iterations per scale-factor update: the device kernel against the host spg() to
+        # rounding; default settings: each update runs to ||res|| < 1e-6, which is then the
+        # accuracy two implementations share
+        _check_scale_factors(aa, orc, X, Z0, C0, a0, form, skw, tol)
+
+
+def _check_scale_factors(aa, orc, X, Z0, C0, a0, form, skw, tol):
     kw = dict(delta=0.1, tolerance=0, max_iterations=6, require_monotonic_cost_decrease=False,
-              dictionary_solver_kwargs=dict(max_iterations=1))
+              dictionary_solver_kwargs=dict(max_iterations=1), scale_factors_solver_kwargs=skw)
     outs = []
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -977,9 +985,9 @@ def test_scale_factors_on_device_match_host_spg(cdr, orc, form):
             want = orc.iterate_kernel_aa(X.dot(X.T), Z0.copy(), C0.copy(), a0.copy(), **kw)
     dev, host = outs
     assert dev[4] == host[4] == want[4] == 5                             # n_iter
-    assert abs(dev[3] - host[3]) < 1e-11 and abs(dev[3] - want[3]) < 1e-10
-    assert np.abs(dev[2] - host[2]).max() < 1e-9 and np.abs(dev[2] - want[2]).max() < 1e-8
+    assert abs(dev[3] - host[3]) < tol * dev[3] and abs(dev[3] - want[3]) < 10 * tol * dev[3]
+    assert np.abs(dev[2] - host[2]).max() < 100 * tol and np.abs(dev[2] - want[2]).max() < 1000 * tol
     assert np.all(dev[2] >= 0.9 - 1e-15) and np.all(dev[2] <= 1.1 + 1e-15)
     assert np.abs(dev[2] - 1.0).max() > 1e-3                             # the scale factors did move
-    assert np.abs(np.asarray(dev[6]) - np.asarray(host[6])).max() < 1e-11
-    assert np.abs(dev[1] - want[1]).max() < 1e-8 and np.abs(dev[0] - want[0]).max() < 1e-6
+    assert np.abs(np.asarray(dev[6]) - np.asarray(host[6])).max() < tol * dev[3] * 10
+    assert np.abs(dev[1] - want[1]).max() < 1e4 * tol and np.abs(dev[0] - want[0]).max() < 1e-4
