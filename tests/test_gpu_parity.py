@@ -957,9 +957,10 @@ def test_scale_factors_on_device_match_host_spg(cdr, orc, form):
     # stretch of the cost curve -- 23 iterations in the reference, 26 with the last bits of alpha
     # rounded differently -- and alpha, which converges slowly, then differs by 1e-4: that tier is
     # covered by test_iterate_aa_traces_golden at the matching tolerance.)
-    for skw, tol in ((dict(max_iterations=2), 1e-11), ({}, 2e-6)):
+    for skw, tol in ((dict(max_iterations=2), 1e-9), ({}, 2e-6)):
         # two SPG iterations per scale-factor update: the device kernel against the host spg() to
-        # rounding; default settings: each update runs to ||res|| < 1e-6, which is then the
+        # rounding carried through six outer iterations of simplex QPs (measured 3e-10 on the
+        # kernel form, whose Gram has condition number ~1e6); default settings: each update runs to ||res|| < 1e-6, which is then the
         # accuracy two implementations share
         _check_scale_factors(aa, orc, X, Z0, C0, a0, form, skw, tol)
 
