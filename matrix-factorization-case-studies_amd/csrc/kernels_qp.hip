@@ -1418,6 +1418,405 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
     }
 }
 
+// ---------------------------------------------------------------------------
+// FOUR LANES PER SAMPLE, laid out as the f64 matrix cores want their operands (round 2).
+//
+// v_mfma_f64_16x16x4 takes its K x N operand with lane l holding (k = l>>4, n = l&15) and leaves
+// the M x N result with lane l, register r holding (m = 4r + (l>>4), n = l&15).  Let the N index
+// be the SAMPLE (16 per wave) and K / M the component: lane (s = l&15, q = l>>4) of sample slot s
+// then supplies, in step t, component 4t + q of the direction, and receives components 4r + q
+// (+16 per further M tile) of A d -- the SAME residue class q mod 4 on both sides.  So with
+// component 4j + q of every vector (x, g, d, A d) in register j of lane (s, q), the k x k
+// mat-vec of 16 samples is KQ/4 * KQ/16 matrix instructions on registers as they are: no LDS
+// round trip, no transposition, no broadcast loads (the lane-per-sample kernel spends 17 800 of
+// its 43 500 cycles per trip on exactly that), and A's operand tiles stay in KQ/2 registers.
+// Element-wise work costs the same instructions per sample as one lane per sample (a VALU
+// instruction covers 64 sample-components either way); reductions are KQ/4 in-lane terms and a
+// two-step butterfly over the four lanes of a sample (v_permlane16_swap / v_permlane32_swap,
+// gfx950: lanes l, l^16, l^32, l^48).  Both partners of a step add the same two numbers, so the
+// four lanes hold identical bits and take every sample-uniform decision identically.
+// A wave batches 16 samples instead of 64, so the batching waste of the divergent pass counts
+// shrinks as well.  All cross-lane operations sit in wave-uniform control flow (idle slots run
+// along with their results discarded).  Samples that reach the pass cap are parked for the
+// wave-per-sample kernel exactly as in k_qp.
+// ---------------------------------------------------------------------------
+typedef unsigned int qq_u2 __attribute__((ext_vector_type(2)));
+
+template <bool R32>
+__device__ __forceinline__ void qq_xchg(unsigned int v, unsigned int &a, unsigned int &b)
+{
+    // both operands = v: afterwards `a` holds the lower partner's word and `b` the upper partner's
+    // in BOTH lanes of a pair (rows r / r^1 for permlane16, halves for permlane32)
+    qq_u2 r;
+    if constexpr (R32) r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    else r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    a = r[0];
+    b = r[1];
+}
+template <bool R32>
+__device__ __forceinline__ void qq_xchg_d(double v, double &a, double &b)
+{
+    unsigned int la, lb, ha, hb;
+    qq_xchg<R32>((unsigned int)__double2loint(v), la, lb);
+    qq_xchg<R32>((unsigned int)__double2hiint(v), ha, hb);
+    a = __hiloint2double((int)ha, (int)la);
+    b = __hiloint2double((int)hb, (int)lb);
+}
+__device__ __forceinline__ double qq_sum(double v)      // over the four lanes of a sample
+{
+    double a, b;
+    qq_xchg_d<false>(v, a, b);
+    v = a + b;
+    qq_xchg_d<true>(v, a, b);
+    return a + b;
+}
+__device__ __forceinline__ double qq_max(double v)
+{
+    double a, b;
+    qq_xchg_d<false>(v, a, b);
+    v = fmax(a, b);
+    qq_xchg_d<true>(v, a, b);
+    return fmax(a, b);
+}
+__device__ __forceinline__ unsigned int qq_sum_u(unsigned int v)
+{
+    unsigned int a, b;
+    qq_xchg<false>(v, a, b);
+    v = a + b;
+    qq_xchg<true>(v, a, b);
+    return a + b;
+}
+
+// Threshold of the projection of w (this lane's J components of it) for the samples with `live`
+// set; same fixed point, same break rules as qp_project_threshold.  One four-word reduction per
+// Michelot round: the sum and size of the NEXT support travel with the "support changed" flag.
+template <int J>
+__device__ __forceinline__ double qq_threshold(const double (&w)[J], unsigned int &mask, bool live)
+{
+    unsigned int m = mask;
+    bool done = !live;
+    double sl = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) sl += ((m >> j) & 1u) ? w[j] : 0.0;
+    double s = qq_sum(sl);
+    unsigned int c = qq_sum_u((unsigned int)__popc(m));
+    if (__any(!done && c == 0u)) {                 // cold start (a sample's first projection)
+        double mx = w[0];
+#pragma unroll
+        for (int j = 1; j < J; ++j) mx = fmax(mx, w[j]);
+        mx = qq_max(mx);
+        if (!done && c == 0u) {
+            const double t0 = mx - 1.0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) m |= (w[j] > t0) ? (1u << j) : 0u;
+        }
+        sl = 0.0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) sl += ((m >> j) & 1u) ? w[j] : 0.0;
+        s = qq_sum(sl);
+        c = qq_sum_u((unsigned int)__popc(m));
+    }
+    for (int pass = 0; pass < 8 * J + 8; ++pass) {
+        const double sm1 = s - 1.0, cd = (double)c;
+        unsigned int nm = 0u;
+        double s2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const bool in = w[j] * cd > sm1;
+            nm |= in ? (1u << j) : 0u;
+            s2 += in ? w[j] : 0.0;
+        }
+        const unsigned int cf = qq_sum_u((unsigned int)__popc(nm) | (nm != m ? 0x10000u : 0u));
+        s2 = qq_sum(s2);
+        const unsigned int c2 = cf & 0xffffu;
+        if (!done) {
+            if ((cf >> 16) == 0u || (pass >= 2 && c2 >= c)) {
+                done = true;
+            } else {
+                m = nm;
+                s = s2;
+                c = c2;
+            }
+        }
+        if (!__any(!done)) break;
+    }
+    if (live) mask = m;
+    return (s - 1.0) / (double)c;
+}
+
+template <int MT, bool MEM1>   // M tiles of 16 components: KQ = 16 MT, J = 4 MT components per lane;
+                               // MEM1: memory == 1 (the default), no history of f in registers
+__device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda][lda], zero padded*/,
+                                             int lda, const double *__restrict__ B, long stride_j,
+                                             long stride_t, const double *__restrict__ bscale,
+                                             double *__restrict__ Z, int ldz, long n, int k,
+                                             const aa_qp_params &p, int pass_cap, int *__restrict__ iters,
+                                             QpHeader *__restrict__ hdr, int *__restrict__ ovf_rows,
+                                             QpCarry *__restrict__ ovf, int refill_min,
+                                             const int *__restrict__ perm, long max_trips)
+{
+    constexpr int J = 4 * MT;
+    const int lane = threadIdx.x, sl = lane & 15, q = lane >> 4;
+    double H[MT][J];                                // A's operand tiles (constant)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < J; ++t) H[mt][t] = A[(long)(16 * mt + sl) * lda + 4 * t + q];
+    double x[J], g[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        x[j] = 0.0;
+        g[j] = 0.0;
+    }
+    double f = 0.0, alpha = 1.0, fmem[MEM1 ? 1 : QP_MAXMEM];
+#pragma unroll
+    for (int i = 0; i < (MEM1 ? 1 : QP_MAXMEM); ++i) fmem[i] = NAN;
+    int n_iter = 0, n_feval = 0;
+    long row = 0;
+    bool active = false, exhausted = false;
+    unsigned int support = 0u, support_r = 0u;
+    const int mem = p.memory < 1 ? 1 : (p.memory > QP_MAXMEM ? QP_MAXMEM : p.memory);
+    const bool alpha0_ok = p.alpha_min <= p.alpha0 && p.alpha0 <= p.alpha_max;
+    // static interleaved slices of the (longest-first) sample list: no queue, no atomics
+    long next_idx = (long)blockIdx.x * 16 + sl;
+    const long idx_stride = (long)gridDim.x * 16;
+    unsigned long long st_total = 0ull;
+    int st_max = 0;
+
+    for (long trip = 0; trip < max_trips; ++trip) {
+        const bool idle = !active && !exhausted;
+        const int n_idle = (int)__popcll(__ballot(idle));
+        const bool refill = n_idle >= 4 * refill_min || !__any(active);
+        bool starting = false;
+        if (refill && idle) {
+            if (next_idx < n) {
+                row = perm ? (long)perm[next_idx] : next_idx;
+                next_idx += idx_stride;
+                starting = true;
+            } else {
+                exhausted = true;
+            }
+        }
+        if (!__any(active || starting)) break;
+        if (__any(starting)) {
+            // ---- start-up: x = P(z0)                                          (spg.py:298-306)
+            double xs[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) xs[j] = (starting && 4 * j + q < k) ? Z[row * ldz + 4 * j + q] : -QP_PAD;
+            unsigned int m0 = 0u;
+            const double t0 = qq_threshold<J>(xs, m0, starting);
+            if (starting) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    x[j] = (4 * j + q < k) ? fmax(xs[j] - t0, 0.0) : 0.0;
+                    g[j] = 0.0;
+                }
+                support = m0;
+                support_r = m0;
+            }
+        }
+        const bool was_active = active;
+        if (__any(was_active && n_iter == 0)) {
+            if (alpha0_ok) {
+                if (was_active && n_iter == 0) alpha = p.alpha0;
+            } else {
+                double w1[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) w1[j] = x[j] - g[j];
+                const bool first = was_active && n_iter == 0;
+                const double t1 = qq_threshold<J>(w1, support_r, first);
+                double ainv = 0.0;
+#pragma unroll
+                for (int j = 0; j < J; ++j) ainv = fmax(ainv, fabs(fmax(w1[j] - t1, 0.0) - x[j]));
+                ainv = qq_max(ainv);
+                if (fabs(ainv) < 1e-12) ainv = 1.0;
+                if (first) alpha = fmin(fmax(p.alpha_min, 1.0 / ainv), p.alpha_max);
+            }
+        }
+        // ---- search direction d = P(x - alpha g) - x                          (spg.py:318-338)
+        double d[J];
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+        {
+            double w[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) w[j] = x[j] - alpha * g[j];
+            const double td = qq_threshold<J>(w, support, was_active);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                d[j] = fmax(w[j] - td, 0.0) - x[j];
+                r0 = fma(d[j], g[j], r0);
+                r1 = fma(d[j], d[j], r1);
+            }
+        }
+        // ---- A v for the whole wave: v = x for a starting sample, d for an active one
+        double Ad[J];
+        {
+            f64x4 acc[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt][0] = (f64x4){0.0, 0.0, 0.0, 0.0};
+                acc[mt][1] = (f64x4){0.0, 0.0, 0.0, 0.0};
+            }
+#pragma unroll
+            for (int t = 0; t < J; ++t) {
+                const double v = starting ? x[t] : (was_active ? d[t] : 0.0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][t & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(H[mt][t], v, acc[mt][t & 1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ad[4 * mt + r] = acc[mt][0][r] + acc[mt][1][r];
+        }
+        if (starting) {
+            // ---- rest of the start-up: g = A x + b; f = x'(g + b)/2           (spg.py:298-315)
+            r0 = 0.0;
+            r1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int comp = 4 * j + q;
+                const double bi =
+                    comp < k ? -B[comp * stride_j + row * stride_t] * (bscale ? bscale[comp] : 1.0) : QP_PAD;
+                g[j] = Ad[j] + bi;
+                r0 = fma(x[j], g[j], r0);
+                r1 = fma(x[j], bi, r1);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < J; ++j) r2 = fma(d[j], Ad[j], r2);
+        }
+        r0 = qq_sum(r0);
+        r1 = qq_sum(r1);
+        r2 = qq_sum(r2);
+        if (starting) {
+            f = 0.5 * (r0 + r1);
+            n_feval = 1;
+            n_iter = 0;
+#pragma unroll
+            for (int i = 0; i < (MEM1 ? 1 : QP_MAXMEM); ++i) fmem[i] = NAN;
+            active = true;                             // its first pass runs in the next trip
+        }
+        if (!__any(was_active)) continue;
+        if (was_active) {
+            const double delta = r0, dd = r1, dAd = r2;
+            // non-monotone reference value (spg.py:341-344): roll, store, nanmax
+            double f_max = f;
+            if constexpr (!MEM1) {
+#pragma unroll
+                for (int i = QP_MAXMEM - 1; i > 0; --i)
+                    if (i < mem) fmem[i] = fmem[i - 1];
+                fmem[0] = f;
+#pragma unroll
+                for (int i = 1; i < QP_MAXMEM; ++i)
+                    if (i < mem && fmem[i] > f_max) f_max = fmem[i];
+            }
+            double lam = 1.0;
+            double f_new = f + lam * delta + 0.5 * lam * lam * dAd;
+            n_feval += 1;
+            int guard = 0;
+            while (f_new > f_max + p.gamma * lam * delta && guard < 200) {
+                const double tmp = -0.5 * lam * lam * delta / (f_new - f - lam * delta);
+                lam = (p.sigma_one <= tmp && tmp <= p.sigma_two * lam) ? tmp : 0.5 * lam;
+                f_new = f + lam * delta + 0.5 * lam * lam * dAd;
+                n_feval += 1;
+                ++guard;
+                if (fabs(lam) < p.lambda_min) break;
+            }
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                x[j] = fma(lam, d[j], x[j]);
+                g[j] = fma(lam, Ad[j], g[j]);
+            }
+            const double sksk = lam * lam * dd;
+            const double beta = lam * (lam * dAd);
+            alpha = (beta <= 0.0) ? p.alpha_max : fmin(p.alpha_max, fmax(p.alpha_min, sksk / beta));
+            f = f_new;
+            n_feval += 1;
+        }
+        // ---- residual of the projected gradient at the new point              (spg.py:378-396)
+        double q2 = 0.0, qinf = 0.0;
+        {
+            double w[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) w[j] = x[j] - g[j];
+            const double tr = qq_threshold<J>(w, support_r, was_active);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const double r = fmax(w[j] - tr, 0.0) - x[j];
+                q2 = fma(r, r, q2);
+                qinf = fmax(qinf, fabs(r));
+            }
+        }
+        q2 = qq_sum(q2);
+        qinf = qq_max(qinf);
+        if (was_active) {
+            n_iter += 1;
+            const bool conv = (sqrt(q2) < p.epsilon_two) || (qinf < p.epsilon_one);
+            const bool finished = conv || n_feval > p.max_feval || n_iter >= p.max_iterations;
+            if (finished || n_iter >= pass_cap) {
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    if (4 * j + q < k) Z[row * ldz + 4 * j + q] = x[j];
+                if (q == 0) {
+                    if (finished) {
+                        if (iters) iters[row] = n_iter;
+                        st_total += (unsigned long long)n_iter;
+                        st_max = n_iter > st_max ? n_iter : st_max;
+                    } else {
+                        const unsigned int slot = atomicAdd(&hdr->n_overflow, 1u);
+                        ovf_rows[slot] = (int)row;
+                        QpCarry cr;
+                        cr.alpha = alpha;
+                        cr.f = f;
+                        cr.n_iter = n_iter;
+                        cr.n_feval = n_feval;
+                        ovf[slot] = cr;
+                    }
+                }
+                active = false;
+            }
+        }
+    }
+    {   // wave totals (fixed-order butterfly), one atomic pair per wave
+        unsigned long long tot = st_total;
+        int mx = st_max;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            tot += __shfl_xor(tot, o, 64);
+            const int om = __shfl_xor(mx, o, 64);
+            mx = om > mx ? om : mx;
+        }
+        if (threadIdx.x == 0 && tot) {
+            atomicAdd(&hdr->total_passes, tot);
+            atomicMax(&hdr->max_passes, (unsigned long long)mx);
+        }
+    }
+}
+
+// The same body at three register budgets: OCC waves per SIMD (2: whatever the compiler likes,
+// 3: <= 168 registers, 4: <= 128 with a little scratch).
+#define QQ_ARGS const double *__restrict__ A, int lda, const double *__restrict__ B, long stride_j, long stride_t,   \
+                const double *__restrict__ bscale, double *__restrict__ Z, int ldz, long n, int k, aa_qp_params p, \
+                int pass_cap, int *__restrict__ iters, QpHeader *__restrict__ hdr, int *__restrict__ ovf_rows,      \
+                QpCarry *__restrict__ ovf, int refill_min, const int *__restrict__ perm, long max_trips
+#define QQ_PASS A, lda, B, stride_j, stride_t, bscale, Z, ldz, n, k, p, pass_cap, iters, hdr, ovf_rows, ovf,        \
+                refill_min, perm, max_trips
+template <int MT, bool MEM1>
+__global__ __launch_bounds__(64) void k_qp_quad(QQ_ARGS) { qp_quad_body<MT, MEM1>(QQ_PASS); }
+template <int MT, bool MEM1>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_qp_quad_w3(QQ_ARGS)
+{
+    qp_quad_body<MT, MEM1>(QQ_PASS);
+}
+template <int MT, bool MEM1>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_qp_quad_w4(QQ_ARGS)
+{
+    qp_quad_body<MT, MEM1>(QQ_PASS);
+}
+#undef QQ_ARGS
+#undef QQ_PASS
+
 // Passes a sample may spend in the lane-per-sample kernel before it is handed to the
 // wave-per-sample kernel.
 int g_qp_pass_cap = 24;        // settable with aa_set_option("qp_pass_cap", v)
@@ -1435,8 +1834,13 @@ int g_qp_refill_min = 64;      // idle lanes of a wave that trigger a refill (1.
                                // loads, a cold projection) is executed by the whole wave, and
                                // mid-flight refills cost more than the idle lanes they fill
                                // (2.64 ms per outer iteration against 2.83 at 24)
-int g_qp_mode = 0;             // 0: row kernel (k <= 32) / wave-per-sample, 1: wave-per-sample only,
-                               // 2: lane-per-sample then wave-per-sample, 3: row kernel
+int g_qp_mode = 0;             // 0: by size (see launch_qp), 1: wave-per-sample only,
+                               // 2: lane-per-sample then wave-per-sample, 3: row kernel,
+                               // 4: four lanes per sample (matrix-core layout) then wave-per-sample
+int g_qp_quad_waves = 3072;    // most waves of k_qp_quad (three per SIMD, all resident)
+int g_qp_quad_refill = 16;     // idle sample slots (of 16) of a wave that trigger a refill
+int g_qp_quad_cap = 24;        // passes after which k_qp_quad parks a sample for the wave kernel
+int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
 int g_qp_profile = 0;          // cycle accounting of k_qp (printed when stats are requested)
 int g_qp_sort = 1;             // order the samples by the previous update's pass counts
@@ -1577,7 +1981,8 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     // (2.22 ms at 100 000 rows against 2.36 for the row kernel, whose longest chain -- 242 passes
     // at ~3.3 us -- then sets the time).  k > 32: one wave per sample.
     const bool row_mode = KQ <= 32 && (g_qp_mode == 3 || (g_qp_mode == 0 && n <= 16384));
-    const bool wave_only = !row_mode && (KQ > 32 || g_qp_mode == 1 || g_qp_mode == 3);   // else: lane + wave
+    const bool quad_mode = KQ <= 32 && (g_qp_mode == 4 || (g_qp_mode == 0 && n > 16384));
+    const bool wave_only = !row_mode && !quad_mode && (KQ > 32 || g_qp_mode == 1 || g_qp_mode == 3);   // else: lane + wave
     const int KW = KQ > 32 ? 64 : 32;              // A padding of the wave and row kernels
     // spg.py:310 allocates f_mem of any length; the kernels keep it in registers
     AA_REQUIRE(p->memory <= (row_mode ? QR_MAXMEM : QP_MAXMEM), AA_ERR_ARG,
@@ -1660,6 +2065,38 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                                stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr, perm,
                                g_qp_row_hot, g_qp_profile, g_qp_row_chunk, cap, ovf_rows, ovf);
         if (hybrid) AA_CHECK_HIP(hipStreamWaitEvent(c->stream, c->evJoin, 0));
+        if (cap < p->max_iterations)
+            hipLaunchKernelGGL(k_qp_wave<32>, dim3(1024), dim3(256), 0, c->stream, A2d, Btall, stride_j,
+                               stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
+                               (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr);
+    } else if (quad_mode) {
+        int cap = g_qp_quad_cap < 1 ? 1 : g_qp_quad_cap;
+        if (p->memory > 1 || p->max_iterations <= cap) cap = p->max_iterations;
+        long waves = (n + 15) / 16;
+        if (waves > g_qp_quad_waves) waves = g_qp_quad_waves;
+        const int *perm = nullptr;
+        if (g_qp_sort && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid)
+            AA_CHECK(qp_order_rows(c, iters_dev, n, &perm));
+        hipStream_t s_main = c->stream;
+        // watchdog only: a wave's slots take their samples one after the other, each at most
+        // cap passes and a start-up trip
+        const long rounds = (n + 16 * waves - 1) / (16 * waves);
+        const long max_trips = 16 * rounds * ((long)cap + 2) + 16;
+        const int refill = g_qp_quad_refill < 1 ? 1 : (g_qp_quad_refill > 16 ? 16 : g_qp_quad_refill);
+#define QQK(KERN, MTV, M1V)                                                                         \
+    hipLaunchKernelGGL((KERN<MTV, M1V>), dim3((unsigned)waves), dim3(64), 0, s_main, A2d, KW, Btall,        \
+                       stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf,   \
+                       refill, perm, max_trips)
+#define QQL(MTV, M1V)                                                                               \
+    do {                                                                                            \
+        if (g_qp_quad_occ >= 4) QQK(k_qp_quad_w4, MTV, M1V);                                        \
+        else if (g_qp_quad_occ == 3) QQK(k_qp_quad_w3, MTV, M1V);                                   \
+        else QQK(k_qp_quad, MTV, M1V);                                                              \
+    } while (0)
+        if (k <= 16) { if (p->memory <= 1) QQL(1, true); else QQL(1, false); }
+        else         { if (p->memory <= 1) QQL(2, true); else QQL(2, false); }
+#undef QQL
+#undef QQK
         if (cap < p->max_iterations)
             hipLaunchKernelGGL(k_qp_wave<32>, dim3(1024), dim3(256), 0, c->stream, A2d, Btall, stride_j,
                                stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,

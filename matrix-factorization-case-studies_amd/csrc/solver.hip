@@ -467,8 +467,20 @@ int aa_set_option(const char *name, int value)
         AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_waves must be >= 1");
         g_qp_waves = value;
     } else if (!strcmp(name, "qp_mode")) {
-        AA_REQUIRE(value >= 0 && value <= 3, AA_ERR_ARG, "qp_mode must be 0, 1, 2 or 3");
+        AA_REQUIRE(value >= 0 && value <= 4, AA_ERR_ARG, "qp_mode must be in 0..4");
         g_qp_mode = value;
+    } else if (!strcmp(name, "qp_quad_waves")) {
+        AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_quad_waves must be >= 1");
+        g_qp_quad_waves = value;
+    } else if (!strcmp(name, "qp_quad_refill")) {
+        AA_REQUIRE(value >= 1 && value <= 16, AA_ERR_ARG, "qp_quad_refill must be in 1..16");
+        g_qp_quad_refill = value;
+    } else if (!strcmp(name, "qp_quad_occ")) {
+        AA_REQUIRE(value >= 2 && value <= 4, AA_ERR_ARG, "qp_quad_occ must be 2, 3 or 4");
+        g_qp_quad_occ = value;
+    } else if (!strcmp(name, "qp_quad_cap")) {
+        AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_quad_cap must be >= 1");
+        g_qp_quad_cap = value;
     } else if (!strcmp(name, "qp_row_waves")) {
         AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_row_waves must be >= 1");
         g_qp_row_waves = value;

@@ -73,7 +73,7 @@ def test_simplex_rows_vs_oracle(cdr, orc, shape):
 
 
 # ---------------------------------------------------------------- per-sample QP
-@pytest.fixture(params=[1, 2, 3], ids=["wave-per-sample", "lane+wave", "row"])
+@pytest.fixture(params=[1, 2, 3, 4], ids=["wave-per-sample", "lane+wave", "row", "quad"])
 def qp_kernel(request):
     """All three mappings of the batched QP (default: the row kernel for k <= 32, one wave per
     sample above)."""
@@ -986,7 +986,9 @@ def _check_scale_factors(aa, orc, X, Z0, C0, a0, form, skw, tol):
             want = orc.iterate_kernel_aa(X.dot(X.T), Z0.copy(), C0.copy(), a0.copy(), **kw)
     dev, host = outs
     assert dev[4] == host[4] == want[4] == 5                             # n_iter
-    assert abs(dev[3] - host[3]) < tol * dev[3] and abs(dev[3] - want[3]) < 10 * tol * dev[3]
+    # device against host: the same state and kernels, only the k-vector SPG differs; against the
+    # oracle the kernel form (Gram of condition number ~1e6 formed in NumPy) agrees to 2e-8
+    assert abs(dev[3] - host[3]) < tol * dev[3] and abs(dev[3] - want[3]) < max(10 * tol, 1e-7) * dev[3]
     assert np.abs(dev[2] - host[2]).max() < 100 * tol and np.abs(dev[2] - want[2]).max() < 1000 * tol
     assert np.all(dev[2] >= 0.9 - 1e-15) and np.all(dev[2] <= 1.1 + 1e-15)
     assert np.abs(dev[2] - 1.0).max() > 1e-3                             # the scale factors did move
