@@ -642,6 +642,29 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
 // 64-sample wave hostage.  memory == 1 only on the continuation path (the host keeps
 // samples in phase 1 otherwise); fresh samples support any memory.
 // ---------------------------------------------------------------------------
+// lane exchange across rows of 16 / halves of 32 (gfx950 v_permlane16_swap / v_permlane32_swap)
+typedef unsigned int qq_u2 __attribute__((ext_vector_type(2)));
+
+template <bool R32>
+__device__ __forceinline__ void qq_xchg(unsigned int v, unsigned int &a, unsigned int &b)
+{
+    // both operands = v: afterwards `a` holds the lower partner's word and `b` the upper partner's
+    // in BOTH lanes of a pair (rows r / r^1 for permlane16, halves for permlane32)
+    qq_u2 r;
+    if constexpr (R32) r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    else r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    a = r[0];
+    b = r[1];
+}
+template <bool R32>
+__device__ __forceinline__ void qq_xchg_d(double v, double &a, double &b)
+{
+    unsigned int la, lb, ha, hb;
+    qq_xchg<R32>((unsigned int)__double2loint(v), la, lb);
+    qq_xchg<R32>((unsigned int)__double2hiint(v), ha, hb);
+    a = __hiloint2double((int)ha, (int)la);
+    b = __hiloint2double((int)hb, (int)lb);
+}
 // Wave-wide reductions on the DPP crossbar (no LDS traffic): inclusive row scan with
 // row_shr 1/2/4/8, then row_bcast15 / row_bcast31 carry the row totals upward; the total
 // ends in lane 63 and is broadcast through an SGPR.  Fixed order => deterministic.
@@ -717,18 +740,23 @@ __device__ __forceinline__ double qw_max(double v)
 // a component): the support-mask fixed point described at qp_project_threshold, the mask
 // being a wave-uniform bit set (one reduction per round; a confirmed warm support costs
 // exactly one).  Division-free comparison w*|S| > sum_S - 1.
+// cold start of the support ({w > max - 1}); out of line: inlined, hipcc runs its max-scan
+// speculatively in EVERY Michelot round (45 instructions of a latency-bound loop)
+template <bool HALF>
+__device__ __attribute__((noinline)) unsigned long long qw_cold_support(double w)
+{
+    const double t0 = qw_max<HALF>(w) - 1.0;
+    return __ballot(w > t0) & (HALF ? 0xffffffffull : ~0ull);
+}
 template <bool HALF>
 __device__ __forceinline__ double qw_threshold(double w, int comp, unsigned long long &mask)
 {
-    const unsigned long long full = HALF ? 0xffffffffull : ~0ull;
     unsigned long long m = mask;
     double s = 0.0;
     int c = 1;
+    const unsigned long long full = HALF ? 0xffffffffull : ~0ull;
     for (int pass = 0; pass < 136; ++pass) {
-        if (m == 0ull) {                       // cold start, or the warm guess emptied
-            const double t0 = qw_max<HALF>(w) - 1.0;
-            m = __ballot(w > t0) & full;
-        }
+        if (__builtin_expect(m == 0ull, 0)) m = qw_cold_support<HALF>(w);   // first projection, or the warm guess emptied
         const bool in = (m >> comp) & 1ull;
         c = __popcll(m);
         s = qw_sum<HALF>(in ? w : 0.0);
@@ -785,6 +813,49 @@ __device__ __forceinline__ double qw_matvec_half(const double (&Ahalf)[16], doub
     return hi ? other + part : part + other;       // columns 0..15 first in both lanes
 }
 
+// The same product on the DPP crossbar (k <= 32, default): v_fmac_f64 with row_newbcast:N
+// multiplies lane N of the caller's ROW into the whole row -- one instruction per column instead
+// of four v_readlane, their moves and two selects.  A row of 16 lanes only sees its own 16
+// components of v, so rows 2 and 3 (the mirror half) first swap theirs (v_permlane16_swap):
+//   row 0: components  0..15 x columns  0..15      row 2: components  0..15 x columns 16..31
+//   row 1: components 16..31 x columns 16..31      row 3: components 16..31 x columns  0..15
+// and the two halves of (A v)_i meet through v_permlane32_swap; both mirror lanes add the same
+// two numbers.  Acol: the 16 entries of row `component` in this lane's column block.
+__device__ __forceinline__ double qw_matvec_bcast(const double (&Acol)[16], double v, int lane)
+{
+    const bool odd_block = ((lane >> 4) == 1) || ((lane >> 4) == 2);      // this row sees columns 16..31
+    qq_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned int)__double2loint(v), (unsigned int)__double2loint(v), false, false);
+    qq_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned int)__double2hiint(v), (unsigned int)__double2hiint(v), false, false);
+    // [0]: rows {0,0,2,2} of v, [1]: rows {1,1,3,3}; the mirror rows equal rows 0 and 1
+    const double vs = odd_block ? __hiloint2double((int)hi[1], (int)lo[1]) : __hiloint2double((int)hi[0], (int)lo[0]);
+    double a0 = 0.0, a1 = 0.0;
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a0), "+v"(a1)
+                 : "v"(vs), "v"(Acol[0]), "v"(Acol[1]), "v"(Acol[2]), "v"(Acol[3]), "v"(Acol[4]), "v"(Acol[5]),
+                   "v"(Acol[6]), "v"(Acol[7]), "v"(Acol[8]), "v"(Acol[9]), "v"(Acol[10]), "v"(Acol[11]),
+                   "v"(Acol[12]), "v"(Acol[13]), "v"(Acol[14]), "v"(Acol[15]));
+    const double part = a0 + a1;
+    double pa, pb;
+    qq_xchg_d<true>(part, pa, pb);                 // lanes l and l ^ 32
+    return pa + pb;
+}
+
 template <int KQ>
 __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*[KQ][KQ]*/,
                                                  const double *__restrict__ B, long stride_j,
@@ -807,10 +878,12 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
     // row `comp` of A in registers (mirrored form: each of the two lanes of a component keeps
     // one half of the row)
     double Arow[HALF ? 16 : KQ];
+    // HALF: rows 1 and 2 of the wave take columns 16..31 (see qw_matvec_bcast)
+    const int col0 = HALF ? ((((lane >> 4) == 1) || ((lane >> 4) == 2)) ? 16 : 0) : 0;
 #pragma unroll
-    for (int j = 0; j < (HALF ? 16 : KQ); ++j) Arow[j] = A[comp * KQ + (HALF ? 16 * (lane >> 5) : 0) + j];
+    for (int j = 0; j < (HALF ? 16 : KQ); ++j) Arow[j] = A[comp * KQ + col0 + j];
     auto matvec = [&](double v) -> double {
-        if constexpr (HALF) return qw_matvec_half(Arow, v, lane);
+        if constexpr (HALF) return qw_matvec_bcast(Arow, v, lane);
         else return qw_matvec<KQ>(Arow, v);
     };
     const int mem = p.memory < 1 ? 1 : (p.memory > QP_MAXMEM ? QP_MAXMEM : p.memory);
@@ -873,14 +946,16 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             const double Ad = matvec(d);
             const double dAd = qw_sum<HALF>(d * Ad);
 
-#pragma unroll
-            for (int i = QP_MAXMEM - 1; i > 0; --i)
-                if (i < mem) fmem[i] = fmem[i - 1];
-            fmem[0] = f;
             double f_max = f;
+            if (mem > 1) {                         // memory == 1 (the default): f_max = f
 #pragma unroll
-            for (int i = 1; i < QP_MAXMEM; ++i)
-                if (i < mem && fmem[i] > f_max) f_max = fmem[i];
+                for (int i = QP_MAXMEM - 1; i > 0; --i)
+                    if (i < mem) fmem[i] = fmem[i - 1];
+                fmem[0] = f;
+#pragma unroll
+                for (int i = 1; i < QP_MAXMEM; ++i)
+                    if (i < mem && fmem[i] > f_max) f_max = fmem[i];
+            }
 
             double lam = 1.0;
             double f_new = f + lam * delta + 0.5 * lam * lam * dAd;
@@ -1440,28 +1515,6 @@ __global__ __launch_bounds__(64) void k_qp_row(const double *__restrict__ A /*[l
 // along with their results discarded).  Samples that reach the pass cap are parked for the
 // wave-per-sample kernel exactly as in k_qp.
 // ---------------------------------------------------------------------------
-typedef unsigned int qq_u2 __attribute__((ext_vector_type(2)));
-
-template <bool R32>
-__device__ __forceinline__ void qq_xchg(unsigned int v, unsigned int &a, unsigned int &b)
-{
-    // both operands = v: afterwards `a` holds the lower partner's word and `b` the upper partner's
-    // in BOTH lanes of a pair (rows r / r^1 for permlane16, halves for permlane32)
-    qq_u2 r;
-    if constexpr (R32) r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    else r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    a = r[0];
-    b = r[1];
-}
-template <bool R32>
-__device__ __forceinline__ void qq_xchg_d(double v, double &a, double &b)
-{
-    unsigned int la, lb, ha, hb;
-    qq_xchg<R32>((unsigned int)__double2loint(v), la, lb);
-    qq_xchg<R32>((unsigned int)__double2hiint(v), ha, hb);
-    a = __hiloint2double((int)ha, (int)la);
-    b = __hiloint2double((int)hb, (int)lb);
-}
 __device__ __forceinline__ double qq_sum(double v)      // over the four lanes of a sample
 {
     double a, b;

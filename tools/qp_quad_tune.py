@@ -34,26 +34,20 @@ def run(label, state, reps=4, **opts):
 
 if only_mode is not None:
     state = [s for s in states if s.startswith(only_state)][0]
-    run("mode %d" % only_mode, state, reps=6, qp_mode=only_mode, qp_quad_refill=16)
+    run("mode %d" % only_mode, state, reps=6, qp_mode=only_mode)
     ctx.close(); sys.exit(0)
 for state in states:
     if only_state and not state.startswith(only_state): continue
     ref, tot_ref = run("lane+wave (mode 2)", state, qp_mode=2)
-    base = dict(qp_mode=4, qp_quad_cap=24, qp_quad_refill=16, qp_quad_long=0, qp_side_cus=0)
-    for label, opts in (("quad occ 2, 2048 waves", dict(qp_quad_occ=2, qp_quad_waves=2048)),
-                        ("quad occ 2, 4096 waves", dict(qp_quad_occ=2, qp_quad_waves=4096)),
-                        ("quad occ 3, 3072 waves", dict(qp_quad_occ=3, qp_quad_waves=3072)),
-                        ("quad occ 3, 6144 waves", dict(qp_quad_occ=3, qp_quad_waves=6144)),
+    base = dict(qp_mode=4, qp_quad_cap=24, qp_quad_refill=16, qp_quad_occ=3, qp_quad_waves=3072)
+    for label, opts in (("quad occ 3, 3072 waves", {}),
+                        ("quad occ 2, 2048 waves", dict(qp_quad_occ=2, qp_quad_waves=2048)),
                         ("quad occ 4, 4096 waves", dict(qp_quad_occ=4, qp_quad_waves=4096)),
-                        ("quad occ 3 refill 8", dict(qp_quad_occ=3, qp_quad_waves=3072, qp_quad_refill=8)),
-                        ("quad occ 3 cap 32", dict(qp_quad_occ=3, qp_quad_waves=3072, qp_quad_cap=32)),
-                        ("quad occ 3 long 48", dict(qp_quad_occ=3, qp_quad_waves=3072, qp_quad_long=48)),
-                        ("quad occ 3 long 32", dict(qp_quad_occ=3, qp_quad_waves=3072, qp_quad_long=32)),
-                        ("quad occ 3 long 48 side 32 CUs", dict(qp_quad_occ=3, qp_quad_waves=3072, qp_quad_long=48, qp_side_cus=32)),
-                        ("quad occ 3 long 32 side 32 CUs", dict(qp_quad_occ=3, qp_quad_waves=3072, qp_quad_long=32, qp_side_cus=32)),
-                        ("quad occ 3 long 32 side 64 CUs", dict(qp_quad_occ=3, qp_quad_waves=3072, qp_quad_long=32, qp_side_cus=64)),
-                        ("quad occ 3 long 24 side 64 CUs", dict(qp_quad_occ=3, qp_quad_waves=3072, qp_quad_long=24, qp_side_cus=64)),
-                        ("quad occ 3 long 48 side 16 CUs", dict(qp_quad_occ=3, qp_quad_waves=3072, qp_quad_long=48, qp_side_cus=16))):
+                        ("quad refill 8", dict(qp_quad_refill=8)),
+                        ("quad refill 1", dict(qp_quad_refill=1)),
+                        ("quad cap 16", dict(qp_quad_cap=16)),
+                        ("quad cap 32", dict(qp_quad_cap=32)),
+                        ("quad cap 48", dict(qp_quad_cap=48))):
         o = dict(base); o.update(opts)
         got, tot = run(label, state, **o)
         print("     vs lane+wave: max |dZ| %.2e, total passes %d vs %d" % (np.abs(got - ref).max(), tot, tot_ref), flush=True)
