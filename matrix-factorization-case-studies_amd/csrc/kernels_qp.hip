@@ -1890,7 +1890,8 @@ int g_qp_refill_min = 64;      // idle lanes of a wave that trigger a refill (1.
 int g_qp_mode = 0;             // 0: by size (see launch_qp), 1: wave-per-sample only,
                                // 2: lane-per-sample then wave-per-sample, 3: row kernel,
                                // 4: four lanes per sample (matrix-core layout) then wave-per-sample
-int g_qp_quad_waves = 3072;    // most waves of k_qp_quad (three per SIMD, all resident)
+int g_qp_quad_waves = 8192;    // most waves of k_qp_quad: up to 131 072 samples every wave takes ONE batch of 16
+                               // and the hardware hands the batches (longest first) to SIMDs as they free up
 int g_qp_quad_refill = 16;     // idle sample slots (of 16) of a wave that trigger a refill
 int g_qp_quad_cap = 24;        // passes after which k_qp_quad parks a sample for the wave kernel
 int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)

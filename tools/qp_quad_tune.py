@@ -39,16 +39,12 @@ if only_mode is not None:
 for state in states:
     if only_state and not state.startswith(only_state): continue
     ref, tot_ref = run("lane+wave (mode 2)", state, qp_mode=2)
-    base = dict(qp_mode=4, qp_quad_cap=24, qp_quad_refill=16, qp_quad_occ=3, qp_quad_waves=3072)
+    base = dict(qp_mode=4, qp_quad_cap=24, qp_quad_occ=3, qp_quad_waves=3072)
     for label, opts in (("quad occ 3, 3072 waves", {}),
-                        ("quad occ 2, 2048 waves", dict(qp_quad_occ=2, qp_quad_waves=2048)),
-                        ("quad occ 4, 4096 waves", dict(qp_quad_occ=4, qp_quad_waves=4096)),
-                        ("quad refill 8", dict(qp_quad_refill=8)),
-                        ("quad refill 1", dict(qp_quad_refill=1)),
-                        ("quad cap 16", dict(qp_quad_cap=16)),
-                        ("quad cap 32", dict(qp_quad_cap=32)),
-                        ("quad cap 48", dict(qp_quad_cap=48))):
+                        ("quad occ 3, 6250 waves", dict(qp_quad_waves=6250)),
+                        ("quad occ 3, 4608 waves", dict(qp_quad_waves=4608)),
+                        ("quad occ 4, 6250 waves", dict(qp_quad_occ=4, qp_quad_waves=6250)),
+                        ("quad occ 2, 6250 waves", dict(qp_quad_occ=2, qp_quad_waves=6250))):
         o = dict(base); o.update(opts)
-        got, tot = run(label, state, **o)
-        print("     vs lane+wave: max |dZ| %.2e, total passes %d vs %d" % (np.abs(got - ref).max(), tot, tot_ref), flush=True)
+        got, tot = run(label, state, reps=7, **o)
 ctx.close()
