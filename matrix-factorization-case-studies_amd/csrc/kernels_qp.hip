@@ -740,28 +740,46 @@ __device__ __forceinline__ double qw_max(double v)
 // a component): the support-mask fixed point described at qp_project_threshold, the mask
 // being a wave-uniform bit set (one reduction per round; a confirmed warm support costs
 // exactly one).  Division-free comparison w*|S| > sum_S - 1.
+// a wave-uniform 64-bit value, told to the compiler (it then lives in an SGPR pair and the
+// branches on it are scalar; hipcc otherwise keeps the support masks in VGPRs and predicates)
+__device__ __forceinline__ unsigned long long qw_uniform64(unsigned long long v)
+{
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// w on the lanes of the mask, 0 elsewhere: the mask goes straight into v_cndmask as its lane mask
+__device__ __forceinline__ double qw_select(unsigned long long lanes, double w)
+{
+    int lo, hi;
+    asm("v_cndmask_b32_e64 %0, 0, %2, %4\n\tv_cndmask_b32_e64 %1, 0, %3, %4"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"(__double2loint(w)), "v"(__double2hiint(w)), "s"(lanes));
+    return __hiloint2double(hi, lo);
+}
 // cold start of the support ({w > max - 1}); out of line: inlined, hipcc runs its max-scan
 // speculatively in EVERY Michelot round (45 instructions of a latency-bound loop)
 template <bool HALF>
 __device__ __attribute__((noinline)) unsigned long long qw_cold_support(double w)
 {
     const double t0 = qw_max<HALF>(w) - 1.0;
-    return __ballot(w > t0) & (HALF ? 0xffffffffull : ~0ull);
+    return __ballot(w > t0);
 }
+// Threshold of the projection of the wave-distributed vector w (w = -inf on lanes without a
+// component).  The support is kept as a LANE mask (k <= 32: both mirror halves set), which is
+// what __ballot returns and what v_cndmask consumes.
 template <bool HALF>
 __device__ __forceinline__ double qw_threshold(double w, int comp, unsigned long long &mask)
 {
-    unsigned long long m = mask;
+    unsigned long long m = qw_uniform64(mask);
     double s = 0.0;
     int c = 1;
-    const unsigned long long full = HALF ? 0xffffffffull : ~0ull;
     for (int pass = 0; pass < 136; ++pass) {
-        if (__builtin_expect(m == 0ull, 0)) m = qw_cold_support<HALF>(w);   // first projection, or the warm guess emptied
-        const bool in = (m >> comp) & 1ull;
-        c = __popcll(m);
-        s = qw_sum<HALF>(in ? w : 0.0);
-        const unsigned long long nm = __ballot(w * (double)c > s - 1.0) & full;
-        if (nm == m || (pass >= 2 && (int)__popcll(nm) >= c)) break;
+        if (__builtin_expect(m == 0ull, 0)) m = qw_uniform64(qw_cold_support<HALF>(w));   // first projection, or the warm guess emptied
+        c = HALF ? __popc((unsigned int)m) : __popcll(m);
+        s = qw_sum<HALF>(qw_select(m, w));
+        const unsigned long long nm = __ballot(w * (double)c > s - 1.0);
+        if (nm == m || (pass >= 2 && (HALF ? __popc((unsigned int)nm) : __popcll(nm)) >= c)) break;
         m = nm;
     }
     mask = m;

@@ -11,7 +11,10 @@ def short(n):
 names = [short(r["Kernel_Name"]) for r in rows]
 # iteration boundaries: launches of the dictionary set-up kernel (fast path) or k_scale_gram
 marks = [i for i, nm in enumerate(names) if nm.startswith("k_dict_setup") or nm.startswith("k_scale_gram")]
-marks = marks[-(last + 12):-11] if len(marks) > last + 12 else marks[:-1]   # skip the 10 timed-gemm iterations at the end
+if len(sys.argv) > 3:        # [n] [skip]: n iterations after the first `skip` of the trace (the timed window)
+    skip = int(sys.argv[3]); marks = marks[skip:skip + last + 1]
+else:
+    marks = marks[-(last + 12):-11] if len(marks) > last + 12 else marks[:-1]   # skip the 10 timed-gemm iterations at the end
 if len(marks) < 3:
     print("too few iterations in trace"); sys.exit(0)
 a, b = marks[0], marks[-1]
