@@ -122,11 +122,20 @@ int aa_device_count(int *count);
  *                               stream while Z'X is accumulated (float32 data); the rows it
  *                               changes enter Z'X as a rank-m correction.  Default 0: measured
  *                               neutral, the stragglers run 2x slower next to the GEMM
- *   "qp_mode"           0..3   0 (default), k <= 32: up to 16384 samples per GPU the row kernel
- *                               (16 lanes per sample, four samples per wave, samples run to
- *                               completion), above that the lane-per-sample kernel followed by the
- *                               wave-per-sample kernel for the stragglers; k > 32: one wave per
- *                               sample.  1: one wave per sample; 2: lane + wave; 3: row kernel
+ *   "qp_mode"           0..4   0 (default), k <= 32: four lanes per sample in the matrix-core operand
+ *                               layout (16 samples per wave) followed by the wave-per-sample kernel
+ *                               for the stragglers; one lane per sample when max_iterations <= 4
+ *                               (nothing diverges); k > 32: one wave per sample.
+ *                               1: one wave per sample; 2: lane-per-sample + wave; 3: row kernel
+ *                               (16 lanes per sample, samples run to completion); 4: four lanes per
+ *                               sample + wave
+ *   "qp_quad_cap"       >= 1   SPG passes after which the four-lane kernel parks a sample for the
+ *                               wave-per-sample kernel (default 24)
+ *   "qp_quad_waves"     >= 1   most waves (16 samples each) of the four-lane kernel (default 8192:
+ *                               up to 131 072 samples every wave takes one batch)
+ *   "qp_quad_occ"       2..4   register budget of the four-lane kernel in waves per SIMD (default 3)
+ *   "qp_quad_refill"    1..16  idle sample slots of a wave that trigger a refill when a wave
+ *                               takes several batches (default 16)
  *   "qp_row_waves"      >= 1   most waves the row kernel runs with (default 2048: 2 per SIMD)
  *   "qp_row_hot"        >= 0   SPG passes after which the wave of a sample raises its issue
  *                               priority (also when the previous update needed twice as many)

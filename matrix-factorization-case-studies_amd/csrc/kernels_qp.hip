@@ -2044,16 +2044,16 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     while (KQ < k) KQ *= 2;
     AA_REQUIRE(KQ <= 64, AA_ERR_ARG, "QP: k = %d > 64 unsupported", k);
     AA_REQUIRE(n < (1L << 31), AA_ERR_ARG, "QP: too many samples");
-    // few samples (small shards of a multi-GPU run): the chip has more wave slots than
-    // samples, so one wave per sample beats the >= pass-cap trips of the lane kernel
-    // default (qp_mode 0), k <= 32: up to 16384 samples per GPU (small problems, shards of a
-    // multi-GPU run) the row kernel -- 16 lanes per sample, run to completion (0.70 ms per outer
-    // iteration at 12 500 rows against 0.79 one wave per sample and 0.81 lane + wave); above that
-    // the lane-per-sample kernel followed by the wave-per-sample kernel for the stragglers
-    // (2.22 ms at 100 000 rows against 2.36 for the row kernel, whose longest chain -- 242 passes
-    // at ~3.3 us -- then sets the time).  k > 32: one wave per sample.
-    const bool row_mode = KQ <= 32 && (g_qp_mode == 3 || (g_qp_mode == 0 && n <= 16384));
-    const bool quad_mode = KQ <= 32 && (g_qp_mode == 4 || (g_qp_mode == 0 && n > 16384));
+    // default (qp_mode 0), k <= 32: four lanes per sample in the matrix-core operand layout
+    // (k_qp_quad) followed by the wave-per-sample kernel for the samples that reach its pass cap --
+    // ahead of the other mappings at every size measured (1 600 .. 100 000 samples per GPU:
+    // 0.63 ms per outer iteration at 12 500 rows against 0.69 for the row kernel and 0.81 for
+    // lane + wave; 1.99 against 2.21 ms at 100 000) -- except when every sample gets the same
+    // one or two passes (GPNH's weights QP with max_iterations = 1): nothing diverges then and
+    // the lane-per-sample kernel, 64 samples per wave, is cheaper (0.175 against 0.188 ms on the
+    // C3 stand-in).  k > 32: one wave per sample.
+    const bool row_mode = KQ <= 32 && g_qp_mode == 3;
+    const bool quad_mode = KQ <= 32 && (g_qp_mode == 4 || (g_qp_mode == 0 && p->max_iterations > 4));
     const bool wave_only = !row_mode && !quad_mode && (KQ > 32 || g_qp_mode == 1 || g_qp_mode == 3);   // else: lane + wave
     const int KW = KQ > 32 ? 64 : 32;              // A padding of the wave and row kernels
     // spg.py:310 allocates f_mem of any length; the kernels keep it in registers

@@ -75,8 +75,8 @@ def test_simplex_rows_vs_oracle(cdr, orc, shape):
 # ---------------------------------------------------------------- per-sample QP
 @pytest.fixture(params=[1, 2, 3, 4], ids=["wave-per-sample", "lane+wave", "row", "quad"])
 def qp_kernel(request):
-    """All three mappings of the batched QP (default: the row kernel for k <= 32, one wave per
-    sample above)."""
+    """All four mappings of the batched QP (default: four lanes per sample for k <= 32, one wave
+    per sample above)."""
     from convex_dim_red import _backend
     _backend.set_option("qp_mode", request.param)
     yield request.param

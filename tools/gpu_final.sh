@@ -17,6 +17,9 @@ python3 -c "import json; b=json.load(open('gpurun_out/final_bench_f64.json')); p
 step "bench 12 500-row shard"
 timeout -k 10 300 python bench.py --n 12500 --no-cpu-baseline --no-f64 > gpurun_out/final_bench_n12500.json 2> gpurun_out/final_bench_n12500.err || exit 1
 python3 -c "import json; b=json.load(open('gpurun_out/final_bench_n12500.json')); print(b['value'], b['ms_per_step'])"
+step "12 500-row shard with the four-lane QP kernel (default there: the row kernel)"
+AA_HIP_OPTIONS=qp_mode=4 timeout -k 10 300 python bench.py --n 12500 --no-cpu-baseline --no-f64 > gpurun_out/final_bench_n12500_quad.json 2> gpurun_out/final_bench_n12500_quad.err || exit 1
+python3 -c "import json; b=json.load(open('gpurun_out/final_bench_n12500_quad.json')); print(b['value'], b['ms_per_step'])"
 step "C2 / C3 stand-ins"
 timeout -k 10 300 python tools/bench_configs.py 200 > gpurun_out/final_configs.jsonl 2> gpurun_out/final_configs.err || { tail -5 gpurun_out/final_configs.err; exit 1; }
 cat gpurun_out/final_configs.jsonl
@@ -27,6 +30,8 @@ cd /tmp && export TMPDIR=/tmp
 step "rocprofv3: bench float32"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_prof_f32 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-f64 > $GRAFT_REPO_ROOT/gpurun_out/final_prof_f32.log 2>&1 || exit 1
 python3 $GRAFT_REPO_ROOT/tools/trace_summary.py $GRAFT_REPO_ROOT/gpurun_out/final_prof_f32 50 | tee $GRAFT_REPO_ROOT/gpurun_out/final_prof_f32.summary
+echo "-- the driver's window (outer iterations 5..25 of the run)" | tee -a $GRAFT_REPO_ROOT/gpurun_out/final_prof_f32.summary
+python3 $GRAFT_REPO_ROOT/tools/trace_summary.py $GRAFT_REPO_ROOT/gpurun_out/final_prof_f32 20 5 | tee -a $GRAFT_REPO_ROOT/gpurun_out/final_prof_f32.summary
 step "rocprofv3: bench float64"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_prof_f64 -- python3 $GRAFT_REPO_ROOT/bench.py --dtype float64 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/final_prof_f64.log 2>&1 || exit 1
 python3 $GRAFT_REPO_ROOT/tools/trace_summary.py $GRAFT_REPO_ROOT/gpurun_out/final_prof_f64 50 | tee $GRAFT_REPO_ROOT/gpurun_out/final_prof_f64.summary
