@@ -595,10 +595,14 @@ __device__ __forceinline__ int rl_phys_chunk(int row, int chunk)
     else return chunk ^ ((row >> 1) & 7);
 }
 
+// blockIdx.y: column chunk of `col_chunk` columns (a multiple of TC), partial result to
+// out + blockIdx.y * n_pad * KP, summed in a fixed order by k_sum_chunks -- short shards (the
+// 12 500 rows of an 8-GPU run are 98 row blocks) otherwise leave most CUs idle.
 template <int NCT, int TC, bool DB>
 __global__ __launch_bounds__(256) void k_row_local_f32_blk(const float *__restrict__ X, long ldx,
                                                            const float *__restrict__ B, int p_pad,
-                                                           double *__restrict__ out, long n_pad)
+                                                           double *__restrict__ out, long n_pad,
+                                                           int col_chunk)
 {
     constexpr int KP = 32 * NCT;
     constexpr int CPR = TC / 4;                  // 16-byte chunks per tile row
@@ -662,13 +666,16 @@ __global__ __launch_bounds__(256) void k_row_local_f32_blk(const float *__restri
         }
     };
 
-    load_tile(0);
+    const int c_begin = (int)blockIdx.y * col_chunk;
+    const int c_end = c_begin + col_chunk < p_pad ? c_begin + col_chunk : p_pad;
+    out += (size_t)blockIdx.y * (size_t)n_pad * KP;
+    load_tile(c_begin);
     if constexpr (DB) {
         store_tile(0);
         __syncthreads();
         int buf = 0;
-        for (int c0 = 0; c0 < p_pad; c0 += TC) {
-            const bool more = c0 + TC < p_pad;
+        for (int c0 = c_begin; c0 < c_end; c0 += TC) {
+            const bool more = c0 + TC < c_end;
             if (more) load_tile(c0 + TC);
             __builtin_amdgcn_sched_barrier(0);
             compute_tile(buf);
@@ -677,10 +684,10 @@ __global__ __launch_bounds__(256) void k_row_local_f32_blk(const float *__restri
             buf ^= 1;
         }
     } else {
-        for (int c0 = 0; c0 < p_pad; c0 += TC) {
+        for (int c0 = c_begin; c0 < c_end; c0 += TC) {
             store_tile(0);
             __syncthreads();
-            if (c0 + TC < p_pad) load_tile(c0 + TC);
+            if (c0 + TC < c_end) load_tile(c0 + TC);
             __builtin_amdgcn_sched_barrier(0);
             compute_tile(0);
             __syncthreads();
@@ -1127,10 +1134,29 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
                                c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, g_row_local_stagger);
     } else if (c->dtype == AA_F32 && row_local_variant(c) >= 2) {
         const float *B = reinterpret_cast<const float *>(B_wideT);
-        dim3 grid((unsigned)(c->n_pad / 128));
+        // few row blocks (short shards): split the contraction over column chunks as well, about
+        // three blocks per CU, chunks of >= 512 columns (a multiple of every tile width)
+        const long rblocks = c->n_pad / 128;
+        int nsplit = 1, chunk = (int)c->p_pad;
+        if (rblocks < 384) {
+            nsplit = (int)((768 + rblocks - 1) / rblocks);
+            const int max_split = (int)(c->p_pad / 512);
+            if (nsplit > max_split) nsplit = max_split;
+            if (nsplit < 1) nsplit = 1;
+        }
+        double *dst = out_tall;
+        if (nsplit > 1) {
+            chunk = (int)round_up((c->p_pad + nsplit - 1) / nsplit, 128);
+            nsplit = (int)((c->p_pad + chunk - 1) / chunk);
+        }
+        if (nsplit > 1) {
+            AA_CHECK(c->rlPartial.alloc((size_t)nsplit * c->n_pad * c->KP * sizeof(double)));
+            dst = c->rlPartial.as<double>();
+        }
+        dim3 grid((unsigned)rblocks, (unsigned)nsplit);
 #define RLB(NCTV, TCV, DBV)                                                                   \
     hipLaunchKernelGGL((k_row_local_f32_blk<NCTV, TCV, DBV>), grid, block, 0, c->stream,       \
-                       c->X.as<float>(), c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad)
+                       c->X.as<float>(), c->p_pad, B, (int)c->p_pad, dst, c->n_pad, chunk)
         const int v = row_local_variant(c);
         if (c->KP == 32) {
             switch (v) {
@@ -1148,6 +1174,11 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
             }
         }
 #undef RLB
+        if (nsplit > 1) {
+            const long elems = c->n_pad * c->KP;
+            hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
+                               (const double *)dst, elems, nsplit, out_tall);
+        }
     } else if (c->dtype == AA_F32 && row_local_variant(c) == 1) {
         const float *B = reinterpret_cast<const float *>(B_wideT);
         dim3 grid((unsigned)(c->n_pad / 128));
