@@ -26,7 +26,9 @@ import warnings
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_CLIB_PATH = os.path.join(_HERE, "_build", "libaa_oracle.so")
+# AA_ORACLE_CLIB: another build of oracle/c/aa_oracle.c (the AddressSanitizer build of
+# tests/test_oracle_golden.py::test_oracle_c_under_address_sanitizer)
+_CLIB_PATH = os.environ.get("AA_ORACLE_CLIB") or os.path.join(_HERE, "_build", "libaa_oracle.so")
 
 
 # --------------------------------------------------------------------------
