@@ -458,6 +458,43 @@ def test_qp_sizes_vs_oracle(cdr, orc, qp_kernel, k):
             assert np.array_equal(it, wit)
 
 
+@pytest.mark.parametrize("k,n", [(6, 5), (13, 17), (31, 333), (32, 64)])
+@pytest.mark.parametrize("memory", [3, 8])
+def test_qp_nonmonotone_memory_vs_oracle(cdr, orc, qp_kernel, k, n, memory):
+    """spg.py:310,341-344: the reference value of the Armijo test is the maximum of the last
+    `memory` objective values.  Every mapping keeps that history in registers; fewer samples than
+    a wave has slots, padded component counts and a full 32 are all in here."""
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(100 * k + memory)
+    p = 2 * k + 3
+    W = rng.standard_normal((k, p)) * (1.0 + 5.0 * rng.rand(k, 1))      # uneven scales: back-tracking happens
+    Zt = orc.right_stochastic_matrix((n, k), rng) ** 3
+    Zt /= Zt.sum(axis=1, keepdims=True)
+    Xs = Zt.dot(W) + 0.05 * rng.standard_normal((n, p))
+    A, B = W.dot(W.T), W.dot(Xs.T)
+    Z0 = orc.right_stochastic_matrix((n, k), rng)
+    for kw, tol in ((dict(max_iterations=8), 1e-9), ({}, 2e-6)):
+        got, it = _backend.qp_batch(A, B, Z0, "kn", return_iters=True, memory=memory, **kw)
+        want, wit = orc.qp_batch(A, B, Z0, "kn", return_iters=True, memory=memory, **kw)
+        assert np.abs(got - want).max() < tol * max(1.0, np.abs(A).max()), (k, kw)
+        _assert_simplex(got)
+        if kw:
+            assert np.array_equal(it, wit)
+        else:
+            # runs of 100-500 passes on a badly scaled Hessian: pass counts of individual samples
+            # move by tens with the last bit (the oracle's own 1-ulp twin does the same)
+            assert abs(it.mean() - wit.mean()) < 0.1 * wit.mean() + 1
+
+
+def test_qp_memory_beyond_the_register_budget_is_an_error(cdr, qp_kernel):
+    """A reference-legal `memory` the kernels cannot hold is refused, never clamped."""
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(3)
+    A = np.eye(4); B = rng.standard_normal((4, 10)); Z0 = np.full((10, 4), 0.25)
+    with pytest.raises(RuntimeError, match="memory"):
+        _backend.qp_batch(A, B, Z0, "kn", memory=17)
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("k", [40, 64])
 def test_dictionary_update_wide_k_vs_oracle(cdr, orc, dtype, k):
