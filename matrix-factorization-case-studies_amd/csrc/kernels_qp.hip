@@ -5,12 +5,20 @@
 // (spg.py:286-398) called from the serial loops at archetypal_analysis.py:359-366 and
 // gpnh_convex_coding.py:244-251.  A (k x k) is shared by all samples.
 //
-// Mapping: ONE LANE PER SAMPLE.  The whole SPG state of a sample (x, g = Ax + b, d,
-// Ad: 4*KQ doubles) lives in that lane's registers; A is read with wave-uniform
-// addresses (scalar loads / broadcast), so the k x k mat-vec costs KQ^2 v_fma_f64 per
-// 64 samples and there is no cross-lane traffic at all.  Samples finish after very
-// different numbers of iterations (heavy tail), so a lane that finishes pulls the next
-// sample from a global counter instead of idling until its wave is done.
+// Four mappings of the same per-sample loop (launch_qp picks; aa_set_option("qp_mode")):
+//   k_qp_quad  four lanes per sample in the f64 matrix cores' operand layout, 16 samples per
+//              wave, mat-vec = 16 MFMAs on registers as they are       (default, k <= 32)
+//   k_qp_wave  one wave per sample, DPP reductions, row_newbcast mat-vec: the low-latency
+//              kernel for the samples the others park at their pass cap; all of k > 32
+//   k_qp       one lane per sample, 64 samples per wave, mat-vec through LDS + MFMA
+//              (default when max_iterations <= 4: nothing diverges)
+//   k_qp_row   one DPP row of 16 lanes per sample, run to completion   (qp_mode 3)
+// Samples finish after very different numbers of passes (heavy tail: mean 14, max 100-450),
+// which is what the batching, the longest-first order and the parking are about.
+//
+// The lane kernel first.  The whole SPG state of a sample (x, g = Ax + b, d, Ad: 4*KQ
+// doubles) lives in that lane's registers, so there is no cross-lane traffic outside the
+// mat-vec; a lane that finishes waits for its batch (qp_refill_min).
 //
 // Restatement notes (each keeps the reference's decisions; differences are rounding):
 //   * f along the search direction is the exact quadratic
