@@ -230,6 +230,15 @@ int aa_dictionary_update(aa_ctx *ctx, const aa_spg_params *params, aa_spg_stats 
  * refresh at :640-643 (:501-503). */
 int aa_weights_update(aa_ctx *ctx, const aa_qp_params *params, aa_qp_stats *stats);
 
+/* KernelAA on the implicit linear kernel K = X X' (SURVEY 8(f4)): with `on` != 0 the resident
+ * DATA matrix X (n x p) stands in for the n x n kernel matrix of _iterate_kernel_aa
+ * (archetypal_analysis.py:399-531), which is never formed: every product with K runs as two
+ * skinny passes over X, exactly as in the data form, and the dictionary gradient follows the
+ * kernel form's convention (divided by n_components, _kernel_aa_dictionary_gradient :281-288,
+ * where _aa_dictionary_gradient :291-300 divides by n_samples) -- the one place where the two
+ * forms of the reference differ for K = X X'.  Reset by aa_set_data. */
+int aa_set_linear_kernel(aa_ctx *ctx, int on);
+
 /* Driver-side preprocessing on the device (bin/run_hadisst_aa.py:133-146 weight_and_flatten_data,
  * :196-209 NaN-column removal and training / validation split; the same steps in
  * bin/run_jra55_pca_gpnh.py).  `raw` is the flattened field, n_total x p_full, row-major

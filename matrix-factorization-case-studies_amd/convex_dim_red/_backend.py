@@ -101,6 +101,7 @@ _SIGNATURES = {
     "aa_set_data": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_long,
                                    ctypes.c_int, ctypes.c_long, ctypes.c_long]),
     "aa_data_trace": (ctypes.c_int, [_vp, _dp]),
+    "aa_set_linear_kernel": (ctypes.c_int, [_vp, ctypes.c_int]),
     "aa_set_data_weighted": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_long,
                                             _dp, ctypes.c_long, ctypes.c_long,
                                             ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_long)]),
@@ -345,6 +346,11 @@ class Context(object):
         _check(self.lib.aa_set_data(self.h, X.ctypes.data_as(_vp), host, n, p, p, form,
                                     n if n_global is None else n_global, row_offset))
         self.n, self.p = n, p
+
+    def set_linear_kernel(self, on):
+        """The resident data matrix X stands in for the kernel K = X X' of KernelAA
+        (aa_set_linear_kernel): kernel-form conventions, K never formed."""
+        _check(self.lib.aa_set_linear_kernel(self.h, 1 if on else 0))
 
     def set_data_weighted(self, raw, col_weights=None, row0=0, n=None):
         """Driver preprocessing on the device (aa_set_data_weighted): ``raw`` is the flattened

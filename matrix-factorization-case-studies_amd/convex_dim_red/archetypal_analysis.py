@@ -395,6 +395,64 @@ def _iterate_aa(X, weights, dictionary, alpha, delta=0,
                                   tolerance, max_iterations, verbose, **kwargs)
 
 
+def _fit_on_data_matrix(self, data, linear_kernel, label, dictionary=None, weights=None, alpha=None,
+                        update_dictionary=True, update_weights=True, update_scale_factors=True,
+                        **kwargs):
+    """Body of ``ArchetypalAnalysis._aa`` (reference :1036-1118) and of ``KernelAA`` on the
+    implicit linear kernel (``linear_kernel``: the data matrix stands in for K = X X')."""
+    on_device = isinstance(data, DeviceData)      # preprocessed on the GPU (preprocessing.py)
+    if not on_device:
+        data = np.asarray(data)
+    n_samples = data.shape[0]
+    if self.n_components is None:
+        self.n_components = data.shape[1]
+    self._check_hyper_parameters()
+    shape_only = _ShapeOnly(n_samples)
+
+    # the data matrix stays on the device between fits of the same array (the drivers' n_init
+    # restarts, bin/run_hadisst_aa.py:158-172): only the start factors travel
+    with (data.borrow() if on_device else
+          _backend.resident_context(data, form=_backend.FORM_DATA, dtype=self.dtype)) as ctx:
+
+        def init_dictionary():
+            init = 'furthest_sum' if self.init is None else self.init
+            if init == 'furthest_sum':
+                rng = self.random_state
+                start_index = kwargs.get('start_index', None)
+                if start_index is None:
+                    start_index = rng.randint(n_samples)
+                exclude = kwargs.get('exclude', None)
+                if exclude is None:
+                    exclude = np.array([], dtype='i8')
+                selected = _furthest_sum_on_device(
+                    ctx, n_samples, self.n_components, start_index,
+                    kwargs.get('n_extra_steps', 10), exclude)
+                return _one_hot_rows(selected, n_samples, np.float64)
+            return _initialize_kernel_aa_dictionary(shape_only, self.n_components, init=init,
+                                                    random_state=self.random_state)
+
+        dictionary, weights, alpha = self._resolve_factors(
+            n_samples, dictionary, weights, alpha, update_dictionary, update_weights,
+            init_dictionary,
+            lambda: _initialize_kernel_aa_weights(shape_only, self.n_components,
+                                                  init=self.init,
+                                                  random_state=self.random_state))
+        if kwargs.get('_draw_only', False):      # restarts.fit_restarts: start factors only
+            return dictionary, weights, alpha
+        self.weights = weights.copy()
+        self.dictionary = dictionary.copy()
+        self.alpha = alpha.copy()
+
+        ctx.set_linear_kernel(linear_kernel)         # the context may be a reused one
+        result = _iterate_on_device(
+            ctx, label, self.weights, self.dictionary, self.alpha, self.delta,
+            update_weights, update_dictionary, update_scale_factors, self.tolerance,
+            self.max_iterations, self.verbose, **self._solver_kwargs())
+        out = self._finish(result)
+        self._cx = ctx.archetypes()
+    return out
+
+
 # ----------------------------------------------------------------------------
 # estimators
 # ----------------------------------------------------------------------------
@@ -495,6 +553,18 @@ class KernelAA(_BaseAA):
     def _kernel_aa(self, kernel, dictionary=None, weights=None, alpha=None,
                    update_dictionary=True, update_weights=True,
                    update_scale_factors=True, **kwargs):
+        if kwargs.pop('features', False):
+            # `kernel` is the n x p feature matrix X (or a DeviceData) of the linear
+            # kernel K = X X', which is never formed -- n = 100 000 would be 80 GB.  Same
+            # algorithm, conventions and RNG order as the explicit-kernel path below; FurthestSum
+            # runs on ||x_i - x_j||^2 = K_ii - 2 K_ij + K_jj computed from X.
+            if self.n_components is None:
+                self.n_components = kernel.shape[0]
+            out = _fit_on_data_matrix(self, kernel, True, "Kernel AA", dictionary, weights, alpha,
+                                      update_dictionary, update_weights, update_scale_factors,
+                                      **kwargs)
+            self.__dict__.pop('_cx', None)
+            return out
         kernel = np.asarray(kernel)
         n_samples = kernel.shape[0]
         if kernel.shape[1] != n_samples:
@@ -521,7 +591,9 @@ class KernelAA(_BaseAA):
             max_iterations=self.max_iterations, verbose=self.verbose, **self._solver_kwargs()))
 
     def fit_transform(self, data, dictionary=None, weights=None, alpha=None, **kwargs):
-        """Factorise the kernel matrix ``data`` (n x n) and return the weights."""
+        """Factorise the kernel matrix ``data`` (n x n) and return the weights.  With
+        ``features=True`` (an extension of the reference's signature) ``data`` is the n x p
+        feature matrix of the linear kernel ``data.dot(data.T)``, which is then never formed."""
         self.cost, self.n_iter, self.avg_time_per_iter, self.cost_deltas = self._kernel_aa(
             data, dictionary=dictionary, weights=weights, alpha=alpha, **kwargs)
         return self.weights
@@ -550,56 +622,8 @@ class ArchetypalAnalysis(_BaseAA):
 
     def _aa(self, data, dictionary=None, weights=None, alpha=None,
             update_dictionary=True, update_weights=True, update_scale_factors=True, **kwargs):
-        on_device = isinstance(data, DeviceData)      # preprocessed on the GPU (preprocessing.py)
-        if not on_device:
-            data = np.asarray(data)
-        n_samples = data.shape[0]
-        if self.n_components is None:
-            self.n_components = data.shape[1]
-        self._check_hyper_parameters()
-        shape_only = _ShapeOnly(n_samples)
-
-        # the data matrix stays on the device between fits of the same array (the drivers' n_init
-        # restarts, bin/run_hadisst_aa.py:158-172): only the start factors travel
-        with (data.borrow() if on_device else
-              _backend.resident_context(data, form=_backend.FORM_DATA, dtype=self.dtype)) as ctx:
-
-            def init_dictionary():
-                init = 'furthest_sum' if self.init is None else self.init
-                if init == 'furthest_sum':
-                    rng = self.random_state
-                    start_index = kwargs.get('start_index', None)
-                    if start_index is None:
-                        start_index = rng.randint(n_samples)
-                    exclude = kwargs.get('exclude', None)
-                    if exclude is None:
-                        exclude = np.array([], dtype='i8')
-                    selected = _furthest_sum_on_device(
-                        ctx, n_samples, self.n_components, start_index,
-                        kwargs.get('n_extra_steps', 10), exclude)
-                    return _one_hot_rows(selected, n_samples, np.float64)
-                return _initialize_kernel_aa_dictionary(shape_only, self.n_components, init=init,
-                                                        random_state=self.random_state)
-
-            dictionary, weights, alpha = self._resolve_factors(
-                n_samples, dictionary, weights, alpha, update_dictionary, update_weights,
-                init_dictionary,
-                lambda: _initialize_kernel_aa_weights(shape_only, self.n_components,
-                                                      init=self.init,
-                                                      random_state=self.random_state))
-            if kwargs.get('_draw_only', False):      # restarts.fit_restarts: start factors only
-                return dictionary, weights, alpha
-            self.weights = weights.copy()
-            self.dictionary = dictionary.copy()
-            self.alpha = alpha.copy()
-
-            result = _iterate_on_device(
-                ctx, "AA", self.weights, self.dictionary, self.alpha, self.delta,
-                update_weights, update_dictionary, update_scale_factors, self.tolerance,
-                self.max_iterations, self.verbose, **self._solver_kwargs())
-            out = self._finish(result)
-            self._cx = ctx.archetypes()
-        return out
+        return _fit_on_data_matrix(self, data, False, "AA", dictionary, weights, alpha,
+                                   update_dictionary, update_weights, update_scale_factors, **kwargs)
 
     def fit_transform(self, data, dictionary=None, weights=None, alpha=None, **kwargs):
         """Factorise ``data`` (n_samples x n_features) and return the weights."""

@@ -190,6 +190,7 @@ struct Ctx {
     DevBuf qpIters;                            // n ints: pass counts of the latest weights update
     DevBuf qpPerm;                             // n ints: sample order of the lane kernel
     bool qp_iters_valid = false;               // qpIters belongs to the current rows / state
+    bool linear_kernel = false;                // data form, KernelAA conventions: K = X X' implicit (aa_set_linear_kernel)
     DevBuf qpStats;                            // 2 long long
     void *hostPinned = nullptr;                // small pinned staging
     size_t hostPinnedBytes = 0;

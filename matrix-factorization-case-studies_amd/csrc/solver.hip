@@ -278,7 +278,9 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
     double *x = c->Ct.as<double>();
     double *gram = c->gramOut.as<double>();
     const size_t GS = (size_t)KP * KP;
-    const double gscale = data ? 1.0 / (double)c->n_global : 1.0 / (double)k;   // :297 vs :288
+    // the data form divides the gradient by n (:297), the kernel form by k (:288); a data matrix
+    // standing in for the kernel K = X X' (aa_set_linear_kernel) follows the kernel form
+    const double gscale = (data && !c->linear_kernel) ? 1.0 / (double)c->n_global : 1.0 / (double)k;
 
     // spg.py:148 projects the start point.  A dictionary that came out of our own update
     // (x_old + lambda d, a convex combination of simplex points) is feasible to rounding,
@@ -566,6 +568,14 @@ int aa_ctx_destroy(aa_ctx *h)
     return AA_OK;
 }
 
+int aa_set_linear_kernel(aa_ctx *h, int on)
+{
+    AA_REQUIRE(h, AA_ERR_ARG, "null ctx");
+    AA_REQUIRE(!on || h->c.form == AA_FORM_DATA, AA_ERR_STATE, "aa_set_linear_kernel needs a data matrix");
+    h->c.linear_kernel = on != 0;
+    return AA_OK;
+}
+
 int aa_comm_get_unique_id(void *id128) { return comm_unique_id(id128); }
 
 int aa_ctx_comm_init(aa_ctx *h, const void *id128, int rank, int world)
@@ -610,6 +620,7 @@ int aa_set_data(aa_ctx *h, const void *X, int host_dtype, long n, long p, long l
                    "kernel form needs a square matrix on a single rank");
     AA_REQUIRE(n_global >= n && row_offset >= 0 && row_offset + n <= n_global, AA_ERR_ARG, "bad shard");
     c->form = form;
+    c->linear_kernel = false;
     c->n = n;
     c->p = p;
     c->n_pad = round_up(n, 128);

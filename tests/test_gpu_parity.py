@@ -982,6 +982,43 @@ def test_gpnh_unused_component_falls_back_to_lstsq(cdr, orc):
     assert np.abs(W - want[1]).max() < 1e-9 * max(1.0, np.abs(want[1]).max())
 
 
+@pytest.mark.parametrize("init", ["random", "furthest_sum"])
+def test_kernel_aa_on_the_implicit_linear_kernel(cdr, orc, init):
+    """KernelAA on K = X X' without forming K (fit_transform(X, features=True),
+    aa_set_linear_kernel) against KernelAA on the explicit n x n matrix -- same RNG draws, same
+    iterates, same n_iter -- and against the oracle's kernel-form loop from the same start."""
+    rng = np.random.RandomState(11)
+    n, p, k = 300, 40, 4
+    B = rng.standard_normal((k, p))
+    X = orc.right_stochastic_matrix((n, k), rng).dot(B) + 0.05 * rng.standard_normal((n, p))
+    K = X.dot(X.T)
+    kw = dict(n_components=k, init=init, tolerance=1e-9, max_iterations=40)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        explicit = cdr.KernelAA(random_state=np.random.RandomState(5), **kw)
+        Ze = explicit.fit_transform(K)
+        implicit = cdr.KernelAA(random_state=np.random.RandomState(5), **kw)
+        Zi = implicit.fit_transform(X, features=True)
+    assert implicit.n_iter == explicit.n_iter
+    assert abs(implicit.cost - explicit.cost) < 1e-9 * explicit.cost
+    assert np.abs(Zi - Ze).max() < 1e-6 and np.abs(implicit.dictionary - explicit.dictionary).max() < 1e-6
+    assert np.array_equal(implicit.dictionary > 0, explicit.dictionary > 0)
+    # five fixed iterations from one start: rounding level against the oracle's kernel form
+    C0 = orc.right_stochastic_matrix((k, n), np.random.RandomState(2))
+    Z0 = orc.right_stochastic_matrix((n, k), np.random.RandomState(3))
+    # (fixed inner iteration counts too: QPs run to their 1e-6 stopping rule agree only to that)
+    inner = dict(weights_solver_kwargs=dict(max_iterations=6), dictionary_solver_kwargs=dict(max_iterations=2))
+    fixed = dict(tolerance=0, max_iterations=5, require_monotonic_cost_decrease=False, **inner)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = orc.iterate_kernel_aa(K, Z0.copy(), C0.copy(), np.ones(k), **fixed)
+        est = cdr.KernelAA(n_components=k, init='custom', tolerance=0, max_iterations=5,
+                           require_monotonic_cost_decrease=False, **inner)
+        est.fit_transform(X, features=True, dictionary=C0.copy(), weights=Z0.copy(), alpha=np.ones(k))
+    assert abs(est.cost - want[3]) < 1e-10 * want[3]
+    assert np.abs(est.weights - want[0]).max() < 1e-8 and np.abs(est.dictionary - want[1]).max() < 1e-8
+
+
 @pytest.mark.parametrize("form", ["data", "kernel"])
 def test_scale_factors_on_device_match_host_spg(cdr, orc, form):
     """delta != 0 (archetypal_analysis.py:220-258,590-609): the k-vector scale-factor SPG inside the
