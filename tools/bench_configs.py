@@ -73,3 +73,26 @@ for lam in (0.0, 1.0):
                       "it_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
                       "algorithmic_bytes_per_step": bytes_it, "hbm_GBps": bytes_it * steps / dt / 1e9,
                       "cost_last": float(costs[-1])}), flush=True)
+
+# KernelAA on the implicit linear kernel of the headline problem (the explicit
+# 100 000 x 100 000 kernel matrix would be 80 GB); float32 data, the benchmark's solver settings
+if os.environ.get("BENCH_CONFIGS_KERNEL", "1") != "0":
+    import bench  # noqa: E402
+    n, p, k = bench.N_SAMPLES, bench.N_FEATURES, bench.N_COMPONENTS
+    X = bench.synthetic_rows(0, n)
+    C0, Z0 = bench.start_factors(n, k)
+    with _backend.Context(dtype="float32") as ctx:
+        ctx.set_data(X)
+        ctx.set_linear_kernel(True)
+        ctx.set_state(C0, Z0, np.ones(k))
+        cost = ctx.prepare()
+        costs, st = ctx.iterate(cost, 5, 0.0, "abs_delta_f", False, True, True, dict(max_iterations=1), {})
+        ksteps = min(steps, 50)
+        t0 = time.perf_counter()
+        costs, st = ctx.iterate(costs[-1], ksteps, 0.0, "abs_delta_f", False, True, True, dict(max_iterations=1), {})
+        dt = time.perf_counter() - t0
+    bytes_it = 4.0 * n * p * 4
+    print(json.dumps({"config": "KernelAA on the implicit linear kernel K = XX', X = 100000 x 4096 float32, k=32 (K never formed)",
+                      "it_per_s": ksteps / dt, "ms_per_step": 1e3 * dt / ksteps, "steps": ksteps,
+                      "algorithmic_bytes_per_step": bytes_it, "hbm_GBps": bytes_it * ksteps / dt / 1e9,
+                      "cost_last": float(costs[-1])}), flush=True)
