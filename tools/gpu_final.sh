@@ -36,5 +36,6 @@ step "rocprofv3: bench float64"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_prof_f64 -- python3 $GRAFT_REPO_ROOT/bench.py --dtype float64 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/final_prof_f64.log 2>&1 || exit 1
 python3 $GRAFT_REPO_ROOT/tools/trace_summary.py $GRAFT_REPO_ROOT/gpurun_out/final_prof_f64 50 | tee $GRAFT_REPO_ROOT/gpurun_out/final_prof_f64.summary
 step "rocprofv3: C2 / C3 stand-ins"
+export BENCH_CONFIGS_KERNEL=0   # the profile is of the two small configurations only
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_prof_configs -- python3 $GRAFT_REPO_ROOT/tools/bench_configs.py 100 > $GRAFT_REPO_ROOT/gpurun_out/final_prof_configs.log 2>&1 || exit 1
 echo done
