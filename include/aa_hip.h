@@ -230,6 +230,13 @@ int aa_dictionary_update(aa_ctx *ctx, const aa_spg_params *params, aa_spg_stats 
  * refresh at :640-643 (:501-503). */
 int aa_weights_update(aa_ctx *ctx, const aa_qp_params *params, aa_qp_stats *stats);
 
+/* Restarts (bin/run_hadisst_aa.py:158-172 fits n_init models on the same data):
+ * `ctx` takes the resident data matrix of `owner` (same device, same dtype, single rank) without
+ * a copy -- the solver only reads it -- so several contexts, each with its own factors, streams
+ * and scratch, work on ONE copy of X concurrently.  `owner` must outlive `ctx` or give it new
+ * data first (aa_set_data / aa_share_data release the alias, never the owner's memory). */
+int aa_share_data(aa_ctx *ctx, const aa_ctx *owner);
+
 /* KernelAA on the implicit linear kernel K = X X' (SURVEY 8(f4)): with `on` != 0 the resident
  * DATA matrix X (n x p) stands in for the n x n kernel matrix of _iterate_kernel_aa
  * (archetypal_analysis.py:399-531), which is never formed: every product with K runs as two

@@ -102,6 +102,7 @@ _SIGNATURES = {
                                    ctypes.c_int, ctypes.c_long, ctypes.c_long]),
     "aa_data_trace": (ctypes.c_int, [_vp, _dp]),
     "aa_set_linear_kernel": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "aa_share_data": (ctypes.c_int, [_vp, _vp]),
     "aa_set_data_weighted": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_long,
                                             _dp, ctypes.c_long, ctypes.c_long,
                                             ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_long)]),
@@ -346,6 +347,13 @@ class Context(object):
         _check(self.lib.aa_set_data(self.h, X.ctypes.data_as(_vp), host, n, p, p, form,
                                     n if n_global is None else n_global, row_offset))
         self.n, self.p = n, p
+
+    def share_data(self, owner):
+        """Use ``owner``'s resident data matrix without a copy (aa_share_data); ``owner`` must stay
+        open while this context uses it."""
+        _check(self.lib.aa_share_data(self.h, owner.h))
+        self.n, self.p = owner.n, owner.p
+        self._data_owner = owner                  # keeps the owner alive
 
     def set_linear_kernel(self, on):
         """The resident data matrix X stands in for the kernel K = X X' of KernelAA

@@ -62,9 +62,10 @@ inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    bool borrowed = false;     // aliases another context's buffer (aa_share_data): never freed here
     int alloc(size_t b)
     {
-        if (b <= bytes && p) return AA_OK;
+        if (b <= bytes && p && !borrowed) return AA_OK;
         release();
         if (b == 0) b = 16;
         AA_CHECK_HIP(hipMalloc(&p, b));
@@ -74,9 +75,10 @@ struct DevBuf {
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
+        borrowed = false;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };

@@ -665,6 +665,39 @@ int aa_set_data(aa_ctx *h, const void *X, int host_dtype, long n, long p, long l
     return AA_OK;
 }
 
+int aa_share_data(aa_ctx *h, const aa_ctx *owner)
+{
+    AA_REQUIRE(h && owner && h != owner, AA_ERR_ARG, "two different contexts needed");
+    Ctx *c = &h->c;
+    const Ctx *o = &owner->c;
+    AA_REQUIRE(o->have_data, AA_ERR_STATE, "the owner holds no data matrix");
+    AA_REQUIRE(o->device == c->device && o->dtype == c->dtype, AA_ERR_ARG,
+               "aa_share_data: same device and same data type needed");
+    AA_REQUIRE(c->world == 1 && !c->force_comm && o->world == 1 && !o->force_comm, AA_ERR_ARG,
+               "aa_share_data is single-rank");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    c->X.release();
+    c->X.p = o->X.p;                    // read-only everywhere in the solver
+    c->X.bytes = o->X.bytes;
+    c->X.borrowed = true;
+    c->form = o->form;
+    c->linear_kernel = false;
+    c->n = o->n;
+    c->p = o->p;
+    c->n_pad = o->n_pad;
+    c->p_pad = o->p_pad;
+    c->n_global = o->n_global;
+    c->row_offset = o->row_offset;
+    c->have_data = true;
+    c->have_trace = o->have_trace;
+    c->trace = o->trace;
+    c->k = 0;
+    c->KP = 0;
+    c->have_state = false;
+    c->grams_valid = false;
+    return AA_OK;
+}
+
 int aa_set_data_weighted(aa_ctx *h, const void *raw, int host_dtype, long n_total, long p_full, long ld,
                          const double *col_weight, long row0, long n, unsigned char *valid, long *p_valid)
 {

@@ -601,3 +601,39 @@ def test_concurrent_restarts_match_the_sequential_loop(cdr, orc, c3_problem):
         assert best == int(np.argmin([m.cost for m in seq]))
         assert shared.uniform() == shared.uniform() or True      # generator left where the loop leaves it
         print("%s: %d restarts sequential %.2f s, 3 at a time %.2f s" % (make.__name__, n_init, t_seq, t_par))
+
+
+def test_contexts_share_one_resident_data_matrix(cdr, orc):
+    """aa_share_data: a second context works on the first one's copy of X -- same
+    results as with its own upload, the owner unaffected, and new data for the alias releases only
+    the alias."""
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(4)
+    n, p, k = 700, 90, 6
+    X = rng.standard_normal((n, p))
+    C0 = orc.right_stochastic_matrix((k, n), rng)
+    Z0 = orc.right_stochastic_matrix((n, k), rng)
+    C1 = orc.right_stochastic_matrix((k, n), rng)
+
+    def run(ctx, C):
+        ctx.set_state(C, Z0, np.ones(k))
+        ctx.prepare()
+        return ctx.outer_iterations(6, dict(max_iterations=1), {}), ctx.get_state()
+
+    with _backend.Context(dtype="float64") as own, _backend.Context(dtype="float64") as alias, \
+            _backend.Context(dtype="float64") as separate:
+        own.set_data(X)
+        separate.set_data(X)
+        alias.share_data(own)
+        costs_a, state_a = run(alias, C1)
+        costs_o, state_o = run(own, C0)                      # the owner, with other factors
+        costs_s, state_s = run(separate, C1)
+        assert np.array_equal(costs_a, costs_s) and np.array_equal(state_a[0], state_s[0])
+        assert np.array_equal(state_a[1], state_s[1])
+        assert not np.array_equal(costs_o, costs_a)
+        assert abs(alias.data_trace() - (X * X).sum()) < 1e-9 * (X * X).sum()
+        alias.set_data(2.0 * X)                              # releases the alias, not the owner's memory
+        costs_o2, _ = run(own, C0)
+        assert np.array_equal(costs_o2, costs_o)
+        with pytest.raises(RuntimeError):
+            alias.share_data(alias)
