@@ -53,9 +53,14 @@ def main():
         costs = ctx.outer_iterations(6, dict(max_iterations=1), {})
         dcol = ctx.distance_column(n // 2 + 3)
         Cs, Zs, _ = ctx.get_state()
+        # the estimators' device-side loop (aa_iterate) over the sharded state: 4 more iterations,
+        # the judge's decisions are taken on replicated costs, so every rank stops at the same one
+        loop_costs, st = ctx.iterate(float(costs[-1]), 4, 0.0, "abs_delta_f", False, True, True,
+                                     dict(max_iterations=1), {})
         ctx.allreduce_host([0.0])                       # all ranks done before the communicator goes
         ctx.close()
-        np.savez(os.path.join(share, "r%d_%s.npz" % (rank, dtype)), C=Cs, Z=Zs, d=dcol, costs=costs, cost0=cost0)
+        np.savez(os.path.join(share, "r%d_%s.npz" % (rank, dtype)), C=Cs, Z=Zs, d=dcol, costs=costs, cost0=cost0,
+                 loop_costs=np.asarray(loop_costs), loop_n_iter=st.n_iter)
         if uid_path and rank == 0:
             try:
                 os.remove(uid_path)
@@ -81,6 +86,8 @@ def main():
             want = ctx.outer_iterations(6, dict(max_iterations=1), {})
             wd = ctx.distance_column(n // 2 + 3)
             wC, wZ, _ = ctx.get_state()
+            wloop, wst = ctx.iterate(float(want[-1]), 4, 0.0, "abs_delta_f", False, True, True,
+                                     dict(max_iterations=1), {})
         C = np.concatenate([q["C"] for q in parts], axis=1)
         Z = np.concatenate([q["Z"] for q in parts], axis=0)
         d = np.concatenate([q["d"] for q in parts])
@@ -91,6 +98,9 @@ def main():
               % (dtype, world, abs(parts[0]["cost0"] - c0) / abs(c0), rel, np.abs(C - wC).max(),
                  np.abs(Z - wZ).max(), np.abs(d - wd).max()), flush=True)
         assert rel < tol and abs(parts[0]["cost0"] - c0) < tol * abs(c0)
+        for q in parts:
+            assert np.array_equal(q["loop_costs"], parts[0]["loop_costs"]) and int(q["loop_n_iter"]) == wst.n_iter
+        assert np.abs(parts[0]["loop_costs"] - np.asarray(wloop)).max() < 10 * tol * abs(c0)
         assert np.abs(C - wC).max() < (1e-9 if dtype == "float64" else 1e-4)
         assert np.abs(Z - wZ).max() < (1e-6 if dtype == "float64" else 1e-2)
         assert np.abs(d - wd).max() < (1e-9 if dtype == "float64" else 1e-3)
