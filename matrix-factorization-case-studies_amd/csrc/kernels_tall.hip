@@ -2191,6 +2191,9 @@ int launch_cost_carry(Ctx *c, double *costs, int *slot, double cost0)
 // (Z'Z/n + lambda GW) W' = Z'X/n  (gpnh_convex_coding.py:213-226, GW of :296-300): every block
 // factorises the k x k system (Cholesky, in LDS) and solves it for its own 256 columns of the
 // right-hand side, one column per thread.  ok[0] = 1 when a pivot is not safely positive.
+// KM >= k: the substitution loops are unrolled over KM with `i < k` predicates, so the column's
+// solution vector stays in registers (indexed by a run-time k it lived in scratch: 25 us a launch)
+template <int KM>
 __global__ __launch_bounds__(256) void k_gpnh_solve(const double *__restrict__ ZtZ /*[KP][KP]*/,
                                                     const double *__restrict__ ZtX /*[KP][ld]*/,
                                                     int ld, int p, int k, int KP, double n_samples,
@@ -2236,21 +2239,38 @@ __global__ __launch_bounds__(256) void k_gpnh_solve(const double *__restrict__ Z
     }
     const int c = blockIdx.x * 256 + t;
     if (c >= ld) return;
-    double y[AA_MAX_K];
-    for (int i = 0; i < k; ++i) {                 // L y = b
-        double v = c < p ? ZtX[(long)i * ld + c] / n_samples : 0.0;
-        for (int q = 0; q < i; ++q) v -= L[i * k + q] * y[q];
-        y[i] = v / L[i * k + i];
+    double y[KM];
+#pragma unroll
+    for (int i = 0; i < KM; ++i) {                // L y = b
+        if (i < k) {
+            double v = c < p ? ZtX[(long)i * ld + c] / n_samples : 0.0;
+#pragma unroll
+            for (int q = 0; q < i; ++q) v -= L[i * k + q] * y[q];
+            y[i] = v / L[i * k + i];
+        } else {
+            y[i] = 0.0;
+        }
     }
-    for (int i = k - 1; i >= 0; --i) {            // L' w = y
-        double v = y[i];
-        for (int q = i + 1; q < k; ++q) v -= L[q * k + i] * y[q];
-        y[i] = v / L[i * k + i];
+#pragma unroll
+    for (int i = KM - 1; i >= 0; --i) {           // L' w = y
+        if (i < k) {
+            double v = y[i];
+#pragma unroll
+            for (int q = i + 1; q < KM; ++q)
+                if (q < k) v -= L[q * k + i] * y[q];
+            y[i] = v / L[i * k + i];
+        }
     }
-    for (int i = 0; i < KP; ++i) {
-        const double v = i < k ? y[i] : 0.0;
-        Wt[(long)i * ld + c] = v;
-        if (WtF) WtF[(long)i * ld + c] = (float)v;
+#pragma unroll
+    for (int i = 0; i < KM; ++i) {
+        if (i < KP) {
+            Wt[(long)i * ld + c] = y[i];
+            if (WtF) WtF[(long)i * ld + c] = (float)y[i];
+        }
+    }
+    for (int i = KM; i < KP; ++i) {               // padding rows of the k x p factor stay zero
+        Wt[(long)i * ld + c] = 0.0;
+        if (WtF) WtF[(long)i * ld + c] = 0.f;
     }
 }
 
@@ -2303,10 +2323,15 @@ __global__ __launch_bounds__(256) void k_copy2(const IterState *__restrict__ st,
 int launch_gpnh_solve(Ctx *c, double lambda, int *ok_dev)
 {
     const size_t lds = (size_t)c->k * c->k * sizeof(double);
-    hipLaunchKernelGGL(k_gpnh_solve, dim3((unsigned)((c->p_pad + 255) / 256)), dim3(256), lds, c->stream,
-                       (const double *)c->gramState.as<double>(), (const double *)c->ZtX.as<double>(),
-                       (int)c->p_pad, (int)c->p, c->k, c->KP, (double)c->n_global, lambda, c->P.as<double>(),
-                       c->dtype == AA_F32 ? c->Pw.as<float>() : (float *)nullptr, ok_dev);
+#define GPS(KMV)                                                                                        \
+    hipLaunchKernelGGL(k_gpnh_solve<KMV>, dim3((unsigned)((c->p_pad + 255) / 256)), dim3(256), lds, c->stream, \
+                       (const double *)c->gramState.as<double>(), (const double *)c->ZtX.as<double>(),      \
+                       (int)c->p_pad, (int)c->p, c->k, c->KP, (double)c->n_global, lambda, c->P.as<double>(), \
+                       c->dtype == AA_F32 ? c->Pw.as<float>() : (float *)nullptr, ok_dev)
+    if (c->k <= 16) GPS(16);
+    else if (c->k <= 32) GPS(32);
+    else GPS(64);
+#undef GPS
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
