@@ -1203,7 +1203,8 @@ __device__ void scalar_stage_simple(int stage, double *__restrict__ sc, const aa
 template <int KP>
 __global__ __launch_bounds__(256) void k_gram_wide_pq(const double *__restrict__ P,
                                                       const double *__restrict__ Q, int ld,
-                                                      double *__restrict__ partial, int cols_per_block)
+                                                      double *__restrict__ partial, int cols_per_block,
+                                                      int k)
 {
     constexpr int JT = KP * KP / 256;
     constexpr int TPI = KP / JT;
@@ -1225,13 +1226,17 @@ __global__ __launch_bounds__(256) void k_gram_wide_pq(const double *__restrict__
             Bs[e / CW][e % CW] = Q[(long)(e / CW) * ld + c0 + cc + e % CW];
         }
         __syncthreads();
-        for (int c = 0; c < CW; ++c) {
-            const double a = As[i][c], b = Bs[i][c];
+        // rows >= k of P and Q are zero padding: a wave whose rows are all padding has nothing
+        // to add (k = 5 of 32: three of the four waves, and the block is LDS-bound)
+        if ((t >> 6) * (64 / TPI) < k) {
+            for (int c = 0; c < CW; ++c) {
+                const double a = As[i][c], b = Bs[i][c];
 #pragma unroll
-            for (int q = 0; q < JT; ++q) {
-                const double bq = Bs[j0 + q][c];
-                acc1[q] = fma(a, bq, acc1[q]);
-                acc2[q] = fma(b, bq, acc2[q]);
+                for (int q = 0; q < JT; ++q) {
+                    const double bq = Bs[j0 + q][c];
+                    acc1[q] = fma(a, bq, acc1[q]);
+                    acc2[q] = fma(b, bq, acc2[q]);
+                }
             }
         }
         __syncthreads();
@@ -2413,11 +2418,11 @@ int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, i
     if (c->KP == 32)
         hipLaunchKernelGGL(k_gram_wide_pq<32>, dim3(nb), dim3(256), 0, c->stream,
                            (const double *)c->P.as<double>(), (const double *)c->Q.as<double>(),
-                           (int)c->p_pad, part, cpb);
+                           (int)c->p_pad, part, cpb, c->k);
     else
         hipLaunchKernelGGL(k_gram_wide_pq<64>, dim3(nb), dim3(256), 0, c->stream,
                            (const double *)c->P.as<double>(), (const double *)c->Q.as<double>(),
-                           (int)c->p_pad, part, cpb);
+                           (int)c->p_pad, part, cpb, c->k);
     hipLaunchKernelGGL(k_linesearch_fin, dim3(1), dim3(1024), 0, c->stream, (const double *)part, nb, c->KP,
                        c->gramOut.as<double>(), (const double *)c->Mdev.as<double>(),
                        c->scalars.as<double>(), *sp, c->k, ckct, (double)c->n_global, cost_out, cost_slot);
