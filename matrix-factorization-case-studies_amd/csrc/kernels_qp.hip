@@ -2155,7 +2155,8 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         long waves = (n + 15) / 16;
         if (waves > g_qp_quad_waves) waves = g_qp_quad_waves;
         const int *perm = nullptr;
-        if (g_qp_sort && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid)
+        // (a cap of one or two passes for everybody: nothing to order, three launches saved)
+        if (g_qp_sort && p->max_iterations > 2 && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid)
             AA_CHECK(qp_order_rows(c, iters_dev, n, &perm));
         hipStream_t s_main = c->stream;
         // watchdog only: a wave's slots take their samples one after the other, each at most
@@ -2204,7 +2205,8 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         // samples ordered by their previous pass count (iters_dev still holds the counts of
         // the previous update of this context; the kernels below overwrite them)
         const int *perm = nullptr;
-        if (g_qp_sort && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid)
+        // (a cap of one or two passes for everybody: nothing to order, three launches saved)
+        if (g_qp_sort && p->max_iterations > 2 && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid)
             AA_CHECK(qp_order_rows(c, iters_dev, n, &perm));
         QpDebug *dbgp = g_qp_profile ? reinterpret_cast<QpDebug *>(base + 64) : (QpDebug *)nullptr;
         if (dbgp) AA_CHECK_HIP(hipMemsetAsync(dbgp, 0, sizeof(QpDebug), c->stream));
