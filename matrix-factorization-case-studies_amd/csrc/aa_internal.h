@@ -257,7 +257,7 @@ int launch_gather_weight(Ctx *c, const void *raw_dev, int host_dtype, long ld, l
                          const int *idx_dev, long p_valid, const double *w_dev);
 int launch_data_to_double(Ctx *c, double *out_dev);
 int launch_gpnh_solve(Ctx *c, double lambda, int *ok_dev);
-int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter);
+int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter, bool from_wide = false);
 int launch_gpnh_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
                       const aa_iter_params *ip);
 enum { ST_INIT_F = 0, ST_ALPHA = 1, ST_LINESEARCH = 2, ST_BB = 3, ST_CONV = 4 };

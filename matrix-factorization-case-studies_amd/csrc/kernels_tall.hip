@@ -2282,15 +2282,32 @@ __global__ __launch_bounds__(256) void k_gpnh_solve(const double *__restrict__ Z
 // cost of gpnh_convex_coding.py:317-330 from the device-side pieces: tr(W'X'Z) in scal[slot],
 // Z'Z and W'W (KP x KP), the GPNH penalty (:179-196) from the Gram of the dictionary
 //   phi(W) = 2 / (k p (k - 1)) sum_{i<j} ||w_i - w_j||^2,  ||w_i - w_j||^2 = G_ii + G_jj - 2 G_ij
+// ZtX / Wt given (the device loop): tr(W'X'Z) = <Z'X, W'> is summed here from the two k x p
+// arrays -- 1670 terms on the C3 shape -- instead of <XW, Z> over n rows in two launches of their own.
 __global__ __launch_bounds__(256) void k_gpnh_cost(const double *__restrict__ ZtZ,
                                                    const double *__restrict__ WtW,
                                                    const double *__restrict__ scal, int slot, int k,
                                                    int KP, int p, double trace, double n_samples,
                                                    double lambda, double *__restrict__ out,
-                                                   int *__restrict__ slot_counter)
+                                                   int *__restrict__ slot_counter,
+                                                   const double *__restrict__ ZtX,
+                                                   const double *__restrict__ Wt, int ld)
 {
-    __shared__ double sm[256], sm2[256];
+    __shared__ double sm[256], sm2[256], sm3[256];
     const int t = threadIdx.x;
+    double cross = 0.0;
+    if (ZtX) {
+        double c4[4] = {0.0, 0.0, 0.0, 0.0};            // four chains, fixed order
+        const long total = (long)k * ld;                // padding columns are zero in both
+        long e = t;
+        for (; e + 3 * 256 < total; e += 4 * 256) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c4[u] = fma(ZtX[e + u * 256], Wt[e + u * 256], c4[u]);
+        }
+        for (; e < total; e += 256) c4[0] = fma(ZtX[e], Wt[e], c4[0]);
+        cross = (c4[0] + c4[1]) + (c4[2] + c4[3]);
+    }
+    sm3[t] = cross;
     double quad = 0.0, pen = 0.0;
     for (int e = t; e < k * k; e += 256) {
         const int i = e / k, j = e % k;
@@ -2304,6 +2321,7 @@ __global__ __launch_bounds__(256) void k_gpnh_cost(const double *__restrict__ Zt
         if (t < o) {
             sm[t] += sm[t + o];
             sm2[t] += sm2[t + o];
+            sm3[t] += sm3[t + o];
         }
         __syncthreads();
     }
@@ -2311,7 +2329,8 @@ __global__ __launch_bounds__(256) void k_gpnh_cost(const double *__restrict__ Zt
         double penalty = 0.0;
         if (lambda != 0.0 && k > 1) penalty = lambda * (2.0 / ((double)k * p * (k - 1.0))) * sm2[0];
         const int idx = slot_counter ? (*slot_counter)++ : 0;
-        out[idx] = 0.5 * (trace - 2.0 * scal[slot] + sm[0]) / n_samples + penalty;
+        const double s1 = ZtX ? sm3[0] : scal[slot];
+        out[idx] = 0.5 * (trace - 2.0 * s1 + sm[0]) / n_samples + penalty;
     }
 }
 
@@ -2341,12 +2360,14 @@ int launch_gpnh_solve(Ctx *c, double lambda, int *ok_dev)
     return AA_OK;
 }
 
-int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter)
+int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter, bool from_wide)
 {
     const double *gs = c->gramState.as<double>();
     hipLaunchKernelGGL(k_gpnh_cost, dim3(1), dim3(256), 0, c->stream, gs, gs + (size_t)c->KP * c->KP,
                        (const double *)c->scalars.as<double>(), (int)SC_S1, c->k, c->KP, (int)c->p, c->trace,
-                       (double)c->n_global, lambda, out_dev, slot_counter);
+                       (double)c->n_global, lambda, out_dev, slot_counter,
+                       from_wide ? (const double *)c->ZtX.as<double>() : (const double *)nullptr,
+                       (const double *)c->P.as<double>(), (int)c->p_pad);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }

@@ -1253,8 +1253,11 @@ int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp,
     // Gram state: [0] = Z'Z, [1] = W'W; scal[SC_S1] = tr(W'X'Z) = <XW, Z>
     AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
     AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), dev_CKCt(c)));
-    AA_CHECK(launch_tall_dot_scaled(c, c->Gr.as<double>(), c->Zt.as<double>(), nullptr, SC_S1));
-    AA_CHECK(launch_gpnh_cost(c, lambda, cd + 2 * n_max + 8, nullptr));
+    // tr(W'X'Z) = <Z'X, W'>: with Z'X of the current weights at hand (the dictionary solve needs it
+    // anyway) the cost takes no pass over the n rows at all
+    AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), nullptr));
+    bool ztx_current = true;
+    AA_CHECK(launch_gpnh_cost(c, lambda, cd + 2 * n_max + 8, nullptr, true));
     double cost0 = 0.0;
     AA_CHECK_HIP(hipMemcpyAsync(&cost0, cd + 2 * n_max + 8, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -1270,12 +1273,12 @@ int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp,
         const int batch = n_max - done < ip->check_every ? n_max - done : ip->check_every;
         for (int b = 0; b < batch; ++b) {
             if (ip->update_dictionary) {
-                AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), nullptr));
+                if (!ztx_current) AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), nullptr));
+                ztx_current = true;
                 AA_CHECK(launch_gpnh_solve(c, lambda, &st->pad0));                      // W'
                 AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));   // X W
                 AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), dev_CKCt(c)));
-                AA_CHECK(launch_tall_dot_scaled(c, c->Gr.as<double>(), c->Zt.as<double>(), nullptr, SC_S1));
-                AA_CHECK(launch_gpnh_cost(c, lambda, cd, slot));
+                AA_CHECK(launch_gpnh_cost(c, lambda, cd, slot, true));
             } else {
                 AA_CHECK(launch_cost_carry(c, cd, slot, cost0));
             }
@@ -1284,8 +1287,9 @@ int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp,
                                    c->k, qp, c->qpIters.as<int>(), nullptr, dev_CKCt(c)));
                 c->qp_iters_valid = true;
                 AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
-                AA_CHECK(launch_tall_dot_scaled(c, c->Gr.as<double>(), c->Zt.as<double>(), nullptr, SC_S1));
-                AA_CHECK(launch_gpnh_cost(c, lambda, cd, slot));
+                AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), nullptr));   // also the next solve's
+                ztx_current = true;
+                AA_CHECK(launch_gpnh_cost(c, lambda, cd, slot, true));
             } else {
                 AA_CHECK(launch_cost_carry(c, cd, slot, cost0));
             }
