@@ -257,9 +257,18 @@ int launch_gather_weight(Ctx *c, const void *raw_dev, int host_dtype, long ld, l
                          const int *idx_dev, long p_valid, const double *w_dev);
 int launch_data_to_double(Ctx *c, double *out_dev);
 int launch_gpnh_solve(Ctx *c, double lambda, int *ok_dev);
-int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter, bool from_wide = false);
+// the outer iteration's judge, run by the cost kernel that records the iteration's last cost
+struct GpnhJudge {
+    int on, it;
+    double cost0, tol, mono_tol;
+    int criterion, require, upd_dict, upd_w;
+    IterState *st;
+};
+bool gpnh_cost_can_gram(const Ctx *c);
+int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter, bool from_wide = false,
+                     bool gram_w = false, const GpnhJudge *judge = nullptr);
 int launch_gpnh_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
-                      const aa_iter_params *ip);
+                      const aa_iter_params *ip, bool judged = false);
 enum { ST_INIT_F = 0, ST_ALPHA = 1, ST_LINESEARCH = 2, ST_BB = 3, ST_CONV = 4 };
 int launch_row_sqnorm_sum(Ctx *c, double *trace_out_host);
 int launch_distance_column(Ctx *c, long j_local, int owner_has_row, const double *xj_host, double *d_host);

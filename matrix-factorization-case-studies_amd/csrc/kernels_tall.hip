@@ -2103,12 +2103,11 @@ int launch_scale_factors(Ctx *c, const aa_spg_params *sp, double delta_box, int 
 // Status record of aa_iterate (device memory): written by one thread after every outer
 // iteration, read by the host once per batch.
 // costs[2*it], costs[2*it + 1]: cost after the dictionary / weights update of iteration `it`.
-__global__ void k_iter_judge(int it, double cost0, const double *__restrict__ costs,
-                             IterState *__restrict__ st, double tol, double mono_tol, int criterion,
-                             int require, int upd_dict, int upd_w, const double *__restrict__ scal,
-                             int track_spg)
+__device__ __forceinline__ void iter_judge_thread0(int it, double cost0, const double *__restrict__ costs,
+                                                   IterState *__restrict__ st, double tol, double mono_tol,
+                                                   int criterion, int require, int upd_dict, int upd_w,
+                                                   const double *__restrict__ scal, int track_spg)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (st->stop) return;
     const double old = it == 0 ? cost0 : costs[2 * it - 1];
     const double c1 = costs[2 * it], c2 = costs[2 * it + 1];
@@ -2143,6 +2142,15 @@ __global__ void k_iter_judge(int it, double cost0, const double *__restrict__ co
         st->converged = 1;
         st->stop_iter = it;
     }
+}
+
+__global__ void k_iter_judge(int it, double cost0, const double *__restrict__ costs,
+                             IterState *__restrict__ st, double tol, double mono_tol, int criterion,
+                             int require, int upd_dict, int upd_w, const double *__restrict__ scal,
+                             int track_spg)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    iter_judge_thread0(it, cost0, costs, st, tol, mono_tol, criterion, require, upd_dict, upd_w, scal, track_spg);
 }
 
 // keeps the factors of the iteration at which the loop stopped (later iterations of the same
@@ -2285,16 +2293,47 @@ __global__ __launch_bounds__(256) void k_gpnh_solve(const double *__restrict__ Z
 // ZtX / Wt given (the device loop): tr(W'X'Z) = <Z'X, W'> is summed here from the two k x p
 // arrays -- 1670 terms on the C3 shape -- instead of <XW, Z> over n rows in two launches of their own.
 __global__ __launch_bounds__(256) void k_gpnh_cost(const double *__restrict__ ZtZ,
-                                                   const double *__restrict__ WtW,
+                                                   const double *WtW /* = WtW_out when that is set */,
                                                    const double *__restrict__ scal, int slot, int k,
                                                    int KP, int p, double trace, double n_samples,
                                                    double lambda, double *__restrict__ out,
                                                    int *__restrict__ slot_counter,
                                                    const double *__restrict__ ZtX,
-                                                   const double *__restrict__ Wt, int ld)
+                                                   const double *__restrict__ Wt, int ld,
+                                                   double *WtW_out, GpnhJudge jd)
 {
     __shared__ double sm[256], sm2[256], sm3[256];
     const int t = threadIdx.x;
+    if (WtW_out) {
+        // W'W (k x k <= 256 outputs, k * ld <= 4096: the launcher checks) right here instead of two
+        // launches of the wide Gram kernel: W' goes through LDS (coalesced in, row stride ld + 1
+        // out), one output per thread; zero padding as k_gram_finalize leaves it
+        __shared__ double wl[4096 + 64];
+        for (int e = t; e < k * ld; e += 256) wl[(e / ld) * (ld + 1) + e % ld] = Wt[e];
+        __syncthreads();
+        // `parts` threads per output, each over its share of the columns, combined in a fixed order
+        const int kk = k * k, parts = 256 / kk >= 4 ? 4 : (256 / kk >= 2 ? 2 : 1);
+        const int span = ld / parts;                   // ld is a multiple of 128
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (t < kk * parts) {
+            const int e = t % kk, part = t / kk;
+            const double *wi = wl + (e / k) * (ld + 1) + part * span, *wj = wl + (e % k) * (ld + 1) + part * span;
+            for (int c = 0; c < span; c += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a4[u] = fma(wi[c + u], wj[c + u], a4[u]);
+            }
+        }
+        sm[t] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        __syncthreads();
+        for (int e = t; e < KP * KP; e += 256) {
+            const int i = e / KP, j = e % KP;
+            double v = 0.0;
+            if (i < k && j < k)
+                for (int q = 0; q < parts; ++q) v += sm[q * kk + i * k + j];
+            WtW_out[e] = v;
+        }
+        __syncthreads();
+    }
     double cross = 0.0;
     if (ZtX) {
         double c4[4] = {0.0, 0.0, 0.0, 0.0};            // four chains, fixed order
@@ -2331,6 +2370,10 @@ __global__ __launch_bounds__(256) void k_gpnh_cost(const double *__restrict__ Zt
         const int idx = slot_counter ? (*slot_counter)++ : 0;
         const double s1 = ZtX ? sm3[0] : scal[slot];
         out[idx] = 0.5 * (trace - 2.0 * s1 + sm[0]) / n_samples + penalty;
+        // the outer iteration's judge (monotonicity, stopping rule) rides along with its last cost
+        if (jd.on)
+            iter_judge_thread0(jd.it, jd.cost0, out, jd.st, jd.tol, jd.mono_tol, jd.criterion, jd.require,
+                               jd.upd_dict, jd.upd_w, scal, 0);
     }
 }
 
@@ -2360,25 +2403,35 @@ int launch_gpnh_solve(Ctx *c, double lambda, int *ok_dev)
     return AA_OK;
 }
 
-int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter, bool from_wide)
+// k x k Gram of the dictionary inside the cost kernel: one output per thread, short rows
+bool gpnh_cost_can_gram(const Ctx *c) { return c->k * c->k <= 256 && (long)c->k * c->p_pad <= 4096; }
+
+int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter, bool from_wide, bool gram_w,
+                     const GpnhJudge *judge)
 {
-    const double *gs = c->gramState.as<double>();
-    hipLaunchKernelGGL(k_gpnh_cost, dim3(1), dim3(256), 0, c->stream, gs, gs + (size_t)c->KP * c->KP,
+    double *gs = c->gramState.as<double>();
+    GpnhJudge jd;
+    memset(&jd, 0, sizeof(jd));
+    if (judge) jd = *judge;
+    hipLaunchKernelGGL(k_gpnh_cost, dim3(1), dim3(256), 0, c->stream, (const double *)gs,
+                       (const double *)(gs + (size_t)c->KP * c->KP),
                        (const double *)c->scalars.as<double>(), (int)SC_S1, c->k, c->KP, (int)c->p, c->trace,
                        (double)c->n_global, lambda, out_dev, slot_counter,
                        from_wide ? (const double *)c->ZtX.as<double>() : (const double *)nullptr,
-                       (const double *)c->P.as<double>(), (int)c->p_pad);
+                       (const double *)c->P.as<double>(), (int)c->p_pad,
+                       gram_w ? gs + (size_t)c->KP * c->KP : (double *)nullptr, jd);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
 
 // GPNH flavour of launch_iter_judge: the snapshot keeps Z and the dictionary (W', wide)
 int launch_gpnh_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
-                      const aa_iter_params *ip)
+                      const aa_iter_params *ip, bool judged)
 {
-    hipLaunchKernelGGL(k_iter_judge, dim3(1), dim3(64), 0, c->stream, it, cost0, costs, st, ip->tolerance,
-                       ip->mono_tolerance, ip->criterion, ip->require_monotonic, ip->update_dictionary,
-                       ip->update_weights, (const double *)c->scalars.as<double>(), 0 /* no SPG behind it */);
+    if (!judged)                                   // else: done by the cost kernel before it
+        hipLaunchKernelGGL(k_iter_judge, dim3(1), dim3(64), 0, c->stream, it, cost0, costs, st, ip->tolerance,
+                           ip->mono_tolerance, ip->criterion, ip->require_monotonic, ip->update_dictionary,
+                           ip->update_weights, (const double *)c->scalars.as<double>(), 0 /* no SPG behind it */);
     hipLaunchKernelGGL(k_copy2, dim3(256), dim3(256), 0, c->stream, (const IterState *)st, it,
                        (const double *)c->Zt.as<double>(), c->snapZ.as<double>(), (long)c->n_pad * c->KP,
                        (const double *)c->P.as<double>(), c->snapC.as<double>(), (long)c->KP * c->p_pad);

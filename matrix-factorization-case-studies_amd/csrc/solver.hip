@@ -1277,8 +1277,9 @@ int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp,
                 ztx_current = true;
                 AA_CHECK(launch_gpnh_solve(c, lambda, &st->pad0));                      // W'
                 AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));   // X W
-                AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), dev_CKCt(c)));
-                AA_CHECK(launch_gpnh_cost(c, lambda, cd, slot, true));
+                const bool gram_in_cost = gpnh_cost_can_gram(c);
+                if (!gram_in_cost) AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), dev_CKCt(c)));
+                AA_CHECK(launch_gpnh_cost(c, lambda, cd, slot, true, gram_in_cost));
             } else {
                 AA_CHECK(launch_cost_carry(c, cd, slot, cost0));
             }
@@ -1289,11 +1290,23 @@ int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp,
                 AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
                 AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), nullptr));   // also the next solve's
                 ztx_current = true;
-                AA_CHECK(launch_gpnh_cost(c, lambda, cd, slot, true));
+                GpnhJudge jd;
+                jd.on = 1;
+                jd.it = done + b;
+                jd.cost0 = cost0;
+                jd.tol = ip->tolerance;
+                jd.mono_tol = ip->mono_tolerance;
+                jd.criterion = ip->criterion;
+                jd.require = ip->require_monotonic;
+                jd.upd_dict = ip->update_dictionary;
+                jd.upd_w = ip->update_weights;
+                jd.st = st;
+                AA_CHECK(launch_gpnh_cost(c, lambda, cd, slot, true, false, &jd));
+                AA_CHECK(launch_gpnh_judge(c, done + b, cost0, cd, st, ip, true));
             } else {
                 AA_CHECK(launch_cost_carry(c, cd, slot, cost0));
+                AA_CHECK(launch_gpnh_judge(c, done + b, cost0, cd, st, ip));
             }
-            AA_CHECK(launch_gpnh_judge(c, done + b, cost0, cd, st, ip));
         }
         done += batch;
         AA_CHECK_HIP(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
