@@ -236,7 +236,15 @@ int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const doubl
 int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev); // A'B  (KPxKP)
 int launch_gram_wide(Ctx *c, const double *A, const double *B, double *out_dev); // A B' (KPxKP)
 int launch_scale_gram(Ctx *c, double *dst, const double *src);      // dst = D src D
-int launch_aa_cost(Ctx *c, double *out_dev, int *slot_counter_dev = nullptr);   // cost from gramState;
+// the outer iteration's judge, run by the cost kernel that records the iteration's last cost
+struct GpnhJudge {
+    int on, it;
+    double cost0, tol, mono_tol;
+    int criterion, require, upd_dict, upd_w;
+    IterState *st;
+    int track_spg;              // AA: fold the dictionary SPG's flags into the status record
+};
+int launch_aa_cost(Ctx *c, double *out_dev, int *slot_counter_dev = nullptr, const GpnhJudge *judge = nullptr);   // cost from gramState;
                                               // with a counter: out_dev[(*counter)++]
 int launch_set_scalars(Ctx *c, double trace, double fnorm);          // SC_TRACE, SC_FNORM
 int launch_wide_axpy_lambda(Ctx *c, double *P, const double *Q, void *PT);   // P += lambda*Q; PT = T(P)
@@ -247,7 +255,7 @@ int launch_scalar_stage(Ctx *c, int stage, const aa_spg_params *sp, int it);
 int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, int *cost_slot);
 int launch_dict_setup(Ctx *c, const aa_spg_params *sp, double fnorm);
 int launch_iter_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
-                      const aa_iter_params *ip);
+                      const aa_iter_params *ip, bool judged = false);
 int launch_cost_carry(Ctx *c, double *costs, int *slot, double cost0);
 int launch_scale_factors(Ctx *c, const aa_spg_params *sp, double delta_box, int it, double cost0,
                          const double *costs, const int *slot, IterState *st, double mono_tol, int require);
@@ -257,13 +265,6 @@ int launch_gather_weight(Ctx *c, const void *raw_dev, int host_dtype, long ld, l
                          const int *idx_dev, long p_valid, const double *w_dev);
 int launch_data_to_double(Ctx *c, double *out_dev);
 int launch_gpnh_solve(Ctx *c, double lambda, int *ok_dev);
-// the outer iteration's judge, run by the cost kernel that records the iteration's last cost
-struct GpnhJudge {
-    int on, it;
-    double cost0, tol, mono_tol;
-    int criterion, require, upd_dict, upd_w;
-    IterState *st;
-};
 bool gpnh_cost_can_gram(const Ctx *c);
 int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter, bool from_wide = false,
                      bool gram_w = false, const GpnhJudge *judge = nullptr);

@@ -2003,9 +2003,10 @@ __global__ __launch_bounds__(256) void k_qp_setup(QpHeader *__restrict__ hdr, do
                                                   double *__restrict__ A2d, double *__restrict__ bsd,
                                                   const double *__restrict__ gram,
                                                   const double *__restrict__ alpha, int k, int KQ,
-                                                  int KW, int KP)
+                                                  int KW, int KP, int *__restrict__ sort_hist)
 {
     const int t = threadIdx.x;
+    if (sort_hist && t < 2 * QP_SORT_BUCKETS) sort_hist[t] = 0;   // histogram + cursors of qp_order_rows
     if (t == 0) {
         hdr->total_passes = 0ull;
         hdr->max_passes = 0ull;
@@ -2029,12 +2030,12 @@ __global__ __launch_bounds__(256) void k_qp_setup(QpHeader *__restrict__ hdr, do
 
 // counting sort of the samples by their previous pass counts, longest first -> *perm_out
 static int qp_order_rows(Ctx *c, const int *iters_dev, long n, const int **perm_out,
-                         QpHeader *hdr = nullptr, int long_from = 0)
+                         QpHeader *hdr = nullptr, int long_from = 0, bool zeroed = false)
 {
     AA_CHECK(c->qpPerm.alloc((size_t)n * sizeof(int) + 2 * QP_SORT_BUCKETS * sizeof(int)));
     int *pm = c->qpPerm.as<int>();
     int *ghist = pm + n, *gcursor = ghist + QP_SORT_BUCKETS;
-    AA_CHECK_HIP(hipMemsetAsync(ghist, 0, 2 * QP_SORT_BUCKETS * sizeof(int), c->stream));
+    if (!zeroed) AA_CHECK_HIP(hipMemsetAsync(ghist, 0, 2 * QP_SORT_BUCKETS * sizeof(int), c->stream));
     const unsigned nblk = (unsigned)((n + QP_SORT_ROWS_PER_BLOCK - 1) / QP_SORT_ROWS_PER_BLOCK);
     hipLaunchKernelGGL(k_qp_order_hist, dim3(nblk), dim3(256), 0, c->stream, iters_dev, n, ghist);
     hipLaunchKernelGGL(k_qp_order_scatter, dim3(nblk), dim3(256), 0, c->stream, iters_dev, n,
@@ -2076,6 +2077,12 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     const size_t off_ovf = off_rows + round_up((long)n * sizeof(int), 16);
     const size_t bytes = off_ovf + (size_t)n * sizeof(QpCarry);
     AA_CHECK(c->qpStats.alloc(bytes));
+    // samples in the order of their pass counts in the previous update of this context (iters_dev
+    // still holds them; the kernels below overwrite them); pointless when everybody gets the same
+    // one or two passes, and for the kernel that takes a wave per sample anyway
+    const bool will_sort = g_qp_sort && p->max_iterations > 2 && !wave_only && iters_dev &&
+                           iters_dev == c->qpIters.as<int>() && c->qp_iters_valid;
+    int *sort_hist = nullptr;
     if (A_host) {
         std::vector<unsigned char> host(off_rows, 0);
         double *Ah = reinterpret_cast<double *>(host.data() + off_A);
@@ -2091,11 +2098,15 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         AA_CHECK_HIP(hipStreamSynchronize(c->stream));   // host vector goes out of scope
     } else {
         AA_REQUIRE(gram_dev != nullptr, AA_ERR_ARG, "QP: no Hessian");
+        if (will_sort) {                               // its histograms are zeroed by the set-up kernel
+            AA_CHECK(c->qpPerm.alloc((size_t)n * sizeof(int) + 2 * QP_SORT_BUCKETS * sizeof(int)));
+            sort_hist = c->qpPerm.as<int>() + n;
+        }
         unsigned char *b0 = reinterpret_cast<unsigned char *>(c->qpStats.p);
         hipLaunchKernelGGL(k_qp_setup, dim3(1), dim3(256), 0, c->stream, reinterpret_cast<QpHeader *>(b0),
                            reinterpret_cast<double *>(b0 + off_A), reinterpret_cast<double *>(b0 + off_A2),
                            reinterpret_cast<double *>(b0 + off_bs), gram_dev,
-                           (const double *)c->alphaDev.as<double>(), k, KQ, KW, c->KP);
+                           (const double *)c->alphaDev.as<double>(), k, KQ, KW, c->KP, sort_hist);
     }
     unsigned char *base = reinterpret_cast<unsigned char *>(c->qpStats.p);
     QpHeader *hdr = reinterpret_cast<QpHeader *>(base);
@@ -2121,9 +2132,9 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         // reach the pass cap to a second wave-per-sample launch.
         const int *perm = nullptr;
         if (g_qp_profile) AA_CHECK_HIP(hipMemsetAsync(base + 64, 0, 64, c->stream));
-        const bool sorted = g_qp_sort && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid;
+        const bool sorted = will_sort;
         const bool hybrid = sorted && g_qp_row_long > 0 && c->stream2 && KW == 32 && p->memory <= 1;
-        if (sorted) AA_CHECK(qp_order_rows(c, iters_dev, n, &perm, hdr, hybrid ? g_qp_row_long : 0));
+        if (sorted) AA_CHECK(qp_order_rows(c, iters_dev, n, &perm, hdr, hybrid ? g_qp_row_long : 0, sort_hist != nullptr));
         int cap = g_qp_row_cap < 1 ? 1 : g_qp_row_cap;
         if (p->memory > 1 || p->max_iterations <= cap || KW != 32) cap = p->max_iterations;
         if (hybrid) {
@@ -2155,9 +2166,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         long waves = (n + 15) / 16;
         if (waves > g_qp_quad_waves) waves = g_qp_quad_waves;
         const int *perm = nullptr;
-        // (a cap of one or two passes for everybody: nothing to order, three launches saved)
-        if (g_qp_sort && p->max_iterations > 2 && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid)
-            AA_CHECK(qp_order_rows(c, iters_dev, n, &perm));
+        if (will_sort) AA_CHECK(qp_order_rows(c, iters_dev, n, &perm, nullptr, 0, sort_hist != nullptr));
         hipStream_t s_main = c->stream;
         // watchdog only: a wave's slots take their samples one after the other, each at most
         // cap passes and a start-up trip
@@ -2205,9 +2214,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         // samples ordered by their previous pass count (iters_dev still holds the counts of
         // the previous update of this context; the kernels below overwrite them)
         const int *perm = nullptr;
-        // (a cap of one or two passes for everybody: nothing to order, three launches saved)
-        if (g_qp_sort && p->max_iterations > 2 && iters_dev && iters_dev == c->qpIters.as<int>() && c->qp_iters_valid)
-            AA_CHECK(qp_order_rows(c, iters_dev, n, &perm));
+        if (will_sort) AA_CHECK(qp_order_rows(c, iters_dev, n, &perm, nullptr, 0, sort_hist != nullptr));
         QpDebug *dbgp = g_qp_profile ? reinterpret_cast<QpDebug *>(base + 64) : (QpDebug *)nullptr;
         if (dbgp) AA_CHECK_HIP(hipMemsetAsync(dbgp, 0, sizeof(QpDebug), c->stream));
 #define QPL4(KQV, FULLV, PROFV, SGV)                                                          \

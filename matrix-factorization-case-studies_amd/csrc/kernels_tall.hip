@@ -1817,11 +1817,17 @@ __global__ __launch_bounds__(256) void k_scale_gram(double *__restrict__ dst,
 
 // 0.5 (tr K - 2 tr(D C K Z) + tr(D Z'Z D C K C')) / n   (archetypal_analysis.py:553-556),
 // one block, fixed summation tree; state = [Z'Z | C K C' | C K Z]
+__device__ __forceinline__ void iter_judge_thread0(int it, double cost0, const double *__restrict__ costs,
+                                                   IterState *__restrict__ st, double tol, double mono_tol,
+                                                   int criterion, int require, int upd_dict, int upd_w,
+                                                   const double *__restrict__ scal, int track_spg);
+
 __global__ __launch_bounds__(256) void k_aa_cost(const double *__restrict__ state,
                                                  const double *__restrict__ alpha, int k, int KP,
                                                  double trace, double n_global,
                                                  double *__restrict__ out,
-                                                 int *__restrict__ slot_counter)
+                                                 int *__restrict__ slot_counter,
+                                                 const double *__restrict__ scal, GpnhJudge jd)
 {
     __shared__ double sm[256];
     const double *ZtZ = state, *CKCt = state + KP * KP, *CKZ = state + 2 * KP * KP;
@@ -1843,6 +1849,10 @@ __global__ __launch_bounds__(256) void k_aa_cost(const double *__restrict__ stat
     if (t == 0) {
         const int idx = slot_counter ? (*slot_counter)++ : 0;
         out[idx] = 0.5 * (trace + sm[0]) / n_global;
+        // the outer iteration's judge rides along with the iteration's last cost (aa_iterate)
+        if (jd.on)
+            iter_judge_thread0(jd.it, jd.cost0, out, jd.st, jd.tol, jd.mono_tol, jd.criterion, jd.require,
+                               jd.upd_dict, jd.upd_w, scal, jd.track_spg);
     }
 }
 
@@ -2180,11 +2190,12 @@ __global__ void k_cost_carry(double *__restrict__ costs, int *__restrict__ slot,
 }
 
 int launch_iter_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
-                      const aa_iter_params *ip)
+                      const aa_iter_params *ip, bool judged)
 {
-    hipLaunchKernelGGL(k_iter_judge, dim3(1), dim3(64), 0, c->stream, it, cost0, costs, st, ip->tolerance,
-                       ip->mono_tolerance, ip->criterion, ip->require_monotonic, ip->update_dictionary, ip->update_weights,
-                       (const double *)c->scalars.as<double>(), 1);
+    if (!judged)                                   // else: done by the cost kernel before it
+        hipLaunchKernelGGL(k_iter_judge, dim3(1), dim3(64), 0, c->stream, it, cost0, costs, st, ip->tolerance,
+                           ip->mono_tolerance, ip->criterion, ip->require_monotonic, ip->update_dictionary,
+                           ip->update_weights, (const double *)c->scalars.as<double>(), 1);
     hipLaunchKernelGGL(k_iter_snapshot, dim3(512), dim3(256), 0, c->stream, it, (const IterState *)st,
                        (const double *)c->Ct.as<double>(), (const double *)c->Zt.as<double>(),
                        c->snapC.as<double>(), c->snapZ.as<double>(), (long)c->n_pad * c->KP,
@@ -2448,12 +2459,16 @@ int launch_scale_gram(Ctx *c, double *dst, const double *src)
     return AA_OK;
 }
 
-int launch_aa_cost(Ctx *c, double *out_dev, int *slot_counter_dev)
+int launch_aa_cost(Ctx *c, double *out_dev, int *slot_counter_dev, const GpnhJudge *judge)
 {
+    GpnhJudge jd;
+    memset(&jd, 0, sizeof(jd));
+    if (judge) jd = *judge;
     hipLaunchKernelGGL(k_aa_cost, dim3(1), dim3(256), 0, c->stream,
                        (const double *)c->gramState.as<double>(),
                        (const double *)c->alphaDev.as<double>(), c->k, c->KP, c->trace,
-                       (double)c->n_global, out_dev, slot_counter_dev);
+                       (double)c->n_global, out_dev, slot_counter_dev,
+                       (const double *)c->scalars.as<double>(), jd);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }

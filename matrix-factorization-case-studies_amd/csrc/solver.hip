@@ -1040,11 +1040,25 @@ int aa_iterate(aa_ctx *h, const aa_iter_params *ip, const aa_spg_params *spg, co
             }
             if (ip->update_weights) {
                 AA_CHECK(weights_update(c, qp, nullptr));
-                AA_CHECK(launch_aa_cost(c, cd, slot));
+                GpnhJudge jd;                          // the judge rides in the cost kernel
+                memset(&jd, 0, sizeof(jd));
+                jd.on = 1;
+                jd.it = done + b;
+                jd.cost0 = cost0;
+                jd.tol = ip->tolerance;
+                jd.mono_tol = ip->mono_tolerance;
+                jd.criterion = ip->criterion;
+                jd.require = ip->require_monotonic;
+                jd.upd_dict = ip->update_dictionary;
+                jd.upd_w = ip->update_weights;
+                jd.st = st;
+                jd.track_spg = 1;
+                AA_CHECK(launch_aa_cost(c, cd, slot, &jd));
+                AA_CHECK(launch_iter_judge(c, done + b, cost0, cd, st, ip, true));
             } else {
                 AA_CHECK(launch_cost_carry(c, cd, slot, cost0));
+                AA_CHECK(launch_iter_judge(c, done + b, cost0, cd, st, ip));
             }
-            AA_CHECK(launch_iter_judge(c, done + b, cost0, cd, st, ip));
         }
         done += batch;
         AA_CHECK_HIP(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
@@ -1291,6 +1305,7 @@ int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp,
                 AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), nullptr));   // also the next solve's
                 ztx_current = true;
                 GpnhJudge jd;
+                memset(&jd, 0, sizeof(jd));
                 jd.on = 1;
                 jd.it = done + b;
                 jd.cost0 = cost0;
