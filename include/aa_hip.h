@@ -102,6 +102,8 @@ int aa_device_count(int *count);
  *   "row_local_waves"   0..16  waves per block of variant 8 (0: one block per CU)
  *   "proj_mode"         0|1    column simplex projection: 0 candidate lists, 1 iterative full
  *                               passes (also the fallback of a rank whose list overflows)
+ *   "proj_small"        0|1    1 (default): columns of at most 8192 entries (single rank) find their
+ *                               projection threshold in one kernel instead of four
  *   "proj_list_cap"     1..2048 multi-rank: most candidates per rank and column that travel in
  *                               the list all-reduce of a projection (effective: min(this,
  *                               2048 / ranks), so that the union fits the solver's LDS)

@@ -441,6 +441,75 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
     }
 }
 
+// Short columns (n <= 256 * PROJ_SMALL_RPT, single rank): the whole threshold search of a column in
+// ONE block -- its entries in registers, the lower bound (max - 1, or the Newton step from the
+// previous projection's threshold) and the Michelot fixed point of k_proj_solve on them -- instead
+// of the first pass, its finalize, the candidate lists and their solver (four launches of ~6 us
+// each; three projections per outer iteration are a fifth of the HadISST-shaped problem's time).
+#define PROJ_SMALL_RPT 32
+__global__ __launch_bounds__(256) void k_proj_small(const double *__restrict__ x,
+                                                    const double *__restrict__ g, double a_const,
+                                                    const double *__restrict__ scal, int a_slot, long n,
+                                                    int KP, int warm_slot, ProjState *__restrict__ ps)
+{
+    __shared__ double rs[4];
+    __shared__ int rm[4];
+    const int comp = blockIdx.x, t = threadIdx.x;
+    const double a = load_a(a_const, scal, a_slot);
+    double w[PROJ_SMALL_RPT];
+    double mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < PROJ_SMALL_RPT; ++q) {
+        const long r = t + 256L * q;
+        w[q] = -INFINITY;
+        if (r < n) w[q] = g ? x[r * KP + comp] - a * g[r * KP + comp] : x[r * KP + comp];
+        mx = fmax(mx, w[q]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((t & 63) == 0) rs[t >> 6] = mx;
+    __syncthreads();
+    mx = fmax(fmax(rs[0], rs[1]), fmax(rs[2], rs[3]));
+    __syncthreads();
+    // lower bound of t* (POST_FIRST): max - 1, or the Newton step from the warm threshold
+    double th = mx - 1.0;
+    if (warm_slot > 0) {
+        const double tw = ps->warm[warm_slot][comp];
+        double s = 0.0;
+        int m = 0;
+#pragma unroll
+        for (int q = 0; q < PROJ_SMALL_RPT; ++q)
+            if (w[q] > tw) { s += w[q]; m += 1; }
+        block_sum_sm(s, m, rs, rm);
+        if (m > 0) {
+            const double t1 = (s - 1.0) / (double)m;
+            if (t1 > th && t1 < mx) th = t1;
+        }
+    }
+    int prev = -1, conv = 0;
+    for (int it = 0; it < 200 && !conv; ++it) {          // the loop of k_proj_solve
+        double s = 0.0;
+        int m = 0;
+#pragma unroll
+        for (int q = 0; q < PROJ_SMALL_RPT; ++q)
+            if (w[q] > th) { s += w[q]; m += 1; }
+        block_sum_sm(s, m, rs, rm);
+        if (m == prev || (prev > 0 && m > prev) || m == 0) conv = 1;
+        if (m > 0 && m != prev) th = (s - 1.0) / (double)m;
+        if (m > 0) prev = m;
+    }
+    if (t == 0) {
+        ps->mx[comp] = mx;
+        ps->t[comp] = th;
+        ps->cnt[comp] = (double)prev;
+        ps->shrunk[comp] = conv;
+        if (comp == 0) {
+            ps->done = 0;
+            ps->passes = -1;                  // list mode: POST_FIN derives `done`
+        }
+    }
+}
+
 // multi-rank: the ranks' candidate lists side by side (gathered [world][KP][cap + 1], summed
 // all-reduce of per-rank slots) -> the same fixed point on every rank, lists concatenated in
 // rank order.  A rank whose list did not fit (count -1) leaves the column unconverged; the
@@ -1593,6 +1662,7 @@ static int g_proj_hard_cap = 200;
 
 int g_proj_mode = 0;        // 0: candidate lists, 1: iterative full passes
 int g_proj_check_always = 0; // multi-rank: 1 = check every list projection for overflow at once (host sync)
+int g_proj_small = 1;           // short columns: threshold search of a projection in one kernel (k_proj_small)
 int g_fuse_finalize = 1;    // 1: second reduction stages run in the last block of their producer (single rank)
 int g_proj_list_cap = 2048; // multi-rank: most candidates per rank and column in the list all-reduce
                             // (the union must fit the solver's LDS: effective cap = min(this, 2048 / world))
@@ -1657,7 +1727,10 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     if (!sp || !g_fuse_finalize) {
         // unfused: the caller launches the stage itself (see below)
     }
-    if (g_proj_mode == 0) {
+    if (g_proj_mode == 0 && !multi && g_proj_small && c->n <= 256L * PROJ_SMALL_RPT) {
+        hipLaunchKernelGGL(k_proj_small, dim3(c->k), dim3(256), 0, c->stream, x, g, a_const, (const double *)scal,
+                           a_slot, c->n, c->KP, c->projWarm[mode] ? mode : 0, ps);
+    } else if (g_proj_mode == 0) {
         const int RS = 256 / c->KP;
         const long nseg = (long)c->tallBlocks * RS, segcap = rpb / RS;
         TALL_DISPATCH_NT(PROJ_NT, k_proj_first, x, g, a_const, (const double *)scal, a_slot, c->n, rpb, c->k,

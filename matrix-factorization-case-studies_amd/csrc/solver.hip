@@ -461,6 +461,8 @@ int aa_set_option(const char *name, int value)
         g_qp_overlap_tail = value != 0;
     } else if (!strcmp(name, "use_graph")) {
         g_use_graph = value != 0;
+    } else if (!strcmp(name, "proj_small")) {
+        g_proj_small = value != 0;
     } else if (!strcmp(name, "qp_profile")) {
         g_qp_profile = value != 0;
     } else if (!strcmp(name, "qp_sort")) {

@@ -613,14 +613,20 @@ def test_rccl_path_single_rank(cdr, orc):
             os.environ.pop("AA_FORCE_RCCL", None)
             _backend.set_option("proj_mode", 0)
             _backend.set_option("proj_list_cap", 2048)
+            _backend.set_option("proj_small", 1)
 
-    for opts in (dict(), dict(proj_mode=1)):
+    # bit-for-bit: both paths on the candidate-list projection (the single-rank default for
+    # columns this short, the one-kernel threshold search, sums in another order)
+    for opts in (dict(proj_small=0), dict(proj_mode=1)):
         a, b = run(False, **opts), run(True, **opts)
         assert a[0] == b[0] and np.array_equal(a[1], b[1])
         assert np.allclose(a[2], b[2], rtol=1e-6, atol=1e-6)   # the row travels through float64
         assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
         assert np.array_equal(b[5], [1.5, 2.5])
-    a, c = run(False), run(True, proj_list_cap=1)
+    small = run(False)                                   # one-kernel threshold search: rounding level
+    assert abs(small[0] - a[0]) < 1e-12 * abs(a[0]) and np.abs(small[1] - a[1]).max() < 1e-6 * abs(a[0])
+    assert np.abs(small[3] - a[3]).max() < 1e-6 and np.abs(small[4] - a[4]).max() < 1e-5
+    a, c = run(False, proj_small=0), run(True, proj_list_cap=1)
     assert np.abs(np.asarray(a[1]) - np.asarray(c[1])).max() < 1e-9 * abs(a[0])
     assert np.abs(a[3] - c[3]).max() < 1e-12 and np.abs(a[4] - c[4]).max() < 1e-9
 
