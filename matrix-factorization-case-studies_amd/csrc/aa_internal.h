@@ -297,7 +297,7 @@ int launch_simplex_rows_generic(hipStream_t s, const double *in, double *out, lo
 
 extern int g_use_graph;           // solver.hip
 extern int g_proj_mode;           // kernels_tall.hip
-extern int g_proj_small;           // kernels_tall.hip
+extern int g_proj_small, g_pq_blocks;           // kernels_tall.hip
 extern int g_fuse_finalize;       // kernels_tall.hip
 extern int g_proj_check_always;   // kernels_tall.hip
 extern int g_proj_list_cap;       // kernels_tall.hip

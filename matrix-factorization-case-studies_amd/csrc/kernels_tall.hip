@@ -1662,6 +1662,8 @@ static int g_proj_hard_cap = 200;
 
 int g_proj_mode = 0;        // 0: candidate lists, 1: iterative full passes
 int g_proj_check_always = 0; // multi-rank: 1 = check every list projection for overflow at once (host sync)
+int g_pq_blocks = 128;          // most blocks of k_gram_wide_pq (their partial Grams are summed by ONE block; 64 -> 128:
+                                // C2, p = 25 000, 0.553 -> 0.537 ms per iteration; 256: 0.548)
 int g_proj_small = 1;           // short columns: threshold search of a projection in one kernel (k_proj_small)
 int g_fuse_finalize = 1;    // 1: second reduction stages run in the last block of their producer (single rank)
 int g_proj_list_cap = 2048; // multi-rank: most candidates per rank and column in the list all-reduce
@@ -2573,7 +2575,8 @@ int launch_gram_wide(Ctx *c, const double *A, const double *B, double *out_dev)
 int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, int *cost_slot)
 {
     const long chunks = c->p_pad / 128;
-    const int cpb = (int)((chunks + 63) / 64) * 128;          // columns per block: <= 64 blocks
+    const int mb = g_pq_blocks < 1 ? 1 : g_pq_blocks;
+    const int cpb = (int)((chunks + mb - 1) / mb) * 128;      // columns per block: <= g_pq_blocks blocks
     const int nb = (int)((c->p_pad + cpb - 1) / cpb);
     double *part = c->redPartial.as<double>();
     double *ckct = c->gramState.as<double>() + (size_t)c->KP * c->KP;
