@@ -131,8 +131,9 @@ int aa_device_count(int *count);
  *                               1: one wave per sample; 2: lane-per-sample + wave; 3: row kernel
  *                               (16 lanes per sample, samples run to completion); 4: four lanes per
  *                               sample + wave
- *   "qp_quad_cap"       >= 1   SPG passes after which the four-lane kernel parks a sample for the
- *                               wave-per-sample kernel (default 24)
+ *   "qp_quad_cap"       >= 0   SPG passes after which the four-lane kernel parks a sample for the
+ *                               wave-per-sample kernel (default 0: 32 from 65 536 samples per GPU,
+ *                               24 below)
  *   "qp_quad_waves"     >= 1   most waves (16 samples each) of the four-lane kernel (default 8192:
  *                               up to 131 072 samples every wave takes one batch)
  *   "qp_quad_occ"       2..4   register budget of the four-lane kernel in waves per SIMD (default 3)

@@ -1919,7 +1919,9 @@ int g_qp_mode = 0;             // 0: by size (see launch_qp), 1: wave-per-sample
 int g_qp_quad_waves = 8192;    // most waves of k_qp_quad: up to 131 072 samples every wave takes ONE batch of 16
                                // and the hardware hands the batches (longest first) to SIMDs as they free up
 int g_qp_quad_refill = 16;     // idle sample slots (of 16) of a wave that trigger a refill
-int g_qp_quad_cap = 24;        // passes after which k_qp_quad parks a sample for the wave kernel
+int g_qp_quad_cap = 0;         // passes after which k_qp_quad parks a sample for the wave kernel; 0: by size --
+                               // 32 from 65 536 samples per GPU (100 000: 1.985 against 2.010 ms per outer
+                               // iteration), 24 below (12 500: 0.572 against 0.582)
 int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
 int g_qp_profile = 0;          // cycle accounting of k_qp (printed when stats are requested)
@@ -2163,7 +2165,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                                stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr);
     } else if (quad_mode) {
-        int cap = g_qp_quad_cap < 1 ? 1 : g_qp_quad_cap;
+        int cap = g_qp_quad_cap > 0 ? g_qp_quad_cap : (n >= 65536 ? 32 : 24);
         if (p->memory > 1 || p->max_iterations <= cap) cap = p->max_iterations;
         long waves = (n + 15) / 16;
         if (waves > g_qp_quad_waves) waves = g_qp_quad_waves;

@@ -486,7 +486,7 @@ int aa_set_option(const char *name, int value)
         AA_REQUIRE(value >= 2 && value <= 4, AA_ERR_ARG, "qp_quad_occ must be 2, 3 or 4");
         g_qp_quad_occ = value;
     } else if (!strcmp(name, "qp_quad_cap")) {
-        AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_quad_cap must be >= 1");
+        AA_REQUIRE(value >= 0, AA_ERR_ARG, "qp_quad_cap must be >= 0");
         g_qp_quad_cap = value;
     } else if (!strcmp(name, "qp_row_waves")) {
         AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_row_waves must be >= 1");
