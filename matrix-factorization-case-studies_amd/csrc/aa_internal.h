@@ -309,6 +309,7 @@ extern int g_f64_mfma;            // kernels_gemm.hip
 extern int g_reduce_rows_blocks;  // kernels_gemm.hip
 extern int g_qp_pass_cap;         // kernels_qp.hip
 extern int g_qp_mode;             // kernels_qp.hip
+extern int g_qp_wave_blocks;
 extern int g_qp_quad_waves, g_qp_quad_refill, g_qp_quad_cap, g_qp_quad_occ;   // kernels_qp.hip
 extern int g_qp_row_waves;        // kernels_qp.hip
 extern int g_qp_matvec;           // kernels_qp.hip

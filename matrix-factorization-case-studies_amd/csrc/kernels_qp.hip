@@ -1922,6 +1922,7 @@ int g_qp_quad_refill = 16;     // idle sample slots (of 16) of a wave that trigg
 int g_qp_quad_cap = 0;         // passes after which k_qp_quad parks a sample for the wave kernel; 0: by size --
                                // 32 from 65 536 samples per GPU (100 000: 1.985 against 2.010 ms per outer
                                // iteration), 24 below (12 500: 0.572 against 0.582)
+int g_qp_wave_blocks = 1024;   // blocks (4 waves each) of the wave-per-sample kernel when it finishes parked samples
 int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
 int g_qp_profile = 0;          // cycle accounting of k_qp (printed when stats are requested)
@@ -2161,7 +2162,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                                g_qp_row_hot, g_qp_profile, g_qp_row_chunk, cap, ovf_rows, ovf);
         if (hybrid) AA_CHECK_HIP(hipStreamWaitEvent(c->stream, c->evJoin, 0));
         if (cap < p->max_iterations)
-            hipLaunchKernelGGL(k_qp_wave<32>, dim3(1024), dim3(256), 0, c->stream, A2d, Btall, stride_j,
+            hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, c->stream, A2d, Btall, stride_j,
                                stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr);
     } else if (quad_mode) {
@@ -2192,7 +2193,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
 #undef QQL
 #undef QQK
         if (cap < p->max_iterations)
-            hipLaunchKernelGGL(k_qp_wave<32>, dim3(1024), dim3(256), 0, c->stream, A2d, Btall, stride_j,
+            hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, c->stream, A2d, Btall, stride_j,
                                stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr);
     } else if (wave_only) {
@@ -2254,7 +2255,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                 s2 = c->stream2;
                 zslot = c->tmpTall.as<double>();
             }
-            hipLaunchKernelGGL(k_qp_wave<32>, dim3(1024), dim3(256), 0, s2, A2d, Btall, stride_j,
+            hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, s2, A2d, Btall, stride_j,
                                stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                (const int *)ovf_rows, (const QpCarry *)ovf, zslot);
             if (defer) {

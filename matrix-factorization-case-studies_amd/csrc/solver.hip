@@ -482,6 +482,9 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "qp_quad_refill")) {
         AA_REQUIRE(value >= 1 && value <= 16, AA_ERR_ARG, "qp_quad_refill must be in 1..16");
         g_qp_quad_refill = value;
+    } else if (!strcmp(name, "qp_wave_blocks")) {
+        AA_REQUIRE(value >= 1 && value <= 8192, AA_ERR_ARG, "qp_wave_blocks must be in 1..8192");
+        g_qp_wave_blocks = value;
     } else if (!strcmp(name, "qp_quad_occ")) {
         AA_REQUIRE(value >= 2 && value <= 4, AA_ERR_ARG, "qp_quad_occ must be 2, 3 or 4");
         g_qp_quad_occ = value;
