@@ -360,6 +360,26 @@ int aa_gpnh_weights_update(aa_ctx *ctx, const double *WtW, const aa_qp_params *p
  * without the penalty term (added on the host). */
 int aa_gpnh_residual_cost(aa_ctx *ctx, double *cost);
 
+/* ------------------------------------------------------------ the two passes, on their own */
+/* The two contractions against the resident matrix that every update is built from, callable
+ * with caller-supplied small operands (unit tests of the pass kernels against X.dot(...) in
+ * float64; the reference's C.dot(X), X.T.dot(Z) at archetypal_analysis.py:614,627 and
+ * CX.dot(X.T), X.dot(XtZ) at :615,628):
+ *   aa_pass_reduce_rows: out[k][p] (ld = ldo) = A' X,  A host n x k row-major (tall operand);
+ *   aa_pass_row_local:   out[n][k]            = X B',  B host k x p row-major (ld = ldb).
+ * Both size the context's factor buffers for k components (like aa_set_state) and leave the
+ * solver state invalid (aa_set_state / aa_prepare must follow before any update). */
+int aa_pass_reduce_rows(aa_ctx *ctx, int k, const double *A, double *out, long ldo);
+int aa_pass_row_local(aa_ctx *ctx, int k, const double *B, long ldb, double *out);
+
+/* Diagnostics: the scalar state of the latest dictionary SPG iteration (device-resident, see
+ * csrc/aa_internal.h: ScalarSlot), copied to out[0..AA_SPG_SCALARS).  Layout: 0 tr, 1 tr(C HD),
+ * 2 tr(M C K C'), 3 f_old, 4 f_new, 5 alpha (BB / first step), 6 alpha_set, 7 lambda,
+ * 8 <d,g>, 9 <d,d>, 10 tr(D HD), 11 a1, 12 a2, 13 <d,g_new>, 14 ||res||^2, 15 ||res||_inf,
+ * 16 n_feval, 17 flags, 18 projection multiplier, 19 max|P(x-g)-x|, 20 divisor of f. */
+#define AA_SPG_SCALARS 21
+int aa_get_spg_scalars(aa_ctx *ctx, double *out);
+
 /* ------------------------------------------------------------ measurement */
 /* Time `reps` launches of one hot-path GEMM kernel with HIP events on the
  * context's stream.  which: 0 = reduce-over-rows (C X, X'Z; k x p out),

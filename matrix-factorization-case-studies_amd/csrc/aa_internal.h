@@ -260,7 +260,7 @@ int launch_cost_carry(Ctx *c, double *costs, int *slot, double cost0);
 int launch_scale_factors(Ctx *c, const aa_spg_params *sp, double delta_box, int it, double cost0,
                          const double *costs, const int *slot, IterState *st, double mono_tol, int require);
 int launch_col_has_nan(Ctx *c, const void *raw_dev, int host_dtype, long ld, long n_total, long p_full,
-                       unsigned char *flags_dev);
+                       const double *w_dev /*nullable*/, unsigned char *flags_dev);
 int launch_gather_weight(Ctx *c, const void *raw_dev, int host_dtype, long ld, long row0, long n,
                          const int *idx_dev, long p_valid, const double *w_dev);
 int launch_data_to_double(Ctx *c, double *out_dev);
@@ -303,6 +303,7 @@ extern int g_proj_check_always;   // kernels_tall.hip
 extern int g_proj_list_cap;       // kernels_tall.hip
 extern int g_row_local_variant;   // kernels_gemm.hip
 extern int g_row_local_waves;     // kernels_gemm.hip
+extern int g_row_local_split, g_row_local_chunk, g_row_local_acc64;     // kernels_gemm.hip
 extern int g_row_local_stagger;   // kernels_gemm.hip
 extern int g_reduce_rows_unroll;  // kernels_gemm.hip
 extern int g_f64_mfma;            // kernels_gemm.hip

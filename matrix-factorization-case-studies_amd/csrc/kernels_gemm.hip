@@ -598,7 +598,7 @@ __device__ __forceinline__ int rl_phys_chunk(int row, int chunk)
 // blockIdx.y: column chunk of `col_chunk` columns (a multiple of TC), partial result to
 // out + blockIdx.y * n_pad * KP, summed in a fixed order by k_sum_chunks -- short shards (the
 // 12 500 rows of an 8-GPU run are 98 row blocks) otherwise leave most CUs idle.
-template <int NCT, int TC, bool DB>
+template <int NCT, int TC, bool DB, bool ACC64 = false>
 __global__ __launch_bounds__(256) void k_row_local_f32_blk(const float *__restrict__ X, long ldx,
                                                            const float *__restrict__ B, int p_pad,
                                                            double *__restrict__ out, long n_pad,
@@ -617,10 +617,15 @@ __global__ __launch_bounds__(256) void k_row_local_f32_blk(const float *__restri
     const int h = lane >> 5, j = lane & 31;
 
     f32x16 acc[NCT];
+    double accd[ACC64 ? NCT : 1][16];            // ACC64: see k_row_local_f32_ws
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < (ACC64 ? NCT : 1); ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accd[ct][e] = 0.0;
 
     const int xr = lane / CPR, xc = lane % CPR;
     const float *gx = X + (r0 + xr) * ldx + 4 * xc;
@@ -663,6 +668,17 @@ __global__ __launch_bounds__(256) void k_row_local_f32_blk(const float *__restri
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct)
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[ct][m], acc[ct], 0, 0, 0);
+            if constexpr (ACC64) {
+                if ((q & 3) == 3) {                 // 32 columns done: the fp32 chain ends here
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            accd[ct][e] += (double)acc[ct][e];
+                            acc[ct][e] = 0.f;
+                        }
+                }
+            }
         }
     };
 
@@ -698,7 +714,8 @@ __global__ __launch_bounds__(256) void k_row_local_f32_blk(const float *__restri
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const long row = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            out[row * KP + ct * 32 + j] = (double)acc[ct][reg];
+            if constexpr (ACC64) out[row * KP + ct * 32 + j] = accd[ct][reg];
+            else out[row * KP + ct * 32 + j] = (double)acc[ct][reg];
         }
 }
 
@@ -710,8 +727,15 @@ __global__ __launch_bounds__(256) void k_row_local_f32_blk(const float *__restri
 // tile register-prefetched ahead.  The small operand B is shared by the whole block as
 // double-buffered 128-column slabs in LDS: one barrier per 128 columns, B crosses
 // L2->LDS once per W*32 rows.  Dynamic LDS = 2 slabs (KP*512 B each) + W * 8 KB.
-template <int NCT>
-__global__ __launch_bounds__(NCT == 1 ? 1024 : 768) void k_row_local_f32_ws(const float *__restrict__ X, long ldx,
+// ACC64: the fp32 accumulation chain is cut after every 32 columns (16 matrix instructions) and
+// the partial sums are added up in float64 (VALU, 32 more registers => 3 waves per SIMD, W <= 12).
+// x_r . p_i is a COHERENT sum (a sample against an archetype built from samples like it), so the
+// fp32 rounding of a long running sum is systematic: relative error ~ eps32 * L / 400 for chains of
+// L columns -- 6.9e-7 unchained (measured, p = 4096), 8.8e-8 at L = 512, 5e-9 at L = 32.  On
+// bench.py's parity_converged problem that difference decides whether a float32 run stays on
+// the reference's trajectory.
+template <int NCT, bool ACC64>
+__global__ __launch_bounds__(!ACC64 ? (NCT == 1 ? 1024 : 768) : (NCT == 1 ? 768 : 512)) void k_row_local_f32_ws(const float *__restrict__ X, long ldx,
                                                            const float *__restrict__ B, int p_pad,
                                                            double *__restrict__ out, long n_pad,
                                                            int W, int stagger)
@@ -731,10 +755,15 @@ __global__ __launch_bounds__(NCT == 1 ? 1024 : 768) void k_row_local_f32_ws(cons
     const int h = lane >> 5, j = lane & 31;
 
     f32x16 acc[NCT];
+    double accd[ACC64 ? NCT : 1][16];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < (ACC64 ? NCT : 1); ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accd[ct][e] = 0.0;
 
     f32x4 sb[NBI], sx[8];
     auto load_b = [&](int c0) {
@@ -777,18 +806,35 @@ __global__ __launch_bounds__(NCT == 1 ? 1024 : 768) void k_row_local_f32_ws(cons
             for (int ct = 0; ct < NCT; ++ct)
                 fb[ct] = *reinterpret_cast<const f32x4 *>(bb + (ct * 32 + j) * SB + pcb);
         };
-        frag(0, a, bv);
+        if constexpr (!ACC64 || NCT == 1) frag(0, a, bv);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (q + 1 < 8) frag(q + 1, an, bn);     // fragments of the next step in flight
+            if constexpr (!ACC64 || NCT == 1) {
+                if (q + 1 < 8) frag(q + 1, an, bn);     // fragments of the next step in flight
+            } else {
+                frag(q, a, bv);                         // k > 32 with float64 sums: no second fragment set
+            }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct)
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[ct][m], acc[ct], 0, 0, 0);
-            a = an;
+            if constexpr (!ACC64 || NCT == 1) {
+                a = an;
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) bv[ct] = bn[ct];
+                for (int ct = 0; ct < NCT; ++ct) bv[ct] = bn[ct];
+            }
+            if constexpr (ACC64) {
+                if ((q & 3) == 3) {                 // 32 columns done: the chain ends here
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            accd[ct][e] += (double)acc[ct][e];
+                            acc[ct][e] = 0.f;
+                        }
+                }
+            }
         }
     };
 
@@ -826,7 +872,8 @@ __global__ __launch_bounds__(NCT == 1 ? 1024 : 768) void k_row_local_f32_ws(cons
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const long row = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                out[row * KP + ct * 32 + j] = (double)acc[ct][reg];
+                if constexpr (ACC64) out[row * KP + ct * 32 + j] = accd[ct][reg];
+                else out[row * KP + ct * 32 + j] = (double)acc[ct][reg];
             }
     }
 }
@@ -1097,6 +1144,11 @@ int g_reduce_rows_unroll = 4;  // row pairs per software-pipeline half step (4 o
 int g_reduce_rows_blocks = 512; // target block count of the reduce-over-rows kernel
 int g_row_local_stagger = 0;   // variant 8: column-slab offset between consecutive blocks
 int g_row_local_waves = 0;     // variant 8: waves per block (0 = one block per CU)
+int g_row_local_acc64 = 1;     // float32 row-local kernels: cut the fp32 accumulation chain every 32 columns and sum the
+                               // pieces in float64 -- 0: never, 1: in the block-tiled kernel (< 32768 rows per GPU; free
+                               // there), 2: in the wave-streaming kernel too (costs it a wave per SIMD: 0.31 -> 0.6 ms)
+int g_row_local_chunk = 0;     // experiment: force the column chunk of the block-tiled float32 kernel (0: by size)
+int g_row_local_split = 1;     // block-tiled kernels: split the contraction over column chunks when there are few row blocks
 static int row_local_variant(const Ctx *c)
 {
     if (g_row_local_variant >= 0) return g_row_local_variant;
@@ -1112,33 +1164,36 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
         const float *B = reinterpret_cast<const float *>(B_wideT);
         const int nct = c->KP / 32;
         const long tiles = c->n_pad / 32;
-        const int wmax = nct == 1 ? 16 : 12;              // 160 KB of LDS
+        const bool a64 = g_row_local_acc64 >= 2;
+        const int wmax = !a64 ? (nct == 1 ? 16 : 12) : (nct == 1 ? 12 : 8);   // 160 KB of LDS; float64 sums: 3 (2) waves per SIMD
         int W = g_row_local_waves > 0 ? g_row_local_waves : (int)((tiles + 255) / 256);
         if (W < 8) W = 8;                                 // the B slab loader assumes >= 512 threads
         if (W > wmax) W = wmax;
         const size_t lds = ((size_t)2 * c->KP * 128 + (size_t)W * 32 * 64) * sizeof(float);
         static bool attr_set[64] = {false};                 // the attribute is per device
         if (!attr_set[c->device & 63]) {
-            AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_local_f32_ws<1>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_local_f32_ws<2>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            const void *fns[4] = {reinterpret_cast<const void *>(&k_row_local_f32_ws<1, false>),
+                                  reinterpret_cast<const void *>(&k_row_local_f32_ws<2, false>),
+                                  reinterpret_cast<const void *>(&k_row_local_f32_ws<1, true>),
+                                  reinterpret_cast<const void *>(&k_row_local_f32_ws<2, true>)};
+            for (const void *fn : fns)
+                AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set[c->device & 63] = true;
         }
         dim3 grid((unsigned)((tiles + W - 1) / W)), blk((unsigned)(64 * W));
-        if (nct == 1)
-            hipLaunchKernelGGL(k_row_local_f32_ws<1>, grid, blk, lds, c->stream, c->X.as<float>(),
-                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, g_row_local_stagger);
-        else
-            hipLaunchKernelGGL(k_row_local_f32_ws<2>, grid, blk, lds, c->stream, c->X.as<float>(),
-                               c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, g_row_local_stagger);
+#define RLW(NCTV, A64V)                                                                              \
+    hipLaunchKernelGGL((k_row_local_f32_ws<NCTV, A64V>), grid, blk, lds, c->stream, c->X.as<float>(), \
+                       c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, g_row_local_stagger)
+        if (nct == 1) { if (a64) RLW(1, true); else RLW(1, false); }
+        else          { if (a64) RLW(2, true); else RLW(2, false); }
+#undef RLW
     } else if (c->dtype == AA_F32 && row_local_variant(c) >= 2) {
         const float *B = reinterpret_cast<const float *>(B_wideT);
         // few row blocks (short shards): split the contraction over column chunks as well, about
         // three blocks per CU, chunks of >= 512 columns (a multiple of every tile width)
         const long rblocks = c->n_pad / 128;
         int nsplit = 1, chunk = (int)c->p_pad;
-        if (rblocks < 384) {
+        if (rblocks < 384 && g_row_local_split) {
             nsplit = (int)((768 + rblocks - 1) / rblocks);
             const int max_split = (int)(c->p_pad / 512);
             if (nsplit > max_split) nsplit = max_split;
@@ -1149,14 +1204,25 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
             chunk = (int)round_up((c->p_pad + nsplit - 1) / nsplit, 128);
             nsplit = (int)((c->p_pad + chunk - 1) / chunk);
         }
+        if (g_row_local_chunk > 0) {
+            chunk = (int)round_up(g_row_local_chunk, 128);
+            if (row_local_variant(c) == 7 || row_local_variant(c) == 5) chunk = (int)round_up(g_row_local_chunk, 32);
+            nsplit = (int)((c->p_pad + chunk - 1) / chunk);
+        }
         if (nsplit > 1) {
             AA_CHECK(c->rlPartial.alloc((size_t)nsplit * c->n_pad * c->KP * sizeof(double)));
             dst = c->rlPartial.as<double>();
         }
         dim3 grid((unsigned)rblocks, (unsigned)nsplit);
 #define RLB(NCTV, TCV, DBV)                                                                   \
-    hipLaunchKernelGGL((k_row_local_f32_blk<NCTV, TCV, DBV>), grid, block, 0, c->stream,       \
-                       c->X.as<float>(), c->p_pad, B, (int)c->p_pad, dst, c->n_pad, chunk)
+    do {                                                                                      \
+        if (g_row_local_acc64)                                                                \
+            hipLaunchKernelGGL((k_row_local_f32_blk<NCTV, TCV, DBV, true>), grid, block, 0, c->stream, \
+                               c->X.as<float>(), c->p_pad, B, (int)c->p_pad, dst, c->n_pad, chunk);    \
+        else                                                                                  \
+            hipLaunchKernelGGL((k_row_local_f32_blk<NCTV, TCV, DBV, false>), grid, block, 0, c->stream, \
+                               c->X.as<float>(), c->p_pad, B, (int)c->p_pad, dst, c->n_pad, chunk);    \
+    } while (0)
         const int v = row_local_variant(c);
         if (c->KP == 32) {
             switch (v) {
@@ -1232,7 +1298,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
             // few row blocks (short, wide data): split the contraction over column chunks too
             const long rblocks = c->n_pad / 64;
             int nsplit = 1;
-            if (rblocks < 192) {
+            if (rblocks < 192 && g_row_local_split) {
                 nsplit = (int)((512 + rblocks - 1) / rblocks);
                 const int max_split = (int)(c->p_pad / 256);       // >= 256 columns per chunk
                 if (nsplit > max_split) nsplit = max_split;

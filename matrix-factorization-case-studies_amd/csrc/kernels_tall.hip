@@ -1940,22 +1940,28 @@ __global__ void k_set_scalars(double *__restrict__ sc, double trace, double fnor
 }
 
 // ---------------------------------------------------------------- driver preprocessing
-// flags[c] = 1 when column c of the raw field holds a NaN in any row (run_hadisst_aa.py:201)
+// flags[c] = 1 when column c of the WEIGHTED field holds a NaN in any row (run_hadisst_aa.py:133,201:
+// the mask is taken on weights * da, so a NaN weight or 0 * inf drops the column too).  blockIdx.y
+// strides over the rows; a thread that sees a NaN stores 1 (flags are zero-initialised, the stores
+// are idempotent: no atomics).
 template <typename T>
 __global__ __launch_bounds__(256) void k_col_has_nan(const T *__restrict__ raw, long ld, long n_total,
-                                                     long p_full, unsigned char *__restrict__ flags)
+                                                     long p_full, const double *__restrict__ w,
+                                                     unsigned char *__restrict__ flags)
 {
     const long c = (long)blockIdx.x * 256 + threadIdx.x;
     if (c >= p_full) return;
+    const double wc = w ? w[c] : 1.0;
     int bad = 0;
-    for (long r = 0; r < n_total; ++r) {
-        const T v = raw[r * ld + c];
+    for (long r = blockIdx.y; r < n_total; r += gridDim.y) {
+        const double v = (double)raw[r * ld + c] * wc;
         bad |= (v != v) ? 1 : 0;
     }
-    flags[c] = (unsigned char)bad;
+    if (bad) flags[c] = (unsigned char)1;
 }
 
 // X[r][j] = raw[row0 + r][idx[j]] * w[idx[j]]   (weights * da, then valid_data[:n_training], :133-146,:202-208)
+// rows: grid-stride over blockIdx.y (gridDim.y <= 65535 whatever n is)
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void k_gather_weight(const TI *__restrict__ raw, long ld, long row0,
                                                        long n, const int *__restrict__ idx, long p_valid,
@@ -1963,11 +1969,13 @@ __global__ __launch_bounds__(256) void k_gather_weight(const TI *__restrict__ ra
                                                        long ldx)
 {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
-    const long r = blockIdx.y;
-    if (j >= p_valid || r >= n) return;
+    if (j >= p_valid) return;
     const int src = idx[j];
-    const double v = (double)raw[(row0 + r) * ld + src] * (w ? w[src] : 1.0);
-    X[r * ldx + j] = (TO)v;
+    const double wj = w ? w[src] : 1.0;
+    for (long r = blockIdx.y; r < n; r += gridDim.y) {
+        const double v = (double)raw[(row0 + r) * ld + src] * wj;
+        X[r * ldx + j] = (TO)v;
+    }
 }
 
 template <typename T>
@@ -1975,20 +1983,27 @@ __global__ __launch_bounds__(256) void k_data_to_double(const T *__restrict__ X,
                                                         double *__restrict__ out)
 {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
-    const long r = blockIdx.y;
-    if (j < p && r < n) out[r * p + j] = (double)X[r * ldx + j];
+    if (j >= p) return;
+    for (long r = blockIdx.y; r < n; r += gridDim.y) out[r * p + j] = (double)X[r * ldx + j];
 }
 
+static inline unsigned row_grid(long rows) { return (unsigned)(rows < 4096 ? (rows < 1 ? 1 : rows) : 4096); }
+
 int launch_col_has_nan(Ctx *c, const void *raw_dev, int host_dtype, long ld, long n_total, long p_full,
-                       unsigned char *flags_dev)
+                       const double *w_dev, unsigned char *flags_dev)
 {
-    const dim3 grid((unsigned)((p_full + 255) / 256));
+    const long xb = (p_full + 255) / 256;
+    // enough blocks to fill the chip when the field has few columns, never more than the rows
+    long yb = (2048 + xb - 1) / xb;
+    if (yb > n_total) yb = n_total;
+    const dim3 grid((unsigned)xb, row_grid(yb));
+    AA_CHECK_HIP(hipMemsetAsync(flags_dev, 0, (size_t)p_full, c->stream));
     if (host_dtype == AA_F32)
         hipLaunchKernelGGL(k_col_has_nan<float>, grid, dim3(256), 0, c->stream,
-                           reinterpret_cast<const float *>(raw_dev), ld, n_total, p_full, flags_dev);
+                           reinterpret_cast<const float *>(raw_dev), ld, n_total, p_full, w_dev, flags_dev);
     else
         hipLaunchKernelGGL(k_col_has_nan<double>, grid, dim3(256), 0, c->stream,
-                           reinterpret_cast<const double *>(raw_dev), ld, n_total, p_full, flags_dev);
+                           reinterpret_cast<const double *>(raw_dev), ld, n_total, p_full, w_dev, flags_dev);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
@@ -1996,7 +2011,7 @@ int launch_col_has_nan(Ctx *c, const void *raw_dev, int host_dtype, long ld, lon
 int launch_gather_weight(Ctx *c, const void *raw_dev, int host_dtype, long ld, long row0, long n,
                          const int *idx_dev, long p_valid, const double *w_dev)
 {
-    const dim3 grid((unsigned)((p_valid + 255) / 256), (unsigned)n);
+    const dim3 grid((unsigned)((p_valid + 255) / 256), row_grid(n));
 #define GW(TI, TO)                                                                                  \
     hipLaunchKernelGGL((k_gather_weight<TI, TO>), grid, dim3(256), 0, c->stream,                     \
                        reinterpret_cast<const TI *>(raw_dev), ld, row0, n, idx_dev, p_valid, w_dev,  \
@@ -2013,7 +2028,7 @@ int launch_gather_weight(Ctx *c, const void *raw_dev, int host_dtype, long ld, l
 
 int launch_data_to_double(Ctx *c, double *out_dev)
 {
-    const dim3 grid((unsigned)((c->p + 255) / 256), (unsigned)c->n);
+    const dim3 grid((unsigned)((c->p + 255) / 256), row_grid(c->n));
     if (c->dtype == AA_F32)
         hipLaunchKernelGGL(k_data_to_double<float>, grid, dim3(256), 0, c->stream, c->X.as<float>(), c->p_pad,
                            c->n, c->p, out_dev);

@@ -17,6 +17,8 @@
 // sigma_one is an absolute bound (spg.py:28).
 #include "aa_internal.h"
 
+#include <mutex>
+
 namespace aa {
 
 int g_use_graph = 0;     // 1: aa_outer_iterations replays a captured pair of iterations (measured neutral)
@@ -435,6 +437,14 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "row_local_waves")) {
         AA_REQUIRE(value == 0 || (value >= 8 && value <= 16), AA_ERR_ARG, "row_local_waves must be 0 or 8..16");
         g_row_local_waves = value;
+    } else if (!strcmp(name, "row_local_acc64")) {
+        AA_REQUIRE(value >= 0 && value <= 2, AA_ERR_ARG, "row_local_acc64 must be 0, 1 or 2");
+        g_row_local_acc64 = value;
+    } else if (!strcmp(name, "row_local_chunk")) {
+        AA_REQUIRE(value >= 0, AA_ERR_ARG, "row_local_chunk must be >= 0");
+        g_row_local_chunk = value;
+    } else if (!strcmp(name, "row_local_split")) {
+        g_row_local_split = value != 0;
     } else if (!strcmp(name, "f64_mfma")) {
         AA_REQUIRE(value >= 0 && value <= 3, AA_ERR_ARG, "f64_mfma must be in 0..3");
         g_f64_mfma = value;
@@ -722,11 +732,16 @@ int aa_set_data_weighted(aa_ctx *h, const void *raw, int host_dtype, long n_tota
     DevBuf draw, dflag, didx, dw;
     int rc = draw.alloc((size_t)n_total * p_full * hes);
     if (rc == AA_OK) rc = dflag.alloc((size_t)p_full);
-    if (rc != AA_OK) { draw.release(); dflag.release(); return rc; }
+    if (rc == AA_OK && col_weight) rc = dw.alloc((size_t)p_full * sizeof(double));
+    if (rc != AA_OK) { draw.release(); dflag.release(); dw.release(); return rc; }
     hipError_t e = hipMemcpy2D(draw.p, (size_t)p_full * hes, raw, (size_t)ld * hes, (size_t)p_full * hes,
                                (size_t)n_total, hipMemcpyHostToDevice);
+    if (e == hipSuccess && col_weight)
+        e = hipMemcpy(dw.p, col_weight, (size_t)p_full * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        rc = launch_col_has_nan(c, draw.p, host_dtype, p_full, n_total, p_full, dflag.as<unsigned char>());
+        // the mask is taken on the weighted field (run_hadisst_aa.py:133,201)
+        rc = launch_col_has_nan(c, draw.p, host_dtype, p_full, n_total, p_full,
+                                col_weight ? dw.as<double>() : (const double *)nullptr, dflag.as<unsigned char>());
         if (rc == AA_OK) e = hipStreamSynchronize(c->stream);
     }
     std::vector<unsigned char> flags((size_t)p_full);
@@ -747,6 +762,7 @@ int aa_set_data_weighted(aa_ctx *h, const void *raw, int host_dtype, long n_tota
     if (rc == AA_OK && e == hipSuccess) {
         const long p = (long)idx.size();
         c->form = AA_FORM_DATA;
+        c->linear_kernel = false;
         c->n = n;
         c->p = p;
         c->n_pad = round_up(n, 128);
@@ -756,10 +772,7 @@ int aa_set_data_weighted(aa_ctx *h, const void *raw, int host_dtype, long n_tota
         c->X.release();
         rc = c->X.alloc((size_t)(c->n_pad + AA_SLACK_ROWS) * c->p_pad * esize(c));
         if (rc == AA_OK) rc = didx.alloc(idx.size() * sizeof(int));
-        if (rc == AA_OK && col_weight) rc = dw.alloc((size_t)p_full * sizeof(double));
         if (rc == AA_OK) e = hipMemcpy(didx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice);
-        if (rc == AA_OK && e == hipSuccess && col_weight)
-            e = hipMemcpy(dw.p, col_weight, (size_t)p_full * sizeof(double), hipMemcpyHostToDevice);
         if (rc == AA_OK && e == hipSuccess)
             rc = launch_gather_weight(c, draw.p, host_dtype, p_full, row0, n, didx.as<int>(), p,
                                       col_weight ? dw.as<double>() : (const double *)nullptr);
@@ -1416,8 +1429,12 @@ int aa_quad_simplex_spg_batch(int device, const double *A, const double *B, long
     // one scratch context per device for the stateless entry points, kept for the life of the
     // process: creating and destroying a context (two streams, events, allocations) per call
     // cost 8 ms -- more than the QPs of every unit-test-sized problem
+    // (ctypes releases the GIL: calls from several threads take turns on the scratch context; it
+    // is never destroyed -- HIP may already be gone when static destructors run)
     static aa_ctx *scratch[64] = {nullptr};
+    static std::mutex scratch_mu;
     AA_REQUIRE(device >= 0 && device < 64, AA_ERR_ARG, "device %d out of range", device);
+    std::lock_guard<std::mutex> hold(scratch_mu);
     if (!scratch[device]) AA_CHECK(aa_ctx_create(&scratch[device], device, AA_F64));
     aa_ctx *h = scratch[device];
     AA_CHECK_HIP(hipSetDevice(device));
@@ -1453,6 +1470,64 @@ int aa_quad_simplex_spg_batch(int device, const double *A, const double *B, long
     dZ.release();
     dI.release();
     return rc;
+}
+
+int aa_get_spg_scalars(aa_ctx *h, double *out)
+{
+    AA_REQUIRE(h && out, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->scalars.p, AA_ERR_STATE, "no solver state");
+    static_assert(AA_SPG_SCALARS == SC_FMEM0, "include/aa_hip.h documents the ScalarSlot layout");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    AA_CHECK_HIP(hipMemcpy(out, c->scalars.p, AA_SPG_SCALARS * sizeof(double), hipMemcpyDeviceToHost));
+    return AA_OK;
+}
+
+// ------------------------------------------------------------------ the two passes, on their own
+static int invalidate_solver_state(Ctx *c)
+{
+    c->have_state = false;
+    c->grams_valid = false;
+    c->products_valid = false;
+    c->ckz_valid = false;
+    c->gpnh_valid = false;
+    c->x_feasible = false;
+    c->qp_iters_valid = false;
+    return AA_OK;
+}
+
+int aa_pass_reduce_rows(aa_ctx *h, int k, const double *A, double *out, long ldo)
+{
+    AA_REQUIRE(h && A && out, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_CHECK(ensure_problem(c, k));
+    AA_REQUIRE(ldo >= (c->form == AA_FORM_KERNEL ? c->n : c->p), AA_ERR_ARG, "ldo too small");
+    AA_CHECK(invalidate_solver_state(c));
+    AA_CHECK(upload_tall(c, c->Dt, A, k, 1, c->n, k));
+    AA_CHECK(launch_reduce_rows(c, c->Dt.as<double>(), c->Q.as<double>(), nullptr));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    AA_CHECK_HIP(hipMemcpy2D(out, (size_t)ldo * sizeof(double), c->Q.p, (size_t)c->p_pad * sizeof(double),
+                             (size_t)c->p * sizeof(double), (size_t)k, hipMemcpyDeviceToHost));
+    return AA_OK;
+}
+
+int aa_pass_row_local(aa_ctx *h, int k, const double *B, long ldb, double *out)
+{
+    AA_REQUIRE(h && B && out, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_CHECK(ensure_problem(c, k));
+    AA_REQUIRE(ldb >= c->p, AA_ERR_ARG, "ldb < p");
+    AA_CHECK(invalidate_solver_state(c));
+    std::vector<double> tmp((size_t)c->KP * c->p_pad, 0.0);
+    for (int i = 0; i < k; ++i)
+        for (long q = 0; q < c->p; ++q) tmp[(size_t)i * c->p_pad + q] = B[(size_t)i * ldb + q];
+    AA_CHECK_HIP(hipMemcpy(c->P.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    AA_CHECK(launch_wide_to_T(c, c->P.as<double>(), operandT(c, c->P, c->Pw)));
+    AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gn.as<double>()));
+    return download_tall(c, c->Gn, out, k, 1, c->n, k);
 }
 
 // ------------------------------------------------------------------ measurement

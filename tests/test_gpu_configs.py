@@ -461,17 +461,25 @@ def test_restarts_keep_the_data_resident(cdr, orc, c2_problem):
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
     assert best_c.cost == best_p.cost and best_c.archetypes.shape == (k, X.shape[1])
     assert len(set(c[0] for c in cached)) == n_init           # different starts, different fits
-    # in-place edits of a sampled row are noticed (new upload), release frees the copy
+    # an in-place edit of ANY entry is noticed (the whole buffer is checksummed: new upload), and
+    # the result is the one a fresh upload of the edited matrix gives; release frees the copy
     X2 = X.copy()
     m = cdr.ArchetypalAnalysis(k, random_state=0, **kw)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m.fit_transform(X2)
         c1 = m.cost
-        X2[0, :] += 1.0
+        X2[X2.shape[0] // 2 + 1, 7] += 50.0           # one entry, not in any sampled row
         m2 = cdr.ArchetypalAnalysis(k, random_state=0, **kw)
         m2.fit_transform(X2)
-    assert m2.cost != c1 and _backend._resident["ctx"].reused == 0
+        assert m2.cost != c1 and _backend._resident["ctx"].reused == 0
+        os.environ["CONVEX_DIM_RED_CACHE"] = "0"
+        try:
+            m3 = cdr.ArchetypalAnalysis(k, random_state=0, **kw)
+            m3.fit_transform(X2.copy())
+        finally:
+            os.environ.pop("CONVEX_DIM_RED_CACHE", None)
+        assert m3.cost == m2.cost
     cdr.release_device_cache()
     assert _backend._resident["ctx"] is None
     print("restarts: %d fits %.2f s resident vs %.2f s with per-fit upload" % (n_init, t_cached, t_plain))
