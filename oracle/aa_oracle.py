@@ -850,3 +850,19 @@ def gpnh_convex_coding(X, k, lambda_W=0, init=None, tolerance=1e-6, max_iteratio
         X, Z.copy(), W.copy(), lambda_W=lambda_W, tolerance=tolerance,
         max_iterations=max_iterations, **kwargs)
     return dict(weights=Z, dictionary=W, cost=cost, n_iter=n_iter, cost_deltas=deltas)
+
+
+def gpnh_transform(W, X_new, lambda_W=0, tolerance=1e-6, max_iterations=1000, random_state=None,
+                   **kwargs):
+    """GPNHConvexCoding.transform (gpnh_convex_coding.py:623-652): fresh random weights from the
+    estimator's generator (:531-537), then the loop of :282-402 with the dictionary held fixed.
+    Returns (weights, cost)."""
+    rng = _rng(random_state)
+    X_new = np.asarray(X_new, dtype=np.float64)
+    k = W.shape[1]
+    Z0 = right_stochastic_matrix((X_new.shape[0], k), random_state=rng)
+    Z, _, cost, _, _, _ = iterate_gpnh(X_new, Z0, np.array(W, dtype=np.float64), lambda_W=lambda_W,
+                                       update_dictionary=False, update_weights=True,
+                                       tolerance=tolerance, max_iterations=max_iterations, **kwargs)
+    return Z, cost
+

@@ -302,7 +302,35 @@ def main():
                 arrays["out_cost_" + key] = np.array([m.cost, m.n_iter], dtype=np.float64)
                 arrays["out_W_" + key] = np.ascontiguousarray(m.dictionary)
                 arrays["out_Z_" + key] = Wt
+                arrays["out_deltas_" + key] = np.asarray(m.cost_deltas)
         save("gpnh_estimator", "GPNHConvexCoding.fit_transform gpnh_convex_coding.py:501-606", **arrays)
+
+    if not only or 'gpnh_transform' in only:
+        # GPNHConvexCoding.transform (gpnh_convex_coding.py:623-652): weights of new samples for the
+        # fitted dictionary -- fresh random weights from the estimator's generator (its state
+        # after the fit), then the weights-only loop to the stopping rule
+        arrays = {}
+        rng = RandomState(0)
+        W0 = rng.standard_normal((30, 5))
+        Zt = ref.right_stochastic_matrix((300, 5), random_state=rng)
+        X = Zt.dot(W0.T) + 0.1 * rng.randn(300, 30)
+        Xn = Zt[:40][::-1].dot(W0.T) + 0.1 * rng.randn(40, 30)
+        arrays.update(in_X=X, in_Xnew=Xn)
+        for lam in (0.0, 1.0):
+            for wtag, wkw in (("one", dict(max_iterations=1)), ("full", dict())):
+                m = ref.GPNHConvexCoding(5, lambda_W=lam, init="random", tolerance=1e-6,
+                                         max_iterations=400, stopping_criterion="rel_delta_f",
+                                         random_state=0, weights_solver_kwargs=wkw)
+                m.fit_transform(X)
+                Wn, cn = m.transform(Xn)
+                key = "lam%d_%s" % (int(lam), wtag)
+                arrays["out_fit_" + key] = np.array([m.cost, m.n_iter], dtype=np.float64)
+                arrays["out_dictionary_" + key] = np.ascontiguousarray(m.dictionary)   # the transform's input
+                arrays["out_W_" + key] = Wn
+                arrays["out_cost_" + key] = np.array([cn, m.n_iter], dtype=np.float64)
+                arrays["out_inverse_" + key] = m.inverse_transform(Wn)
+        save("gpnh_transform", "GPNHConvexCoding.transform / inverse_transform "
+             "gpnh_convex_coding.py:623-668 after fit_transform", **arrays)
 
 
 if __name__ == "__main__":

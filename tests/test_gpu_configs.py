@@ -58,6 +58,14 @@ def ulp_perturbed(X, seed=5):
     return X * (1.0 + 2e-16 * np.random.RandomState(seed).standard_normal(X.shape))
 
 
+def f32_perturbed(X, seed=6):
+    """X with every entry moved by about one float32 rounding (6e-8 relative): what storing the
+    data in float32 and running the two big contractions on the fp32 matrix cores does to the
+    inputs of an otherwise exact run.  The float32 legs are held to 20 x the oracle's own
+    response to this perturbation -- the same rule as `ulp_perturbed` for the float64 legs."""
+    return X * (1.0 + 6e-8 * np.random.RandomState(seed).standard_normal(X.shape))
+
+
 # ------------------------------------------------------------------ C2: HadISST-shaped AA
 @pytest.fixture(scope="module")
 def c2_problem(orc):
@@ -117,11 +125,13 @@ def test_c2_hadisst_shape_fixed_iterations(cdr, orc, c2_problem, dtype):
         assert np.array_equal(C > 1e-15, wC > 1e-15)
     # five iterations: the oracle's own 1-ulp sensitivity is the yardstick
     wZ, wC, _, wcost, _, _, wdeltas = oracle(Xd, 5)
-    self_diff = abs(oracle(ulp_perturbed(Xd), 5)[3] - wcost)
+    twin = ulp_perturbed(Xd) if dtype == "float64" else f32_perturbed(Xd)
+    self_diff = abs(oracle(twin, 5)[3] - wcost)
     Z, C, _, cost, n_iter, _, deltas = hip(5)
     assert n_iter == 4 and len(deltas) == 5
-    floor = 1e-9 if dtype == "float64" else 2e-3
-    assert abs(cost - wcost) < max(floor * wcost, 20 * self_diff), (cost, wcost, self_diff)
+    print("C2 %s, 5 iterations: |cost - oracle| / cost = %.2e, oracle twin %.2e"
+          % (dtype, abs(cost - wcost) / wcost, self_diff / wcost))
+    assert abs(cost - wcost) < max(1e-9 * wcost, 20 * self_diff), (cost, wcost, self_diff)
     assert np.array_equal(C.argmax(axis=1), wC.argmax(axis=1))
     _assert_simplex(C)
     _assert_simplex(Z)
@@ -210,11 +220,27 @@ def test_c3_jra55_shape_fixed_iterations(cdr, orc, c3_problem, lam, dtype, rtol)
         # in another
         assert np.array_equal(Z > 1e-15, wZ > 1e-15)
     else:
-        # float32 data: single weights may land on another face of the simplex after eight
-        # one-pass updates (max |dZ| ~ 0.1 on a handful of samples); the factors are compared
-        # in the mean, the cost (above) is the tight check
-        assert np.abs(W - wW).max() < 2e-2 * scale
-        assert np.abs(Z - wZ).mean() < 5e-3
+        # float32 data.  One-pass weight updates amplify a difference ~5-8x per outer iteration on
+        # this problem, in ANY arithmetic (the float64 path against the oracle: max|dZ| 6e-13 after
+        # one iteration, 6e-10 after eight), and single weights then land on another face of the
+        # simplex.  So the float32 factors after eight iterations are held to the float32 error of
+        # ONE iteration (fp32 rounding of the X W' entries, ~1e-7, seen through one projected step)
+        # times the growth the float64 path itself shows over the same seven iterations, x 20.
+        def run(dt, iters):
+            kk = dict(kw, max_iterations=iters)
+            o = orc.iterate_gpnh(Xd, Zi.copy(), Wi.copy(), **kk)
+            h = gp._iterate_gpnh_convex_coding(Xh if dt == "float32" else Xd, Zi.copy(), Wi.copy(), dtype=dt, **kk)
+            return np.abs(h[0] - o[0]).max(), np.abs(h[1] - o[1]).max()
+        z32_1, w32_1 = run("float32", 1)
+        z64_1, w64_1 = run("float64", 1)
+        z64_8, w64_8 = run("float64", 8)
+        gz, gw = max(z64_8 / z64_1, 1.0), max(w64_8 / w64_1, 1.0)
+        print("C3 float32 lam=%g: one iteration max|dZ| %.2e max|dW| %.2e; float64 growth over 7 more: %.0fx / %.0fx; "
+              "eight iterations max|dZ| %.2e max|dW| %.2e"
+              % (lam, z32_1, w32_1, gz, gw, np.abs(Z - wZ).max(), np.abs(W - wW).max()))
+        assert z32_1 < 1e-3 and w32_1 < 1e-5 * scale          # one iteration: fp32 rounding through one step
+        assert np.abs(Z - wZ).max() <= min(20 * gz * z32_1, 1.0)
+        assert np.abs(W - wW).max() <= 20 * gw * w32_1
 
 
 @pytest.mark.parametrize("lam", [0.0, 1.0])

@@ -317,15 +317,51 @@ def test_gpnh_golden(cdr, qp_kernel):
                 X, Z0.copy(), W0.copy(), lambda_W=lam, tolerance=1e-6, max_iterations=200,
                 stopping_criterion="rel_delta_f", weights_solver_kwargs=wkw)
             want_cost, want_it = g["out_cost_%s_%s" % (tag, wtag)]
-            # ('lam1', 'one') stops at the iteration cap, not at a fixed point
-            assert abs(cost - want_cost) < 5e-5 * want_cost, (tag, wtag)
-            assert abs(n_iter - int(want_it)) <= max(3, int(0.1 * want_it)), (tag, wtag)
+            want_deltas = g["out_deltas_%s_%s" % (tag, wtag)]
+            # fixed-iteration part: the cost change of each of the first ten outer iterations at
+            # rounding level (cost ~ 1, changes down to 1e-4)
+            m = min(10, len(deltas), len(want_deltas))
+            assert np.abs(np.asarray(deltas[:m]) - want_deltas[:m]).max() < 1e-10, (tag, wtag)
+            # run to the stopping rule |delta cost| / cost < 1e-6.  Yardstick from the reference's
+            # own trace: near the end its relative cost change hovers within a factor 1.5 of the
+            # threshold for `window` iterations (with one SPG pass per outer iteration it is not
+            # even monotone there: 1.24, 1.20, 1.35, 1.19, 1.03, 0.98 e-6), so a run whose changes
+            # differ in the 8th digit may fire anywhere in that window, before or after, and its
+            # end cost then differs by the changes in between, each < 1.5e-6 of the cost.  With the
+            # full QP the trace is smooth and the stop is the reference's (asserted exactly).
+            window = _stop_window(want_deltas, want_cost)
+            shift = abs(n_iter - int(want_it))
+            print("gpnh golden %s %s: n_iter %d (reference %d, window %d), cost rel diff %.2e"
+                  % (tag, wtag, n_iter, int(want_it), window, abs(cost - want_cost) / want_cost))
+            if wtag == "full":
+                assert shift == 0, (tag, wtag)
+                assert abs(cost - want_cost) < 1e-10 * want_cost, (tag, wtag)
+            else:
+                assert shift <= 2 * window, (tag, wtag, window)
+                assert abs(cost - want_cost) <= (shift + 1) * 1.5e-6 * want_cost, (tag, wtag)
             _assert_simplex(Z, 1e-12)
     assert np.abs(gp._update_gpnh_weights(X, Z0, W0) - g["out_Zupd"]).max() < 1e-6
 
 
-@pytest.mark.parametrize("dtype,tol", [("float64", 5e-5), ("float32", 1e-4)])
-def test_gpnh_estimator_known_answers(cdr, dtype, tol):
+def _stop_window(ref_deltas, ref_cost, threshold=1e-6, factor=1.5):
+    """Trailing iterations of the reference's own trace whose relative cost change stays within
+    `factor` of the stopping threshold: a run whose changes differ from the reference's in the 8th
+    digit may fire the |delta cost| / cost < threshold rule anywhere in a window of that length
+    before or after the reference's stop (with one SPG pass per outer iteration the changes are
+    not even monotone there), and its end cost differs by the changes in between."""
+    rel_change = np.abs(np.asarray(ref_deltas)) / ref_cost
+    big = rel_change >= factor * threshold
+    return int(np.argmax(big[::-1])) if np.any(big) else len(rel_change)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_gpnh_estimator_known_answers(cdr, dtype):
+    """GPNHConvexCoding.fit_transform to the stopping rule (production setting: one SPG pass per
+    weights update, rel_delta_f at 1e-6) against the reference's runs.  float64: the first ten
+    cost changes at rounding level, the stopping iteration inside the reference's own window
+    (`_stop_window`), the end cost within the changes of the iterations in between.  float32
+    data rounds X itself (6e-8 relative): the cost level moves by ~1e-6 relative, the yardstick
+    for the stop is the same window."""
     g = load_golden("gpnh_estimator")
     X = g["in_X"]
     for lam in (0.0, 1.0):
@@ -337,8 +373,51 @@ def test_gpnh_estimator_known_answers(cdr, dtype, tol):
                                      weights_solver_kwargs=dict(max_iterations=1))
             Z = m.fit_transform(X)
             want_cost, want_it = g["out_cost_" + key]
-            assert abs(m.cost - want_cost) < tol * want_cost, key
+            want_deltas = g["out_deltas_" + key]
+            window = _stop_window(want_deltas, want_cost)
+            shift = abs(m.n_iter - int(want_it))
+            print("gpnh estimator %s %s: n_iter %d (reference %d, window %d), cost rel diff %.2e"
+                  % (dtype, key, m.n_iter, int(want_it), window, abs(m.cost - want_cost) / want_cost))
+            early = np.abs(np.asarray(m.cost_deltas[:10]) - want_deltas[:10]).max()
+            assert early < (1e-10 if dtype == "float64" else 2e-5), key
+            assert shift <= 2 * window, (key, window)
+            assert abs(m.cost - want_cost) <= ((shift + 1) * 1.5e-6 + (0 if dtype == "float64" else 5e-6)) * want_cost, key
             assert m.dictionary.shape == (30, 5) and Z.shape == (300, 5)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_gpnh_transform_golden(cdr, dtype):
+    """GPNHConvexCoding.transform / inverse_transform (gpnh_convex_coding.py:623-668) against the
+    reference's outputs: the reference's fitted dictionary, the generator in its state after that
+    fit (randn(p, k) and uniform(n, k) drawn), fresh random weights, weights-only loop to the
+    stopping rule on the device.  Tolerances: the run ends by |delta cost| / cost < 1e-6, and an end
+    one iteration earlier or later moves the cost by about that much: cost within 5e-6 relative;
+    the weights within 1e-5 with the full QP, within 5e-3 with one SPG pass per outer iteration,
+    where single samples still move by ~1e-3 per iteration when the rule fires (the oracle's own
+    fast QP variant differs from the reference by as much: tests/test_oracle_golden.py)."""
+    g = load_golden("gpnh_transform")
+    X, Xn = g["in_X"], g["in_Xnew"]
+    for lam in (0.0, 1.0):
+        for wtag, wkw in (("one", dict(max_iterations=1)), ("full", {})):
+            key = "lam%d_%s" % (int(lam), wtag)
+            rs = np.random.RandomState(0)
+            rs.randn(X.shape[1], 5)
+            rs.uniform(size=(X.shape[0], 5))
+            m = cdr.GPNHConvexCoding(5, lambda_W=lam, init="random", tolerance=1e-6, max_iterations=400,
+                                     stopping_criterion="rel_delta_f", random_state=rs, dtype=dtype,
+                                     weights_solver_kwargs=wkw)
+            m.dictionary = g["out_dictionary_" + key].copy()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                Wn, cn = m.transform(Xn)
+            want = g["out_cost_" + key][0]
+            if dtype == "float32" and wtag == "one":
+                continue        # float32 data moves the stopping iteration on the flat trace (see above)
+            assert abs(cn - want) < (5e-6 if dtype == "float64" else 2e-5) * want, key
+            wtol = 5e-3 if wtag == "one" else (1e-5 if dtype == "float64" else 1e-3)
+            assert np.abs(Wn - g["out_W_" + key]).max() < wtol, key
+            _assert_simplex(Wn, 1e-12)
+            assert np.abs(m.inverse_transform(Wn) - g["out_inverse_" + key]).max() < 4 * wtol
 
 
 # ---------------------------------------------------------------- bigger problems vs oracle

@@ -1,0 +1,34 @@
+import os, sys, warnings
+import numpy as np
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_R, "matrix-factorization-case-studies_amd")); sys.path.insert(0, _R)
+from convex_dim_red import _backend
+from convex_dim_red import gpnh_convex_coding as gp
+from oracle import aa_oracle as orc
+warnings.simplefilter("ignore")
+n, p, k = 22280, 167, 10
+rng = np.random.RandomState(0)
+W0 = rng.standard_normal((p, k))
+Zt = orc.right_stochastic_matrix((n, k), rng)
+X = Zt.dot(W0.T) + 0.1 * rng.standard_normal((n, p))
+rs = np.random.RandomState(1)
+Wi = np.sqrt(np.abs(X).mean() / k) * rs.randn(p, k)
+Zi = orc.right_stochastic_matrix((n, k), rs)
+X32 = X.astype(np.float32); Xd = X32.astype(np.float64)
+with _backend.Context(dtype="float32") as ctx:
+    ctx.set_data(X32)
+    got = ctx.pass_reduce_rows(Zi); want = Zi.T.dot(Xd)
+    print("reduce_rows f32: max|err| %.3e  max|value| %.3e  err/yardstick %.2e  err/|value|max %.2e" % (
+        np.abs(got-want).max(), np.abs(want).max(), (np.abs(got-want)/np.abs(Zi).T.dot(np.abs(Xd))).max(), np.abs(got-want).max()/np.abs(want).max()))
+    got = ctx.pass_row_local(Wi.T); want = Xd.dot(Wi)
+    print("row_local f32: max|err| %.3e max|value| %.3e err/yardstick %.2e" % (np.abs(got-want).max(), np.abs(want).max(), (np.abs(got-want)/np.abs(Xd).dot(np.abs(Wi))).max()))
+for lam in (1.0, 0.0):
+    for iters in (1, 2, 4, 8):
+        kw = dict(lambda_W=lam, tolerance=0, max_iterations=iters, stopping_criterion="rel_delta_f",
+                  weights_solver_kwargs=dict(max_iterations=1), require_monotonic_cost_decrease=False)
+        wZ, wW, wcost = orc.iterate_gpnh(Xd, Zi.copy(), Wi.copy(), **kw)[:3]
+        out = {}
+        for dt in ("float32", "float64"):
+            Z, W, cost = gp._iterate_gpnh_convex_coding(X32 if dt == "float32" else Xd, Zi.copy(), Wi.copy(), dtype=dt, **kw)[:3]
+            out[dt] = (np.abs(W - wW).max(), np.abs(Z - wZ).max(), abs(cost - wcost) / wcost)
+        print("lam %g iters %d: f32 dW %.2e dZ %.2e dcost %.2e | f64 dW %.2e dZ %.2e dcost %.2e" % ((lam, iters) + out["float32"] + out["float64"]))
