@@ -143,6 +143,13 @@ struct Ctx {
     hipStream_t stream2 = nullptr;             // side stream: the QP's straggler kernel
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     bool qp_tail_pending = false;              // stragglers run on stream2, results in tmpTall by slot
+    // the residual projection of the dictionary SPG (spg.py:250-276: convergence flags only) runs on
+    // the side stream beside the weights QP, on its own scratch set (launch_proj_side / join_side)
+    hipEvent_t evFork2 = nullptr, evJoin2 = nullptr;
+    bool side_pending = false;
+    DevBuf tmpTall2, redPartial2, redOut2, proj2, projList2, projSegCnt2;
+    int projPassHint2[4] = {0, 0, 0, 0};
+    bool projWarm2[4] = {false, false, false, false};
     // measurement (aa_gemm_timing): HIP event pairs around every launch of the two pass kernels
     bool time_gemm = false;
     std::vector<hipEvent_t> gemmEvents[2];     // [0] reduce-over-rows, [1] row-local: start, stop, ...
@@ -274,6 +281,10 @@ enum { ST_INIT_F = 0, ST_ALPHA = 1, ST_LINESEARCH = 2, ST_BB = 3, ST_CONV = 4 };
 int launch_row_sqnorm_sum(Ctx *c, double *trace_out_host);
 int launch_distance_column(Ctx *c, long j_local, int owner_has_row, const double *xj_host, double *d_host);
 int launch_row_broadcast(Ctx *c, long j_local, bool own);
+int launch_proj_side(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode,
+                     const aa_spg_params *sp, int stage_after);   // launch_proj on the side stream / scratch set
+int join_side(Ctx *c);             // the main stream waits for a pending side-stream projection
+extern int g_proj_res_side;
 int proj_poll_multirank(Ctx *c);   // multi-rank: read the deferred overflow flag / list lengths (host sync point)   // multi-rank: row j -> wideScratch on every rank
 int launch_residual_cost(Ctx *c, const double *Ztall, const double *Wwide, const double *alpha_dev,
                          double *out_host);
@@ -322,7 +333,7 @@ extern int g_qp_refill_min;       // kernels_qp.hip
 extern int g_qp_waves;            // kernels_qp.hip
 extern int g_qp_sort;             // kernels_qp.hip
 extern int g_qp_profile;          // kernels_qp.hip
-extern int g_qp_overlap_tail;     // kernels_qp.hip
+extern int g_qp_overlap_tail, g_qp_tail_cap;     // kernels_qp.hip
 
 // ------------------------------------------------------------------ comm.hip
 int comm_unique_id(void *id128);

@@ -892,8 +892,15 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
                                                  const int *__restrict__ ovf_rows,
                                                  const QpCarry *__restrict__ ovf,
                                                  double *__restrict__ zslot /*[slot][KQ] or null*/,
-                                                 const int *__restrict__ fresh_list = nullptr)
+                                                 const int *__restrict__ fresh_list = nullptr,
+                                                 const unsigned int *__restrict__ count_ptr = nullptr,
+                                                 int park_at = 1 << 30, unsigned int *__restrict__ n_parked = nullptr,
+                                                 int *__restrict__ park_rows = nullptr,
+                                                 QpCarry *__restrict__ park = nullptr)
 {
+    // park_at (continuation path): a sample still running after that many passes is written back
+    // and appended to a second overflow list (n_parked / park_rows / park) -- the handful of
+    // samples with hundreds of passes, which a later launch finishes beside the next pass over X
     constexpr bool HALF = KQ == 32;
     // latency-bound waves: take issue priority over the bandwidth-bound GEMM waves they may
     // share a SIMD with (the stragglers run concurrently with the Z'X pass)
@@ -916,7 +923,8 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
     // n_fresh >= 0: process rows [0, n_fresh) from scratch; otherwise the overflow list
     // fresh_list: the first hdr->n_long entries of the sorted sample list, from scratch
     const bool fresh = n_fresh >= 0 || fresh_list != nullptr;
-    const unsigned int count = fresh_list ? hdr->n_long : (fresh ? (unsigned int)n_fresh : hdr->n_overflow);
+    const unsigned int count = count_ptr ? *count_ptr
+                                         : (fresh_list ? hdr->n_long : (fresh ? (unsigned int)n_fresh : hdr->n_overflow));
 
     const unsigned int wave_id =
         (unsigned int)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -953,6 +961,7 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             n_feval = cr.n_feval;
         }
 
+        bool parked = false;
         // `guard_w` bounds the loop even if the arithmetic goes non-finite
         for (int guard_w = 0; guard_w < p.max_iterations + 2; ++guard_w) {
             if (n_iter == 0) {
@@ -1011,10 +1020,27 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             n_iter += 1;
             const bool conv = (sqrt(r2) < p.epsilon_two) || rinf_small;
             if (conv || n_feval > p.max_feval || n_iter >= p.max_iterations) break;
+            if (n_iter >= park_at) {
+                parked = true;
+                break;
+            }
         }
         if (live && lane == comp) {
             if (zslot) zslot[(size_t)slot * KQ + comp] = x;     // deferred commit (launch_qp_tail_fixup)
             else Z[row * ldz + comp] = x;
+        }
+        if (parked) {
+            if (lane == 0) {
+                const unsigned int s2 = atomicAdd(n_parked, 1u);
+                park_rows[s2] = (int)row;
+                QpCarry cr;
+                cr.alpha = alpha;
+                cr.f = f;
+                cr.n_iter = n_iter;
+                cr.n_feval = n_feval;
+                park[s2] = cr;
+            }
+            continue;
         }
         if (lane == 0 && iters) iters[row] = n_iter;
         wv_total += (unsigned long long)n_iter;
@@ -1925,6 +1951,7 @@ int g_qp_quad_cap = 0;         // passes after which k_qp_quad parks a sample fo
 int g_qp_wave_blocks = 1024;   // blocks (4 waves each) of the wave-per-sample kernel when it finishes parked samples
 int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
+int g_qp_tail_cap = 96;        // with qp_overlap_tail: only samples beyond this many passes go to the side stream (0: all parked ones)
 int g_qp_profile = 0;          // cycle accounting of k_qp (printed when stats are requested)
 int g_qp_sort = 1;             // order the samples by the previous update's pass counts
 int g_qp_waves = 1024;         // most waves the lane-per-sample kernel is launched with
@@ -2078,7 +2105,9 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     const size_t off_bs = off_A2 + (size_t)KW * KW * sizeof(double);
     const size_t off_rows = off_bs + 64 * sizeof(double);
     const size_t off_ovf = off_rows + round_up((long)n * sizeof(int), 16);
-    const size_t bytes = off_ovf + (size_t)n * sizeof(QpCarry);
+    const size_t off_rows2 = off_ovf + (size_t)n * sizeof(QpCarry);          // second overflow list (qp_tail_cap)
+    const size_t off_ovf2 = off_rows2 + round_up((long)n * sizeof(int), 16);
+    const size_t bytes = off_ovf2 + (size_t)n * sizeof(QpCarry);
     AA_CHECK(c->qpStats.alloc(bytes));
     // samples in the order of their pass counts in the previous update of this context (iters_dev
     // still holds them; the kernels below overwrite them); pointless when everybody gets the same
@@ -2120,6 +2149,8 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     const double *bsd = (bscale_host || !A_host) ? reinterpret_cast<const double *>(base + off_bs) : nullptr;
     int *ovf_rows = reinterpret_cast<int *>(base + off_rows);
     QpCarry *ovf = reinterpret_cast<QpCarry *>(base + off_ovf);
+    int *ovf2_rows = reinterpret_cast<int *>(base + off_rows2);
+    QpCarry *ovf2 = reinterpret_cast<QpCarry *>(base + off_ovf2);
 
     if (p->max_iterations <= 0) {
         dim3 grid((unsigned)((n + 255) / 256));
@@ -2192,10 +2223,52 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         else         { if (p->memory <= 1) QQL(2, true); else QQL(2, false); }
 #undef QQL
 #undef QQK
-        if (cap < p->max_iterations)
-            hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, c->stream, A2d, Btall, stride_j,
-                               stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
-                               (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr);
+        if (cap < p->max_iterations) {
+            // the parked samples, one wave each.  defer_tail: on the side stream, results to
+            // tmpTall by slot; the caller's Z'X pass runs beside them on the weights as k_qp_quad
+            // left them and launch_qp_tail_fixup adds the rank-m correction afterwards -- the
+            // dependent chain of the longest sample (100-450 passes at ~0.9 us) hides behind an
+            // HBM-bound pass instead of idling the chip
+            const bool defer = defer_tail && !stats && c->stream2 && ldz == c->KP && KW == 32 &&
+                               c->dtype == AA_F32 && c->tmpTall.bytes >= (size_t)n * 32 * sizeof(double);
+            const int tail_cap = g_qp_tail_cap;
+            if (defer && tail_cap > cap && tail_cap < p->max_iterations) {
+                // two stages: everything up to tail_cap passes here, at full speed on the whole chip;
+                // the few samples beyond it on the side stream beside the caller's Z'X pass
+                hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, c->stream, A2d, Btall,
+                                   stride_j, stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
+                                   (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr,
+                                   (const int *)nullptr, (const unsigned int *)nullptr, tail_cap, &hdr->pad, ovf2_rows, ovf2);
+                AA_CHECK_HIP(hipEventRecord(c->evFork, c->stream));
+                AA_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->evFork, 0));
+                hipLaunchKernelGGL(k_qp_wave<32>, dim3(64), dim3(256), 0, c->stream2, A2d, Btall,
+                                   stride_j, stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
+                                   (const int *)ovf2_rows, (const QpCarry *)ovf2, c->tmpTall.as<double>(),
+                                   (const int *)nullptr, (const unsigned int *)&hdr->pad);
+                AA_CHECK_HIP(hipEventRecord(c->evJoin, c->stream2));
+                c->qp_tail_pending = true;
+                c->qp_tail_rows = ovf2_rows;
+                c->qp_tail_count = &hdr->pad;
+            } else {
+                hipStream_t s2 = c->stream;
+                double *zslot = nullptr;
+                if (defer) {
+                    AA_CHECK_HIP(hipEventRecord(c->evFork, c->stream));
+                    AA_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->evFork, 0));
+                    s2 = c->stream2;
+                    zslot = c->tmpTall.as<double>();
+                }
+                hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, s2, A2d, Btall, stride_j,
+                                   stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
+                                   (const int *)ovf_rows, (const QpCarry *)ovf, zslot);
+                if (defer) {
+                    AA_CHECK_HIP(hipEventRecord(c->evJoin, c->stream2));
+                    c->qp_tail_pending = true;
+                    c->qp_tail_rows = ovf_rows;
+                    c->qp_tail_count = &hdr->n_overflow;
+                }
+            }
+        }
     } else if (wave_only) {
         long blocks = (n + 3) / 4;
         if (blocks > 2048) blocks = 2048;
@@ -2309,12 +2382,12 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
 }
 
 // commit of the deferred stragglers: Z[row_s] = z_new[s]
-__global__ __launch_bounds__(256) void k_qp_commit_tail(const QpHeader *__restrict__ hdr,
+__global__ __launch_bounds__(256) void k_qp_commit_tail(const unsigned int *__restrict__ count_dev,
                                                         const int *__restrict__ rows,
                                                         const double *__restrict__ zslot,
                                                         double *__restrict__ Z, int KP, int k)
 {
-    const unsigned int count = hdr->n_overflow;
+    const unsigned int count = *count_dev;
     const int comp = threadIdx.x % KP;
     for (unsigned int s = blockIdx.x * (256 / KP) + threadIdx.x / KP; s < count; s += gridDim.x * (256 / KP))
         if (comp < k) Z[(size_t)rows[s] * KP + comp] = zslot[(size_t)s * KP + comp];
@@ -2325,9 +2398,8 @@ int launch_qp_tail_fixup(Ctx *c, double *Ztall)
     if (!c->qp_tail_pending) return AA_OK;
     c->qp_tail_pending = false;
     AA_CHECK_HIP(hipStreamWaitEvent(c->stream, c->evJoin, 0));
-    const QpHeader *hdr = reinterpret_cast<const QpHeader *>(c->qpStats.p);
     AA_CHECK(launch_reduce_rows_fixup(c, c->qp_tail_count, c->qp_tail_rows, c->tmpTall.as<double>(), Ztall));
-    hipLaunchKernelGGL(k_qp_commit_tail, dim3(64), dim3(256), 0, c->stream, hdr, c->qp_tail_rows,
+    hipLaunchKernelGGL(k_qp_commit_tail, dim3(64), dim3(256), 0, c->stream, c->qp_tail_count, c->qp_tail_rows,
                        (const double *)c->tmpTall.as<double>(), Ztall, c->KP, c->k);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;

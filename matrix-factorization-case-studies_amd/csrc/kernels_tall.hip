@@ -22,6 +22,8 @@
 // and stays selectable (aa_set_option("proj_mode", 1)).
 #include "aa_internal.h"
 
+#include <utility>
+
 namespace aa {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -1594,6 +1596,18 @@ int tall_setup(Ctx *c)
     }
     AA_CHECK(c->Mdev.alloc((size_t)c->KP * c->KP * sizeof(double)));
     AA_CHECK(c->alphaDev.alloc((size_t)c->KP * sizeof(double)));
+    if (g_proj_res_side && c->stream2 && c->world <= 1 && !c->force_comm) {
+        // scratch set of the side-stream projection (launch_proj_side)
+        AA_CHECK(c->redPartial2.alloc(need + 4096));
+        AA_CHECK(c->redOut2.alloc((size_t)8 * c->KP * sizeof(double)));
+        AA_CHECK(c->proj2.alloc(sizeof(ProjState)));
+        const long rpb = tall_rows_pb(c);
+        AA_CHECK(c->projList2.alloc((size_t)c->KP * c->tallBlocks * rpb * sizeof(double)));
+        AA_CHECK(c->projSegCnt2.alloc((size_t)c->KP * c->tallBlocks * (256 / c->KP) * sizeof(int)));
+        AA_CHECK(c->tmpTall2.alloc((size_t)(c->n_pad + AA_SLACK_ROWS) * c->KP * sizeof(double)));
+        if (!c->evFork2) AA_CHECK_HIP(hipEventCreateWithFlags(&c->evFork2, hipEventDisableTiming));
+        if (!c->evJoin2) AA_CHECK_HIP(hipEventCreateWithFlags(&c->evJoin2, hipEventDisableTiming));
+    }
     return AA_OK;
 }
 
@@ -1664,6 +1678,7 @@ int g_proj_mode = 0;        // 0: candidate lists, 1: iterative full passes
 int g_proj_check_always = 0; // multi-rank: 1 = check every list projection for overflow at once (host sync)
 int g_pq_blocks = 128;          // most blocks of k_gram_wide_pq (their partial Grams are summed by ONE block; 64 -> 128:
                                 // C2, p = 25 000, 0.553 -> 0.537 ms per iteration; 256: 0.548)
+int g_proj_res_side = 1;        // the SPG's residual projection (flags only) on the side stream, beside the weights QP
 int g_proj_small = 1;           // short columns: threshold search of a projection in one kernel (k_proj_small)
 int g_fuse_finalize = 1;    // 1: second reduction stages run in the last block of their producer (single rank)
 int g_proj_list_cap = 2048; // multi-rank: most candidates per rank and column in the list all-reduce
@@ -1803,6 +1818,49 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     }
     AA_CHECK_HIP(hipGetLastError());
     if (mode > 0) c->projWarm[mode] = true;
+    return AA_OK;
+}
+
+// The same projection on the side stream with the second scratch set: the members launch_proj
+// works on are swapped for the call (host code is single-threaded per context).  Used for the
+// residual projection at the end of a dictionary SPG iteration, whose only consumers are the
+// convergence flags: it then runs beside the weights QP (VALU-bound, 0.3 ms) instead of in front of it.
+int join_side(Ctx *c)
+{
+    if (!c->side_pending) return AA_OK;
+    c->side_pending = false;
+    AA_CHECK_HIP(hipStreamWaitEvent(c->stream, c->evJoin2, 0));
+    return AA_OK;
+}
+
+int launch_proj_side(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode,
+                     const aa_spg_params *sp, int stage_after)
+{
+    const bool ok = g_proj_res_side && c->stream2 && c->proj2.p && c->evFork2 && c->world <= 1 && !c->force_comm &&
+                    g_proj_mode == 0 && g_fuse_finalize;
+    if (!ok) return launch_proj(c, x, g, a_const, a_slot, mode, sp, stage_after);
+    AA_CHECK(join_side(c));
+    AA_CHECK_HIP(hipEventRecord(c->evFork2, c->stream));
+    AA_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->evFork2, 0));
+    auto swap_all = [&]() {
+        std::swap(c->stream, c->stream2);
+        std::swap(c->tmpTall, c->tmpTall2);
+        std::swap(c->redPartial, c->redPartial2);
+        std::swap(c->redOut, c->redOut2);
+        std::swap(c->proj, c->proj2);
+        std::swap(c->projList, c->projList2);
+        std::swap(c->projSegCnt, c->projSegCnt2);
+        for (int m = 0; m < 4; ++m) {
+            std::swap(c->projWarm[m], c->projWarm2[m]);
+            std::swap(c->projPassHint[m], c->projPassHint2[m]);
+        }
+    };
+    swap_all();
+    const int rc = launch_proj(c, x, g, a_const, a_slot, mode, sp, stage_after);
+    swap_all();
+    AA_CHECK(rc);
+    AA_CHECK_HIP(hipEventRecord(c->evJoin2, c->stream2));
+    c->side_pending = true;
     return AA_OK;
 }
 

@@ -276,6 +276,7 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
     const int k = c->k, KP = c->KP;
     const bool data = c->form == AA_FORM_DATA;
     if (cost_recorded) *cost_recorded = false;
+    AA_CHECK(join_side(c));
 
     double *x = c->Ct.as<double>();
     double *gram = c->gramOut.as<double>();
@@ -366,7 +367,11 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
             AA_CHECK(launch_grad(c, c->Gr.as<double>(), c->H.as<double>(), c->gn.as<double>(), gscale,
                                  c->Dt.as<double>(), SC_DGN, nullptr, sp, ST_BB));
         }
-        AA_CHECK(launch_proj(c, x, c->gn.as<double>(), 1.0, -1, PROJ_RES, sp, ST_CONV));   // spg.py:250-276
+        // spg.py:250-276; with one SPG iteration per update nobody waits for the flags: side stream
+        if (sp->max_iterations == 1 && !st && data)
+            AA_CHECK(launch_proj_side(c, x, c->gn.as<double>(), 1.0, -1, PROJ_RES, sp, ST_CONV));
+        else
+            AA_CHECK(launch_proj(c, x, c->gn.as<double>(), 1.0, -1, PROJ_RES, sp, ST_CONV));
         if (data) std::swap(c->Gr, c->Gn);
         std::swap(c->gk, c->gn);
         // the host needs the flags only to decide on a further iteration or to report
@@ -403,6 +408,7 @@ static int weights_update(Ctx *c, const aa_qp_params *qp, aa_qp_stats *stats)
                        c->k, qp, c->qpIters.as<int>(), stats, dev_CKCt(c), defer));
     c->qp_iters_valid = true;
     AA_CHECK(refresh_after_weights(c));
+    AA_CHECK(join_side(c));                      // the judge behind this update reads the SPG flags
     return AA_OK;
 }
 
@@ -469,11 +475,16 @@ int aa_set_option(const char *name, int value)
         g_fuse_finalize = value != 0;
     } else if (!strcmp(name, "qp_overlap_tail")) {
         g_qp_overlap_tail = value != 0;
+    } else if (!strcmp(name, "qp_tail_cap")) {
+        AA_REQUIRE(value >= 0, AA_ERR_ARG, "qp_tail_cap must be >= 0");
+        g_qp_tail_cap = value;
     } else if (!strcmp(name, "use_graph")) {
         g_use_graph = value != 0;
     } else if (!strcmp(name, "pq_blocks")) {
         AA_REQUIRE(value >= 1 && value <= 1024, AA_ERR_ARG, "pq_blocks must be in 1..1024");
         g_pq_blocks = value;
+    } else if (!strcmp(name, "proj_res_side")) {
+        g_proj_res_side = value != 0;      // takes effect at the next aa_set_state of a new problem size
     } else if (!strcmp(name, "proj_small")) {
         g_proj_small = value != 0;
     } else if (!strcmp(name, "qp_profile")) {
@@ -574,8 +585,10 @@ int aa_ctx_destroy(aa_ctx *h)
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->rlPartial, &c->redPartial,
                      &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->iterState, &c->snapC, &c->snapZ, &c->snapAlpha, &c->qpIters, &c->qpPerm,
-                     &c->qpStats};
+                     &c->qpStats, &c->tmpTall2, &c->redPartial2, &c->redOut2, &c->proj2, &c->projList2, &c->projSegCnt2};
     for (DevBuf *b : all) b->release();
+    if (c->evFork2) (void)hipEventDestroy(c->evFork2);
+    if (c->evJoin2) (void)hipEventDestroy(c->evJoin2);
     for (int w = 0; w < 2; ++w)
         for (hipEvent_t e : c->gemmEvents[w]) (void)hipEventDestroy(e);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
@@ -838,6 +851,7 @@ int aa_set_state(aa_ctx *h, int k, const double *C, long ldc, const double *Z, c
     AA_REQUIRE(h && C && Z, AA_ERR_ARG, "null argument");
     Ctx *c = &h->c;
     AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_CHECK(join_side(c));
     AA_CHECK(ensure_problem(c, k));
     AA_REQUIRE(ldc >= c->n, AA_ERR_ARG, "ldc < n");
     AA_CHECK(upload_tall(c, c->Ct, C, 1, ldc, c->n, k));     // Ct[r][i] = C[i][r]
@@ -852,8 +866,8 @@ int aa_set_state(aa_ctx *h, int k, const double *C, long ldc, const double *Z, c
     c->products_valid = false;
     c->ckz_valid = false;
     for (int m = 0; m < 4; ++m) {
-        c->projWarm[m] = false;
-        c->projPassHint[m] = 0;
+        c->projWarm[m] = c->projWarm2[m] = false;
+        c->projPassHint[m] = c->projPassHint2[m] = 0;
         c->projListShort[m] = false;
     }
     return AA_OK;
@@ -1477,6 +1491,7 @@ int aa_get_spg_scalars(aa_ctx *h, double *out)
     AA_REQUIRE(h && out, AA_ERR_ARG, "null argument");
     Ctx *c = &h->c;
     AA_REQUIRE(c->scalars.p, AA_ERR_STATE, "no solver state");
+    AA_CHECK(join_side(c));
     static_assert(AA_SPG_SCALARS == SC_FMEM0, "include/aa_hip.h documents the ScalarSlot layout");
     AA_CHECK_HIP(hipSetDevice(c->device));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));

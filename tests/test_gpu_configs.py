@@ -235,12 +235,13 @@ def test_c3_jra55_shape_fixed_iterations(cdr, orc, c3_problem, lam, dtype, rtol)
         z64_1, w64_1 = run("float64", 1)
         z64_8, w64_8 = run("float64", 8)
         gz, gw = max(z64_8 / z64_1, 1.0), max(w64_8 / w64_1, 1.0)
+        g = max(gz, gw)                                       # the factors feed each other
         print("C3 float32 lam=%g: one iteration max|dZ| %.2e max|dW| %.2e; float64 growth over 7 more: %.0fx / %.0fx; "
               "eight iterations max|dZ| %.2e max|dW| %.2e"
               % (lam, z32_1, w32_1, gz, gw, np.abs(Z - wZ).max(), np.abs(W - wW).max()))
         assert z32_1 < 1e-3 and w32_1 < 1e-5 * scale          # one iteration: fp32 rounding through one step
-        assert np.abs(Z - wZ).max() <= min(20 * gz * z32_1, 1.0)
-        assert np.abs(W - wW).max() <= 20 * gw * w32_1
+        assert np.abs(Z - wZ).max() <= min(20 * g * z32_1, 1.0)
+        assert np.abs(W - wW).max() <= 20 * g * w32_1
 
 
 @pytest.mark.parametrize("lam", [0.0, 1.0])

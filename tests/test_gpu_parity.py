@@ -968,12 +968,19 @@ def test_device_loop_reports_cost_increase(cdr, orc):
     Z0 = orc.right_stochastic_matrix((n, k), rng)
     kw = dict(tolerance=1e-9, max_iterations=80, dtype="float32",
               dictionary_solver_kwargs=dict(max_iterations=1))
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        with pytest.raises(RuntimeError, match="factorization cost increased after (dictionary|weights) update"):
-            aa._iterate_aa(X, Z0, C0, np.ones(k), **kw)
-        # require_monotonic_cost_decrease=False: the same run goes through to the iteration cap
-        out = aa._iterate_aa(X, Z0, C0, np.ones(k), require_monotonic_cost_decrease=False, **kw)
+    from convex_dim_red import _backend
+    # the provocation needs the plain fp32 accumulation chain (one rounding per column of a sum
+    # that grows to 5e6); with the 32-column pieces summed in float64 the noise is 100x smaller
+    _backend.set_option("row_local_acc64", 0)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with pytest.raises(RuntimeError, match="factorization cost increased after (dictionary|weights) update"):
+                aa._iterate_aa(X, Z0, C0, np.ones(k), **kw)
+            # require_monotonic_cost_decrease=False: the same run goes through to the iteration cap
+            out = aa._iterate_aa(X, Z0, C0, np.ones(k), require_monotonic_cost_decrease=False, **kw)
+    finally:
+        _backend.set_option("row_local_acc64", 1)
     assert out[4] == 79 and len(out[6]) == 80
 
 

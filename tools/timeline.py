@@ -1,0 +1,14 @@
+# scratch: timeline (start, duration, queue) of the kernels of ONE outer iteration from a rocprofv3 kernel trace
+# usage: timeline.py <dir> [iteration index]
+import csv, glob, sys
+d = sys.argv[1]; which = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+f = sorted(glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv"))[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+short = lambda n: n.split("(")[0].replace("void aa::", "").replace("aa::", "")[:40]
+marks = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith("k_dict_setup")]
+a, b = marks[which], marks[which + 1]
+t0 = int(rows[a]["Start_Timestamp"])
+for r in rows[a:b]:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    print("%9.1f us +%8.1f us  q%-3s %s" % ((s - t0) / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?"), short(r["Kernel_Name"])))
