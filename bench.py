@@ -67,24 +67,8 @@ def start_factors(n=N_SAMPLES, k=N_COMPONENTS):
 
 
 def exchange_unique_id(rank, world, backend):
-    # all ranks of one launch are children of the same torch.distributed.run agent, so its
-    # pid makes the rendezvous file unique to this launch (no stale file of an earlier one)
-    port = os.environ.get("MASTER_PORT", "0")
-    path = "/tmp/aa_bench_uid_%s_%d_%d" % (port, os.getppid(), world)
-    if rank == 0:
-        uid = backend.comm_unique_id()
-        tmp = path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as fh:
-            fh.write(uid)
-        os.replace(tmp, path)
-        return uid, path
-    deadline = time.time() + 300
-    while time.time() < deadline:
-        if os.path.exists(path) and os.path.getsize(path) == 128:
-            with open(path, "rb") as fh:
-                return fh.read(), path
-        time.sleep(0.05)
-    raise RuntimeError("rank %d: timed out waiting for the RCCL unique id" % rank)
+    """RCCL unique id of this launch's communicator (rank 0 publishes it through a file)."""
+    return backend.exchange_unique_id(rank, world, "bench")
 
 
 def cpu_baseline(k, p, spg_kw, n_sample, steps):
@@ -281,6 +265,20 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
 
+    # MFMA utilisation from the SQ counters (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE,
+    # tools/gpu_pmc_mfma.sh): busy cycles of the matrix pipes over SIMD-cycles of the dispatch; like
+    # the traffic counters it cannot be read from inside this process, so the committed
+    # measurement of this configuration is reported next to the flops/time figure
+    mfma_pmc = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "round3_pmc_mfma.json")) as fh:
+            pm = json.load(fh)["kernels"]
+        if (n, p, k, world, args.dtype) == (N_SAMPLES, N_FEATURES, N_COMPONENTS, 1, "float32"):
+            mfma_pmc = {name.split("<")[0]: round(v["mfma_busy_frac_of_simd_cycles"], 4)
+                        for name, v in pm.items() if "mfma_busy_frac_of_simd_cycles" in v}
+    except (OSError, ValueError, KeyError):
+        pass
+
     es = 4 if args.dtype == "float32" else 8
     n_loc = hi - lo
     bytes_pass = float(n_loc) * p * es                     # algorithmic bytes of one pass over X
@@ -313,7 +311,9 @@ def main():
                      "launches_timed": [n_reduce, n_local],
                      "ms_streaming_read_probe": ms_probe,
                      "bytes_per_launch": bytes_pass, "flops_per_launch": flops_pass,
-                     "mfma_frac_of_kernel": flops_pass / (ms_dom * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12)},
+                     "mfma_frac_of_kernel": flops_pass / (ms_dom * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12),
+                     "mfma_busy_frac_pmc": mfma_pmc,
+                     "mfma_busy_source": "profiles/round3_pmc_mfma.json (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), per kernel)"},
         "mfma_frac_outer_iteration": flops_alg / world / (elapsed / args.steps) / (MFMA_F32_PEAK_TFLOPS * 1e12),
         "cost": {"initial": cost0, "final_trace_form": trace_cost, "final_residual_form": recon,
                  "after_each_update_last": [float(costs[-2]), float(costs[-1])]},

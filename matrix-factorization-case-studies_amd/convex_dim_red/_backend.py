@@ -181,10 +181,30 @@ def _check(rc):
         raise RuntimeError("libaa_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
 
 
+def distributed_env():
+    """``(rank, local_rank, world)`` when this process is one rank of a one-process-per-GPU launch
+    (``python -m torch.distributed.run --nproc-per-node N driver.py`` or any launcher that exports
+    RANK / LOCAL_RANK / WORLD_SIZE) AND row sharding was asked for with
+    ``CONVEX_DIM_RED_DISTRIBUTED=1``; ``None`` otherwise.  In that mode every rank runs the same
+    driver (same data, same seeds): ``ArchetypalAnalysis`` / ``GPNHConvexCoding`` keep rows
+    ``[n r / N, n (r + 1) / N)`` of the data matrix on their GPU, RCCL all-reduces the small Gram
+    products (csrc/comm.hip), and every rank returns the full factors."""
+    if os.environ.get("CONVEX_DIM_RED_DISTRIBUTED", "0") != "1":
+        return None
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 and os.environ.get("AA_FORCE_RCCL", "0") != "1":
+        return None
+    rank = int(os.environ.get("RANK", "0"))
+    return rank, int(os.environ.get("LOCAL_RANK", str(rank))), world
+
+
 def device_index():
     env = os.environ.get("CONVEX_DIM_RED_DEVICE")
     if env is not None:
         return int(env)
+    dist = distributed_env()
+    if dist is not None:
+        return dist[1]
     return int(os.environ.get("LOCAL_RANK", "0")) if "CONVEX_DIM_RED_USE_LOCAL_RANK" in os.environ else 0
 
 
@@ -308,6 +328,11 @@ class Context(object):
         self.p = 0
         self.world = 1
         self.reused = 0            # fits served from the resident copy of the data (resident_context)
+        # row shard of a distributed fit (sharded_context): with `global_view` the factor methods
+        # below take and return arrays of the WHOLE problem and slice / gather this rank's rows
+        self.global_view = False
+        self.row_lo = 0
+        self.n_global = 0
 
     def close(self):
         if self.h:
@@ -351,6 +376,25 @@ class Context(object):
         _check(self.lib.aa_set_data(self.h, X.ctypes.data_as(_vp), host, n, p, p, form,
                                     n if n_global is None else n_global, row_offset))
         self.n, self.p = n, p
+        self.row_lo, self.n_global = int(row_offset), int(n if n_global is None else n_global)
+
+    def _rows(self, a):
+        """This rank's rows of a whole-problem array (global view only)."""
+        return a[self.row_lo:self.row_lo + self.n] if self.global_view else a
+
+    def _gather_rows(self, local):
+        """Whole-problem array from every rank's rows: zero-padded sum all-reduce (exact: every
+        entry is one value plus zeros)."""
+        if not self.global_view:
+            return local
+        local = np.asarray(local, dtype=np.float64)
+        full = np.zeros((self.n_global,) + local.shape[1:])
+        full[self.row_lo:self.row_lo + self.n] = local
+        flat = full.reshape(-1)
+        step = 1 << 24                                    # aa_ctx_allreduce_host counts with an int
+        for i in range(0, flat.size, step):
+            flat[i:i + step] = self.allreduce_host(flat[i:i + step])
+        return full
 
     def share_data(self, owner):
         """Use ``owner``'s resident data matrix without a copy (aa_share_data); ``owner`` must stay
@@ -397,6 +441,8 @@ class Context(object):
         return t.value
 
     def set_state(self, C, Z, alpha):
+        if self.global_view:
+            C, Z = np.asarray(C)[:, self.row_lo:self.row_lo + self.n], self._rows(np.asarray(Z))
         C, Z, alpha = _c64(C), _c64(Z), _c64(alpha)
         k = C.shape[0]
         _check(self.lib.aa_set_state(self.h, k, _ptr(C), C.shape[1], _ptr(Z), _ptr(alpha)))
@@ -407,6 +453,9 @@ class Context(object):
         Z = np.empty((self.n, self.k))
         alpha = np.empty(self.k)
         _check(self.lib.aa_get_state(self.h, _ptr(C), self.n, _ptr(Z), _ptr(alpha)))
+        if self.global_view:
+            C = np.ascontiguousarray(self._gather_rows(np.ascontiguousarray(C.T)).T)
+            Z = self._gather_rows(Z)
         return C, Z, alpha
 
     def set_alpha(self, alpha):
@@ -487,13 +536,13 @@ class Context(object):
     def distance_column(self, j):
         d = np.empty(self.n)
         _check(self.lib.aa_distance_column(self.h, int(j), _ptr(d)))
-        return d
+        return self._gather_rows(d)
 
     # -- GPNH
     def gpnh_set_factors(self, k, W=None, Z=None):
         """W is the reference's dictionary (p x k); it travels transposed (k x p)."""
         Wt = None if W is None else _c64(np.asarray(W).T)
-        Zc = None if Z is None else _c64(Z)
+        Zc = None if Z is None else _c64(self._rows(np.asarray(Z)))
         _check(self.lib.aa_gpnh_set_factors(self.h, k, None if Wt is None else _ptr(Wt), self.p,
                                             None if Zc is None else _ptr(Zc)))
         self.k = k
@@ -501,7 +550,7 @@ class Context(object):
     def gpnh_get_weights(self):
         Z = np.empty((self.n, self.k))
         _check(self.lib.aa_gpnh_get_weights(self.h, _ptr(Z)))
-        return Z
+        return self._gather_rows(Z)
 
     def gpnh_reduce(self, want_ztx=True, want_trace=True):
         k = self.k
@@ -700,3 +749,82 @@ def comm_unique_id():
     buf = ctypes.create_string_buffer(128)
     _check(load_library().aa_comm_get_unique_id(ctypes.cast(buf, _vp)))
     return buf.raw
+
+
+_uid_serial = [0]
+
+
+def exchange_unique_id(rank, world, tag="fit"):
+    """Rank 0 draws an RCCL unique id and publishes it through a file in the temporary directory;
+    the other ranks of the same launch (same MASTER_PORT, same parent: the launcher's agent) wait
+    for it.  Every communicator of a process gets its own file (`tag` + a per-process serial,
+    which all ranks advance in the same order).  Returns ``(id, path)``."""
+    import tempfile
+    import time
+    _uid_serial[0] += 1
+    path = os.path.join(tempfile.gettempdir(), "aa_uid_%s_%d_%d_%s_%d" % (
+        os.environ.get("MASTER_PORT", "0"), os.getppid(), world, tag, _uid_serial[0]))
+    if rank == 0:
+        uid = comm_unique_id()
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as fh:
+            fh.write(uid)
+        os.replace(tmp, path)
+        return uid, path
+    deadline = time.time() + 300
+    while time.time() < deadline:
+        if os.path.exists(path) and os.path.getsize(path) == 128:
+            with open(path, "rb") as fh:
+                return fh.read(), path
+        time.sleep(0.02)
+    raise RuntimeError("rank %d: timed out waiting for the RCCL unique id (%s)" % (rank, path))
+
+
+class _Sharded(object):
+    """Context manager of a distributed fit's context: closes it after a barrier (a rank must not
+    tear its communicator down while another is still inside a collective) and removes the
+    rendezvous file."""
+
+    def __init__(self, ctx, uid_path, rank):
+        self.ctx, self.uid_path, self.rank = ctx, uid_path, rank
+
+    def __enter__(self):
+        return self.ctx
+
+    def __exit__(self, *exc):
+        try:
+            if exc[0] is None:
+                self.ctx.allreduce_host([0.0])
+        finally:
+            self.ctx.close()
+            if self.rank == 0 and self.uid_path:
+                try:
+                    os.remove(self.uid_path)
+                except OSError:
+                    pass
+        return False
+
+
+def sharded_context(X, form=FORM_DATA, dtype=None):
+    """Context of a distributed fit (see `distributed_env`): this rank's rows of ``X`` on its GPU,
+    an RCCL communicator over all ranks, and the global view switched on -- the estimators then
+    use it exactly like a single-GPU context."""
+    rank, local_rank, world = distributed_env()
+    X = np.asarray(X)
+    if form != FORM_DATA or X.ndim != 2:
+        raise ValueError("a distributed fit needs a data matrix (n_samples x n_features)")
+    n = X.shape[0]
+    bounds = np.linspace(0, n, world + 1).astype(np.int64)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    if hi <= lo:
+        raise ValueError("fewer samples (%d) than ranks (%d)" % (n, world))
+    ctx = Context(dtype=dtype, device=local_rank)
+    try:
+        uid, path = exchange_unique_id(rank, world)
+        ctx.comm_init(uid, rank, world)
+        ctx.set_data(X[lo:hi], form=form, n_global=n, row_offset=lo)
+        ctx.global_view = True
+    except Exception:
+        ctx.close()
+        raise
+    return _Sharded(ctx, path, rank)

@@ -411,7 +411,11 @@ def _fit_on_data_matrix(self, data, linear_kernel, label, dictionary=None, weigh
 
     # the data matrix stays on the device between fits of the same array (the drivers' n_init
     # restarts, bin/run_hadisst_aa.py:158-172): only the start factors travel
+    # one process per GPU (torch.distributed.run) with CONVEX_DIM_RED_DISTRIBUTED=1: this rank keeps
+    # its row block of the data, RCCL all-reduces the Gram products, every rank gets the full factors
+    distributed = _backend.distributed_env() is not None and not on_device
     with (data.borrow() if on_device else
+          _backend.sharded_context(data, form=_backend.FORM_DATA, dtype=self.dtype) if distributed else
           _backend.resident_context(data, form=_backend.FORM_DATA, dtype=self.dtype)) as ctx:
 
         def init_dictionary():

@@ -359,7 +359,10 @@ class GPNHConvexCoding(object):
         k = self.n_components
         whom = '_gpnh_convex_coding'
         # data resident across the drivers' n_init restarts (bin/run_jra55_pca_gpnh.py:123-136)
-        with (data.borrow() if on_device else _backend.resident_context(data, dtype=self.dtype)) as ctx:
+        distributed = _backend.distributed_env() is not None and not on_device   # see _backend.distributed_env
+        with (data.borrow() if on_device else
+              _backend.sharded_context(data, dtype=self.dtype) if distributed else
+              _backend.resident_context(data, dtype=self.dtype)) as ctx:
             ctx.set_linear_kernel(False)             # a reused context may come from KernelAA(features=True)
             if on_device:
                 data = data.to_host() if self.init != 'custom' and update_dictionary else data

@@ -32,7 +32,8 @@
 
 namespace aa {
 
-#define QP_MAXMEM 8
+#define QP_MAXMEM 8        // f_mem entries the lane / quad kernels keep in registers (spg.py:310)
+#define QW_MAXMEM 32       // ... and the wave-per-sample kernel, which takes over for memory > 8
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // Threshold t of the projection of w = x - a*g (components >= k excluded).
@@ -919,7 +920,7 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
         if constexpr (HALF) return qw_matvec_bcast(Arow, v, lane);
         else return qw_matvec<KQ>(Arow, v);
     };
-    const int mem = p.memory < 1 ? 1 : (p.memory > QP_MAXMEM ? QP_MAXMEM : p.memory);
+    const int mem = p.memory < 1 ? 1 : (p.memory > QW_MAXMEM ? QW_MAXMEM : p.memory);
     // n_fresh >= 0: process rows [0, n_fresh) from scratch; otherwise the overflow list
     // fresh_list: the first hdr->n_long entries of the sorted sample list, from scratch
     const bool fresh = n_fresh >= 0 || fresh_list != nullptr;
@@ -936,11 +937,11 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
 
         double x = live ? Z[row * ldz + comp] : 0.0;
         const double b = live ? -B[comp * stride_j + row * stride_t] * (bscale ? bscale[comp] : 1.0) : 0.0;
-        double f, alpha = 1.0, fmem[QP_MAXMEM];
+        double f, alpha = 1.0, fmem[QW_MAXMEM];
         int n_iter, n_feval;
         unsigned long long support = 0ull, support_r = 0ull;   // latest direction / residual supports
 #pragma unroll
-        for (int i = 0; i < QP_MAXMEM; ++i) fmem[i] = NAN;
+        for (int i = 0; i < QW_MAXMEM; ++i) fmem[i] = NAN;
         if (fresh) {
             const double t0 = qw_threshold<HALF>(live ? x : -INFINITY, comp, support);
             x = live ? fmax(x - t0, 0.0) : 0.0;
@@ -984,11 +985,11 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             double f_max = f;
             if (mem > 1) {                         // memory == 1 (the default): f_max = f
 #pragma unroll
-                for (int i = QP_MAXMEM - 1; i > 0; --i)
+                for (int i = QW_MAXMEM - 1; i > 0; --i)
                     if (i < mem) fmem[i] = fmem[i - 1];
                 fmem[0] = f;
 #pragma unroll
-                for (int i = 1; i < QP_MAXMEM; ++i)
+                for (int i = 1; i < QW_MAXMEM; ++i)
                     if (i < mem && fmem[i] > f_max) f_max = fmem[i];
             }
 
@@ -2091,14 +2092,16 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     // one or two passes (GPNH's weights QP with max_iterations = 1): nothing diverges then and
     // the lane-per-sample kernel, 64 samples per wave, is cheaper (0.175 against 0.188 ms on the
     // C3 stand-in).  k > 32: one wave per sample.
-    const bool row_mode = KQ <= 32 && g_qp_mode == 3;
-    const bool quad_mode = KQ <= 32 && (g_qp_mode == 4 || (g_qp_mode == 0 && p->max_iterations > 4));
-    const bool wave_only = !row_mode && !quad_mode && (KQ > 32 || g_qp_mode == 1 || g_qp_mode == 3);   // else: lane + wave
+    // spg.py:310 allocates f_mem of any length; the kernels keep it in registers: 8 entries in the
+    // throughput kernels, 16 in the row kernel, 32 in the wave-per-sample kernel, which therefore
+    // takes the whole update when memory > 8 (a setting the reference's callers never use)
+    const bool big_mem = p->memory > QP_MAXMEM;
+    const bool row_mode = KQ <= 32 && g_qp_mode == 3 && p->memory <= QR_MAXMEM;
+    const bool quad_mode = !big_mem && KQ <= 32 && (g_qp_mode == 4 || (g_qp_mode == 0 && p->max_iterations > 4));
+    const bool wave_only = !row_mode && !quad_mode && (big_mem || KQ > 32 || g_qp_mode == 1 || g_qp_mode == 3);   // else: lane + wave
     const int KW = KQ > 32 ? 64 : 32;              // A padding of the wave and row kernels
-    // spg.py:310 allocates f_mem of any length; the kernels keep it in registers
-    AA_REQUIRE(p->memory <= (row_mode ? QR_MAXMEM : QP_MAXMEM), AA_ERR_ARG,
-               "QP: memory = %d exceeds the HIP backend limit of %d for k = %d", p->memory,
-               row_mode ? QR_MAXMEM : QP_MAXMEM, k);
+    AA_REQUIRE(p->memory <= QW_MAXMEM, AA_ERR_ARG,
+               "QP: memory = %d exceeds the HIP backend limit of %d", p->memory, QW_MAXMEM);
     // scratch layout: QpHeader | A[KQ*KQ] | A2[KW*KW] | bscale[64] | ovf_rows[n] | ovf[n]
     const size_t off_A = 192;             // QpHeader at 0, QpDebug at 64 (96 bytes)
     const size_t off_A2 = off_A + (size_t)KQ * KQ * sizeof(double);

@@ -1675,7 +1675,12 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
 static int g_proj_hard_cap = 200;
 
 int g_proj_mode = 0;        // 0: candidate lists, 1: iterative full passes
-int g_proj_check_always = 0; // multi-rank: 1 = check every list projection for overflow at once (host sync)
+int g_proj_check_always = 1; // multi-rank: 1 (default) = every list projection is checked for overflow at once (one host
+                             // synchronisation; an overflowing column falls back to the iterative passes in the same
+                             // projection), 0 = the check is deferred to the next poll while the lists of that kind of
+                             // projection have been short -- faster, but a list that outgrows its slot between two
+                             // polls (seen: the residual projection a few iterations after a FurthestSum start) then
+                             // ends the fit with an error instead of being handled
 int g_pq_blocks = 128;          // most blocks of k_gram_wide_pq (their partial Grams are summed by ONE block; 64 -> 128:
                                 // C2, p = 25 000, 0.553 -> 0.537 ms per iteration; 256: 0.548)
 int g_proj_res_side = 1;        // the SPG's residual projection (flags only) on the side stream, beside the weights QP

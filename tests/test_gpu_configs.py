@@ -512,6 +512,64 @@ def test_restarts_keep_the_data_resident(cdr, orc, c2_problem):
     print("restarts: %d fits %.2f s resident vs %.2f s with per-fit upload" % (n_init, t_cached, t_plain))
 
 
+# ------------------------------------------------------------------ distributed estimators
+def test_estimators_in_distributed_mode_single_rank(cdr, orc):
+    """CONVEX_DIM_RED_DISTRIBUTED=1 (one process per GPU, `_backend.distributed_env`): the
+    estimators build a row-sharded context with an RCCL communicator and a global view of the
+    factors.  Here with ONE rank and a forced communicator (AA_FORCE_RCCL=1), which runs every
+    collective of the multi-rank code path -- split-row GEMM results, gathered reductions,
+    candidate lists, FurthestSum row broadcast, the zero-padded gathers of the factors -- and must
+    reproduce the plain single-GPU fit.  tools/two_rank_check.py runs the same estimators on two
+    ranks (tests/test_gpu_configs.py::test_two_ranks_match_one_rank; needs two GPUs)."""
+    import os
+    rng = np.random.RandomState(5)
+    n, p, k = 700, 90, 4
+    B = rng.standard_normal((k, p))
+    Zt = orc.right_stochastic_matrix((n, k), rng) ** 3
+    Zt /= Zt.sum(axis=1, keepdims=True)
+    X = Zt.dot(B) + 0.02 * rng.standard_normal((n, p))
+
+    def fits():
+        out = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for init in ("furthest_sum", "random"):
+                # tolerance 0: a fixed number of iterations (a stopping rule would fire an iteration
+                # apart where the two paths sum in different orders)
+                m = cdr.ArchetypalAnalysis(k, init=init, random_state=0, tolerance=0, max_iterations=12,
+                                           dictionary_solver_kwargs=dict(max_iterations=1),
+                                           require_monotonic_cost_decrease=False)
+                W = m.fit_transform(X)
+                out.append((m.cost, m.n_iter, W, m.dictionary, m.archetypes))
+                g = cdr.GPNHConvexCoding(k, lambda_W=0.5, init=init, random_state=0, tolerance=0,
+                                         max_iterations=12, stopping_criterion="rel_delta_f",
+                                         require_monotonic_cost_decrease=False,
+                                         weights_solver_kwargs=dict(max_iterations=1))
+                Wg = g.fit_transform(X)
+                out.append((g.cost, g.n_iter, Wg, g.dictionary, g.transform(X[:50])[0]))
+        return out
+
+    from convex_dim_red import _backend
+    cdr.release_device_cache()
+    _backend.set_option("proj_small", 0)      # the multi-rank path projects by candidate lists: same sums
+    try:
+        plain = fits()
+    finally:
+        _backend.set_option("proj_small", 1)
+    os.environ["CONVEX_DIM_RED_DISTRIBUTED"] = "1"
+    os.environ["AA_FORCE_RCCL"] = "1"
+    try:
+        dist = fits()
+    finally:
+        os.environ.pop("CONVEX_DIM_RED_DISTRIBUTED", None)
+        os.environ.pop("AA_FORCE_RCCL", None)
+    for a, b in zip(plain, dist):
+        assert a[1] == b[1]
+        assert abs(a[0] - b[0]) < 1e-12 * abs(a[0])
+        for x, y in zip(a[2:], b[2:]):
+            assert x.shape == y.shape and np.abs(x - y).max() < 1e-10
+
+
 # ------------------------------------------------------------------ more than one GPU (C5)
 def test_two_ranks_match_one_rank(cdr):
     """libaa_hip itself on two GPUs: two processes (one per GPU, launched with
@@ -536,6 +594,7 @@ def test_two_ranks_match_one_rank(cdr):
     out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          timeout=420, universal_newlines=True)
     assert out.returncode == 0 and "MULTI_RANK_OK world=2" in out.stdout, out.stdout[-3000:]
+    assert "MULTI_RANK_ESTIMATORS_OK world=2" in out.stdout, out.stdout[-3000:]
 
 
 # ------------------------------------------------------------------ driver preprocessing

@@ -538,11 +538,12 @@ def test_qp_sizes_vs_oracle(cdr, orc, qp_kernel, k):
 
 
 @pytest.mark.parametrize("k,n", [(6, 5), (13, 17), (31, 333), (32, 64)])
-@pytest.mark.parametrize("memory", [3, 8])
+@pytest.mark.parametrize("memory", [3, 8, 12, 32])
 def test_qp_nonmonotone_memory_vs_oracle(cdr, orc, qp_kernel, k, n, memory):
     """spg.py:310,341-344: the reference value of the Armijo test is the maximum of the last
-    `memory` objective values.  Every mapping keeps that history in registers; fewer samples than
-    a wave has slots, padded component counts and a full 32 are all in here."""
+    `memory` objective values.  Every mapping keeps that history in registers (8 entries; beyond
+    that the wave-per-sample kernel, which holds 32, takes the update); fewer samples than a wave
+    has slots, padded component counts and a full 32 are all in here."""
     from convex_dim_red import _backend
     rng = np.random.RandomState(100 * k + memory)
     p = 2 * k + 3
@@ -571,7 +572,7 @@ def test_qp_memory_beyond_the_register_budget_is_an_error(cdr, qp_kernel):
     rng = np.random.RandomState(3)
     A = np.eye(4); B = rng.standard_normal((4, 10)); Z0 = np.full((10, 4), 0.25)
     with pytest.raises(RuntimeError, match="memory"):
-        _backend.qp_batch(A, B, Z0, "kn", memory=17)
+        _backend.qp_batch(A, B, Z0, "kn", memory=33)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

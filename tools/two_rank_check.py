@@ -45,7 +45,7 @@ def main():
         ctx = _backend.Context(dtype=dtype, device=local)
         uid_path = None
         if world > 1:
-            uid, uid_path = bench.exchange_unique_id(rank, world, _backend)
+            uid, uid_path = _backend.exchange_unique_id(rank, world, "check")
             ctx.comm_init(uid, rank, world)
         ctx.set_data(np.ascontiguousarray(Xd[lo:hi]), n_global=n, row_offset=lo)
         ctx.set_state(np.ascontiguousarray(C0[:, lo:hi]), Z0[lo:hi], np.ones(k))
@@ -108,5 +108,58 @@ def main():
     print("MULTI_RANK_OK world=%d" % world, flush=True)
 
 
+def estimators():
+    """The estimators themselves in distributed mode (CONVEX_DIM_RED_DISTRIBUTED=1): AA and GPNH,
+    FurthestSum and random initialisation, the device loops run to their stopping rules, on every
+    rank; rank 0 then repeats the fits on its own GPU alone and compares."""
+    import warnings
+    import convex_dim_red as cdr
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n, p, k = 5003, 240, 6
+    rng = np.random.RandomState(4)
+    B = rng.standard_normal((k, p))
+    Zt = rng.uniform(size=(n, k)) ** 4
+    Zt /= Zt.sum(axis=1, keepdims=True)
+    X = Zt.dot(B) + 0.05 * rng.standard_normal((n, p))
+
+    def fits():
+        out = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for init in ("furthest_sum", "random"):
+                m = cdr.ArchetypalAnalysis(k, init=init, random_state=0, tolerance=0, max_iterations=12,
+                                           dictionary_solver_kwargs=dict(max_iterations=1),
+                                           require_monotonic_cost_decrease=False)
+                W = m.fit_transform(X)
+                out.append(("AA " + init, m.cost, m.n_iter, W, m.dictionary))
+                g = cdr.GPNHConvexCoding(k, lambda_W=0.5, init=init, random_state=0, tolerance=0,
+                                         max_iterations=12, stopping_criterion="rel_delta_f",
+                                         require_monotonic_cost_decrease=False,
+                                         weights_solver_kwargs=dict(max_iterations=1))
+                Wg = g.fit_transform(X)
+                out.append(("GPNH " + init, g.cost, g.n_iter, Wg, g.dictionary))
+        return out
+
+    os.environ["CONVEX_DIM_RED_DISTRIBUTED"] = "1"
+    dist = fits()
+    os.environ["CONVEX_DIM_RED_DISTRIBUTED"] = "0"
+    if rank != 0:
+        return
+    os.environ["CONVEX_DIM_RED_DEVICE"] = os.environ.get("LOCAL_RANK", "0")
+    alone = fits()
+    for a, b in zip(alone, dist):
+        print("%-18s %d ranks vs 1: n_iter %d / %d, cost rel diff %.2e, weights %.2e, dictionary %.2e"
+              % (a[0], world, b[2], a[2], abs(a[1] - b[1]) / abs(a[1]), np.abs(a[3] - b[3]).max(),
+                 np.abs(a[4] - b[4]).max()), flush=True)
+        # twelve iterations: the partition only changes summation orders, and a last-bit difference
+        # grows about 2x per outer iteration
+        # (test_rccl_path_single_rank: 1e-6 after six iterations between two projection variants)
+        assert a[2] == b[2] and abs(a[1] - b[1]) < 1e-6 * abs(a[1])
+        assert np.abs(a[3] - b[3]).max() < 1e-4 and np.abs(a[4] - b[4]).max() < 1e-4
+    print("MULTI_RANK_ESTIMATORS_OK world=%d" % world, flush=True)
+
+
 if __name__ == "__main__":
     main()
+    estimators()
