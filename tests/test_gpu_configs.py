@@ -656,6 +656,56 @@ def test_driver_preprocessing_on_device(cdr, orc, dtype):
         assert g.cost == g2.cost and np.array_equal(Zg, Zh)
 
 
+def test_restart_loop_against_the_oracle(cdr, orc):
+    """The drivers' restart loops (bin/run_hadisst_aa.py:149-174, bin/run_jra55_pca_gpnh.py:112-138:
+    n_init fresh models, ONE shared RandomState, keep the lowest cost) through fit_restarts --
+    several fits at a time on one resident copy of the data -- against the ORACLE driven by the
+    same loop: every restart draws the start the oracle draws (same generator order), so restart
+    by restart the fixed-length fits agree at rounding level and the kept model is the same one."""
+    rng = np.random.RandomState(21)
+    n, p, k, n_init = 400, 60, 4, 6
+    B = rng.standard_normal((k, p))
+    Zt = orc.right_stochastic_matrix((n, k), rng) ** 3
+    Zt /= Zt.sum(axis=1, keepdims=True)
+    X = Zt.dot(B) + 0.05 * rng.standard_normal((n, p))
+    aa_kw = dict(init="random", tolerance=0, max_iterations=10, require_monotonic_cost_decrease=False,
+                 dictionary_solver_kwargs=dict(max_iterations=1))
+    gp_kw = dict(lambda_W=0.5, init="random", tolerance=0, max_iterations=10, stopping_criterion="rel_delta_f",
+                 require_monotonic_cost_decrease=False, weights_solver_kwargs=dict(max_iterations=1))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # archetypal analysis
+        shared = np.random.RandomState(0)
+        want = [orc.archetypal_analysis(X, k, random_state=shared, **aa_kw) for _ in range(n_init)]
+        shared = np.random.RandomState(0)
+        twin = [orc.archetypal_analysis(ulp_perturbed(X), k, random_state=shared, **aa_kw) for _ in range(n_init)]
+        shared = np.random.RandomState(0)
+        models, best = cdr.fit_restarts(lambda: cdr.ArchetypalAnalysis(k, random_state=shared, **aa_kw),
+                                        X, n_init, n_jobs=3)
+        for m, w, t in zip(models, want, twin):
+            # ten outer iterations: the oracle's own response to a one-ulp change of X is the yardstick
+            assert m.n_iter == w["n_iter"]
+            assert abs(m.cost - w["cost"]) < max(1e-10 * w["cost"], 20 * abs(t["cost"] - w["cost"]))
+            assert np.abs(m.weights - w["weights"]).max() < max(1e-8, 20 * np.abs(t["weights"] - w["weights"]).max())
+            assert np.array_equal(m.dictionary.argmax(axis=1), w["dictionary"].argmax(axis=1))
+        assert best == int(np.argmin([w["cost"] for w in want]))
+        # GPNH convex coding
+        shared = np.random.RandomState(0)
+        want = [orc.gpnh_convex_coding(X, k, random_state=shared, **gp_kw) for _ in range(n_init)]
+        shared = np.random.RandomState(0)
+        models, best = cdr.fit_restarts(lambda: cdr.GPNHConvexCoding(k, random_state=shared, **gp_kw),
+                                        X, n_init, n_jobs=3)
+        shared = np.random.RandomState(0)
+        twin = [orc.gpnh_convex_coding(ulp_perturbed(X), k, random_state=shared, **gp_kw) for _ in range(n_init)]
+        for m, w, t in zip(models, want, twin):
+            assert m.n_iter == w["n_iter"]
+            assert abs(m.cost - w["cost"]) < max(1e-10 * w["cost"], 20 * abs(t["cost"] - w["cost"]))
+            assert np.abs(m.weights - w["weights"]).max() < max(1e-8, 20 * np.abs(t["weights"] - w["weights"]).max())
+            assert np.abs(m.dictionary - w["dictionary"]).max() < max(
+                1e-9, 20 * np.abs(t["dictionary"] - w["dictionary"]).max())
+        assert best == int(np.argmin([w["cost"] for w in want]))
+
+
 def test_concurrent_restarts_match_the_sequential_loop(cdr, orc, c3_problem):
     """fit_restarts: the starting factors of all restarts are drawn first, in the drivers' order,
     then the fits run several at a time on separate device contexts -- every restart gives what
