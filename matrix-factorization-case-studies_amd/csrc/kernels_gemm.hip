@@ -878,6 +878,131 @@ __global__ __launch_bounds__(!ACC64 ? (NCT == 1 ? 1024 : 768) : (NCT == 1 ? 768 
     }
 }
 
+// row-local, float32 MFMA, wave-streaming with LDS-DMA staging (k <= 32).  The structure of
+// k_row_local_f32_ws -- a block is W waves on one CU, every wave owns one 32-row tile and sweeps
+// the columns -- with both operands brought in by `global_load_lds_dwordx4`: no staging registers
+// (32 fewer than the register-staged kernel, which is what makes room for the float64 sums at four
+// waves per SIMD), no ds_write instructions.  A wave-instruction writes 64 x 16 B = 1 KiB of LDS
+// in lane order (a "piece"), so the XOR swizzle that keeps the fragment reads conflict free sits
+// on the SOURCE address: lane l of a piece fetches the chunk whose swizzled position is l.
+//   X: a tile is 32 rows x 32 columns = 4 pieces (8 rows x 128 B each); every wave owns a RING of
+//      R pieces (R = 9..12, whatever 160 KB of LDS allow for W waves): tile t's pieces sit in ring
+//      slots (4t + i) mod R, and R - 4 pieces of the tiles behind it are in flight while it is
+//      multiplied (the register-staged kernel keeps 8 KB per wave in flight).
+//   B: 64-column slabs (8 pieces: 4 components x 256 B each), two buffers shared by the block;
+//      every wave issues one piece per slab (waves past the eighth repeat earlier pieces:
+//      identical bytes).
+// Every wave issues the same number of DMA instructions per step, so the waits are counted
+// (`s_waitcnt vmcnt(N)`: hipcc does not track what lands in LDS; LDS-DMA data is ordered for a
+// ds_read only by the issuing wave's covering vmcnt, plus a barrier for other waves' reads) and the
+// block barrier is the raw s_barrier (a __syncthreads would drain the DMAs in flight).  The fp32
+// accumulation chain ends after every tile (32 columns); the pieces are summed in float64 (see
+// k_row_local_f32_ws).
+template <bool NT>
+__device__ __forceinline__ void dma16(const float *src, float *lds_uniform)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_uniform, 16, 0, NT ? 2 : 0);
+}
+
+template <int R, bool NT>
+__global__ __launch_bounds__(1024) void k_row_local_f32_dma(const float *__restrict__ X, long ldx,
+                                                            const float *__restrict__ B, int p_pad,
+                                                            double *__restrict__ out, long n_pad, int W)
+{
+    constexpr int KP = 32, SB = 64, TC = 32;
+    static_assert(R >= 8 && R <= 12, "ring of 8..12 pieces");
+    extern __shared__ __attribute__((aligned(16))) float dma_smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    float *bs = dma_smem;                                   // [2][KP * SB]
+    float *xs = dma_smem + 2 * KP * SB + wave * (R * 256);  // R pieces of 256 floats, wave-private
+    const long r0 = ((long)blockIdx.x * W + wave) * 32;
+    const bool active = r0 < n_pad;
+    const long r0c = active ? r0 : n_pad - 32;
+    const int h = lane >> 5, j = lane & 31;
+
+    // X piece i of a tile (rows 8i .. 8i+7): lane -> row 8i + (lane >> 3), swizzled position lane & 7
+    int xoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        xoff[i] = (int)(row * ldx) + 4 * chunk;
+    }
+    const float *gx = X + r0c * ldx;
+    // B piece of this wave: components 4 pb .. 4 pb + 3 of the slab, lane -> component 4 pb + (lane >> 4)
+    const int pb = wave & 7;
+    const int bcomp = 4 * pb + (lane >> 4);
+    const int boff = bcomp * p_pad + 4 * ((lane & 15) ^ (bcomp & 15));
+    const int ntile = p_pad / TC, nslab = p_pad / SB;
+    int issued = 0;                                          // X pieces issued so far (uniform)
+    auto issue_piece = [&]() {                               // next piece of the sweep into its ring slot
+        int tl = issued >> 2;
+        if (tl >= ntile) tl = ntile - 1;                     // past the end: harmless reloads
+        const int i = issued & 3;
+        const int slot = issued % R;
+        const int off = i == 0 ? xoff[0] : (i == 1 ? xoff[1] : (i == 2 ? xoff[2] : xoff[3]));
+        dma16<NT>(gx + off + tl * TC, xs + slot * 256);
+        ++issued;
+    };
+    auto issue_b = [&](int sl, int buf) { dma16<false>(B + boff + sl * SB, bs + buf * (KP * SB) + pb * 256); };
+
+    f32x16 acc;
+    double accd[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        acc[e] = 0.f;
+        accd[e] = 0.0;
+    }
+
+    issue_b(0, 0);
+#pragma unroll
+    for (int i = 0; i < R; ++i) issue_piece();
+    for (int tl = 0; tl < ntile; ++tl) {
+        const int s = tl >> 1, ts = tl & 1;
+        if (ts == 0) {
+            // pieces 4 tl .. 4 tl + 3 and (older) this wave's B(s) piece have landed when at most the
+            // R - 4 younger X pieces are outstanding
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R - 4) : "memory");
+            __builtin_amdgcn_s_barrier();                    // all waves: B(s) complete, slab s-1 read
+            issue_b(s + 1 < nslab ? s + 1 : s, (s + 1) & 1);
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R - 3) : "memory");   // + the B piece issued one tile ago
+        }
+        const int base = (4 * tl) % R;                       // ring slot of this tile's first piece
+        int slot = base + (j >> 3);
+        slot = slot >= R ? slot - R : slot;
+        const float *xb = xs + slot * 256 + (j & 7) * TC;
+        const float *bb = bs + (s & 1) * (KP * SB) + j * SB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pcx = ((2 * q + h) ^ ((j >> 1) & 7)) << 2;
+            const int pcb = ((ts * 8 + 2 * q + h) ^ (j & 15)) << 2;
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(xb + pcx);
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bb + pcb);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[m], acc, 0, 0, 0);
+        }
+        // the four slots of this tile are free again (their reads were waited for before the MFMAs)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_piece();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            accd[e] += (double)acc[e];
+            acc[e] = 0.f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the trailing reloads
+    if (active) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const long row = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            out[row * KP + j] = accd[reg];
+        }
+    }
+}
+
 // row-local, float64 VALU: block = 64 rows, X tile staged through LDS with coalesced
 // loads; thread (row = t&63, q = t>>6) accumulates the components [q*KP/4, (q+1)*KP/4).
 template <int KP>
@@ -1135,8 +1260,9 @@ int launch_reduce_rows_fixup(Ctx *c, const unsigned int *count_dev, const int *r
 // 0: operands straight from global memory; 1: X staged in wave-private LDS;
 // >= 2: block-tiled, B shared through LDS: 2 = 64-column tiles, 3 = 64 double-buffered,
 // 4 (default) = 128, 5 = 32 double-buffered, 6 = 128 double-buffered, 7 = 32;
-// 8: wave-streaming (wave-private X tiles, B slabs shared per block).  aa_set_option.
-int g_row_local_variant = -1;   // -1: by size (8 from 32768 rows per GPU, else 4)
+// 8: wave-streaming (wave-private X tiles, B slabs shared per block); 9: the same with LDS-DMA staging
+// and float64 sums of 32-column pieces (k <= 32).  aa_set_option.
+int g_row_local_variant = -1;   // -1: by size (wave-streaming from 32768 rows per GPU -- 9 for k <= 32, 8 above -- else 4)
 int g_f64_mfma = 1;            // float64 data: pass kernels on the f64 matrix cores (0: f64 VALU;
                                // row-local: 1 = wave-streaming from 32768 rows, else block-tiled;
                                // 2 / 3 = always wave-streaming / always block-tiled)
@@ -1145,21 +1271,64 @@ int g_reduce_rows_blocks = 512; // target block count of the reduce-over-rows ke
 int g_row_local_stagger = 0;   // variant 8: column-slab offset between consecutive blocks
 int g_row_local_waves = 0;     // variant 8: waves per block (0 = one block per CU)
 int g_row_local_acc64 = 1;     // float32 row-local kernels: cut the fp32 accumulation chain every 32 columns and sum the
-                               // pieces in float64 -- 0: never, 1: in the block-tiled kernel (< 32768 rows per GPU; free
-                               // there), 2: in the wave-streaming kernel too (costs it a wave per SIMD: 0.31 -> 0.6 ms)
+                               // pieces in float64 -- 0: never (row_local_variant 8 for large shards), 1: in the
+                               // block-tiled kernel and, for large shards with k <= 32, through the LDS-DMA kernel
+                               // (variant 9), 2: in the register-staged wave-streaming kernel too (k > 32; costs
+                               // it a wave per SIMD: 0.31 -> 0.6 ms)
+int g_row_local_ring = 8;      // LDS-DMA kernel: pieces in a wave's ring (8: one tile in flight per wave -- measured
+                               // fastest, 0.376 ms back to back against 0.388 at 11; 0: what LDS allows)
+int g_row_local_nt = 0;        // LDS-DMA kernel: non-temporal hint on the X stream
 int g_row_local_chunk = 0;     // experiment: force the column chunk of the block-tiled float32 kernel (0: by size)
 int g_row_local_split = 1;     // block-tiled kernels: split the contraction over column chunks when there are few row blocks
 static int row_local_variant(const Ctx *c)
 {
     if (g_row_local_variant >= 0) return g_row_local_variant;
-    return c->n_pad / 32 >= 8 * 128 ? 8 : 4;
+    if (c->n_pad / 32 < 8 * 128) return 4;
+    // large shards: wave-streaming; k <= 32 with float64 sums of 32-column pieces through the LDS-DMA
+    // kernel (1 % slower than the register-staged kernel with one fp32 chain per row, 86 x closer to
+    // the exact product: rms error 3.5e-9 against 3.1e-7 of sum |x||b| at p = 4096)
+    return (c->KP == 32 && g_row_local_acc64 >= 1) ? 9 : 8;
 }
 
 int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
 {
     dim3 block(256);
     gemm_event(c, 1);
-    if (c->dtype == AA_F32 && row_local_variant(c) == 8) {
+    if (c->dtype == AA_F32 && row_local_variant(c) == 9 && c->KP == 32) {
+        // LDS-DMA wave-streaming kernel with float64 sums
+        const float *B = reinterpret_cast<const float *>(B_wideT);
+        const long tiles = c->n_pad / 32;
+        int W = g_row_local_waves > 0 ? g_row_local_waves : (int)((tiles + 255) / 256);
+        if (W < 8) W = 8;
+        if (W > 16) W = 16;
+        int R = (160 * 1024 - 2 * 32 * 64 * 4) / (W * 1024);      // ring pieces per wave that 160 KB allow
+        if (R > 12) R = 12;
+        if (g_row_local_ring > 0 && g_row_local_ring < R) R = g_row_local_ring;
+        if (R < 8) R = 8;
+        const size_t lds = ((size_t)2 * 32 * 64 + (size_t)W * R * 256) * sizeof(float);
+        dim3 grid((unsigned)((tiles + W - 1) / W)), blk((unsigned)(64 * W));
+#define RLD(RV, NTV)                                                                               \
+    do {                                                                                           \
+        static bool attr_done[64] = {false};                                                       \
+        if (!attr_done[c->device & 63]) {                                                          \
+            AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_local_f32_dma<RV, NTV>), \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
+            attr_done[c->device & 63] = true;                                                      \
+        }                                                                                          \
+        hipLaunchKernelGGL((k_row_local_f32_dma<RV, NTV>), grid, blk, lds, c->stream, c->X.as<float>(),   \
+                           c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W);                     \
+    } while (0)
+#define RLD2(RV) do { if (g_row_local_nt) RLD(RV, true); else RLD(RV, false); } while (0)
+        switch (R) {
+            case 8: RLD2(8); break;
+            case 9: RLD2(9); break;
+            case 10: RLD2(10); break;
+            case 11: RLD2(11); break;
+            default: RLD2(12); break;
+        }
+#undef RLD2
+#undef RLD
+    } else if (c->dtype == AA_F32 && row_local_variant(c) == 8) {
         // wave-streaming kernel: W waves per block, one block per CU where possible
         const float *B = reinterpret_cast<const float *>(B_wideT);
         const int nct = c->KP / 32;

@@ -432,7 +432,7 @@ int aa_set_option(const char *name, int value)
 {
     AA_REQUIRE(name != nullptr, AA_ERR_ARG, "null option name");
     if (!strcmp(name, "row_local_variant")) {
-        AA_REQUIRE(value >= -1 && value <= 8, AA_ERR_ARG, "row_local_variant must be in -1..8");
+        AA_REQUIRE(value >= -1 && value <= 9, AA_ERR_ARG, "row_local_variant must be in -1..9");
         g_row_local_variant = value;
     } else if (!strcmp(name, "qp_pass_cap")) {
         AA_REQUIRE(value >= 1, AA_ERR_ARG, "qp_pass_cap must be >= 1");
@@ -446,6 +446,11 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "row_local_acc64")) {
         AA_REQUIRE(value >= 0 && value <= 2, AA_ERR_ARG, "row_local_acc64 must be 0, 1 or 2");
         g_row_local_acc64 = value;
+    } else if (!strcmp(name, "row_local_ring")) {
+        AA_REQUIRE(value == 0 || (value >= 8 && value <= 12), AA_ERR_ARG, "row_local_ring must be 0 or 8..12");
+        g_row_local_ring = value;
+    } else if (!strcmp(name, "row_local_nt")) {
+        g_row_local_nt = value != 0;
     } else if (!strcmp(name, "row_local_chunk")) {
         AA_REQUIRE(value >= 0, AA_ERR_ARG, "row_local_chunk must be >= 0");
         g_row_local_chunk = value;

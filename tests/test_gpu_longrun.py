@@ -219,5 +219,5 @@ def test_pass_kernels_against_numpy(cdr, dtype, n):
     if dtype == "float64":
         assert err_rl < 2e-14 and err_rr < 2e-14
     else:
-        assert err_rl < (5e-8 if n < 32768 else 6e-6)
+        assert err_rl < 5e-8
         assert err_rr < 2e-7

@@ -603,7 +603,7 @@ def test_dictionary_update_wide_k_vs_oracle(cdr, orc, dtype, k):
     assert (st.n_iter, st.n_feval) == (want[2], want[3])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("k", [7, 40])
 def test_row_local_variants_agree(cdr, orc, variant, k):
     """The float32 row-local GEMM kernels (direct, wave-private LDS, and the block-tiled
