@@ -106,8 +106,8 @@ def test_converged_parity(cdr, problem, dtype):
 # afterwards), and it has a second local optimum, 4 of the 32 archetypes elsewhere, at
 # 58.7192 = +1.0e-2: the oracle, continued for 300 iterations from a HIP end state there, stays
 # (tools/diverge_continue.py).  Which optimum a run reaches is decided around iteration 80.  Of
-# 67 float64 runs (oracle under data perturbations, HIP float64 under start perturbations and
-# kernel choices) none went to the second optimum; of 34 float32 runs with the 32-column chains
+# 80 float64 runs (oracle under data perturbations, HIP float64 under start perturbations and
+# kernel choices) none went to the second optimum; of 45 float32 runs with the 32-column chains
 # one did (qp_quad_cap = 1000).  So beyond the default configuration, which is pinned above, the
 # families below are judged by count: every end point is one of the two optima, and at most one
 # run of a family may sit in the second.

@@ -1,6 +1,6 @@
 #!/bin/bash
 : "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
-# round-2 artefacts: bench lines and rocprofv3 kernel statistics for every configuration measured
+# round artefacts: bench lines and rocprofv3 kernel statistics for every configuration measured
 # (outputs under gpurun_out/final_*; the ones quoted in DESIGN.md are copied to profiles/)
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT

@@ -1,0 +1,15 @@
+# scratch: run the row-local pass kernel N times per variant (for rocprofv3 counter collection)
+import os, sys
+import numpy as np
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_R, "matrix-factorization-case-studies_amd")); sys.path.insert(0, _R)
+import bench
+from convex_dim_red import _backend
+n, p, k = bench.N_SAMPLES, bench.N_FEATURES, bench.N_COMPONENTS
+X = bench.synthetic_rows(0, n); C0, Z0 = bench.start_factors(n, k)
+with _backend.Context(dtype="float32") as ctx:
+    ctx.set_data(X); ctx.set_state(C0, Z0, np.ones(k)); ctx.prepare()
+    for v in (8, 9):
+        _backend.set_option("row_local_variant", v)
+        print(v, ctx.time_kernel(1, 10))
+        print("reduce", ctx.time_kernel(0, 10))
