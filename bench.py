@@ -306,7 +306,7 @@ def main():
                    "parallelism": "rows/%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                     "kernel": "k_reduce_rows_f32 / k_row_local_f32_ws (mean of the two pass kernels, event pairs around every launch in 10 outer iterations)",
+                     "kernel": "k_reduce_rows_f32 / k_row_local_f32_dma (mean of the two pass kernels, event pairs around every launch in 10 outer iterations)",
                      "ms_reduce_rows": ms_reduce, "ms_row_local": ms_local,
                      "launches_timed": [n_reduce, n_local],
                      "ms_streaming_read_probe": ms_probe,

@@ -948,18 +948,18 @@ __global__ __launch_bounds__(1024) void k_row_local_f32_dma(const float *__restr
     };
     auto issue_b = [&](int sl, int buf) { dma16<false>(B + boff + sl * SB, bs + buf * (KP * SB) + pb * 256); };
 
-    f32x16 acc;
+    // two fp32 accumulator sets, alternating tile by tile: the float64 flush of one set runs in the
+    // shadow of the matrix instructions that fill the other (the flush needs the LAST instruction of
+    // its chain to have retired: 16 passes)
+    f32x16 acc0, acc1;
     double accd[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        acc[e] = 0.f;
+        acc0[e] = 0.f;
+        acc1[e] = 0.f;
         accd[e] = 0.0;
     }
-
-    issue_b(0, 0);
-#pragma unroll
-    for (int i = 0; i < R; ++i) issue_piece();
-    for (int tl = 0; tl < ntile; ++tl) {
+    auto tile_mfma = [&](int tl, f32x16 &acc) {
         const int s = tl >> 1, ts = tl & 1;
         if (ts == 0) {
             // pieces 4 tl .. 4 tl + 3 and (older) this wave's B(s) piece have landed when at most the
@@ -987,12 +987,25 @@ __global__ __launch_bounds__(1024) void k_row_local_f32_dma(const float *__restr
         // the four slots of this tile are free again (their reads were waited for before the MFMAs)
 #pragma unroll
         for (int i = 0; i < 4; ++i) issue_piece();
+    };
+    auto flush = [&](f32x16 &acc) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             accd[e] += (double)acc[e];
             acc[e] = 0.f;
         }
+    };
+
+    issue_b(0, 0);
+#pragma unroll
+    for (int i = 0; i < R; ++i) issue_piece();
+    for (int tl = 0; tl < ntile; tl += 2) {                  // p_pad is a multiple of 128: ntile is even
+        tile_mfma(tl, acc0);
+        flush(acc1);                                         // the previous tile's sums (zeros at tl = 0)
+        tile_mfma(tl + 1, acc1);
+        flush(acc0);
     }
+    flush(acc1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the trailing reloads
     if (active) {
 #pragma unroll

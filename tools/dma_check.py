@@ -39,7 +39,7 @@ with _backend.Context(dtype="float32") as ctx:
               (variant, waves, ring, nt, ms, n * p * 4 / ms / 1e9, np.sqrt((err ** 2).mean()), err.max(),
                bool(np.isfinite(full[-40:]).all())), flush=True)
     _backend.set_option("row_local_waves", 0)
-    _backend.set_option("row_local_ring", 0)
+    _backend.set_option("row_local_ring", 8)
     _backend.set_option("row_local_nt", 0)
     for variant in (8, 9, 8, 9):
         _backend.set_option("row_local_variant", variant)
