@@ -502,6 +502,12 @@ class Context(object):
                                             _ptr(costs)))
         return costs
 
+    def outer_iterations_nocost(self, n_outer, spg_kw, qp_kw):
+        """The same iterations without a cost record (with the library option ``outer_nosync`` the
+        call returns while the work is in flight: tools/interleave_probe.py)."""
+        sp, qp = spg_params(**spg_kw), qp_params(**qp_kw)
+        _check(self.lib.aa_outer_iterations(self.h, n_outer, ctypes.byref(sp), ctypes.byref(qp), None))
+
     def iterate(self, cost0, max_outer, tolerance, stopping_criterion, require_monotonic,
                 update_dictionary, update_weights, spg_kw, qp_kw, check_every=8,
                 mono_tolerance=None, delta=0.0, scale_kw=None):

@@ -141,7 +141,12 @@ struct Ctx {
     int dtype = AA_F64;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // side stream: the QP's straggler kernel
+    hipStream_t stream3 = nullptr;             // the live consumers of parked QP samples (qp_live): a queue of
+                                               // their own, stream2 may still hold the residual projection
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    DevBuf qpLive;                             // ready[cap] | done[cap] flags of the live hand-over (QpLive)
+    long qp_live_cap = 0;
+    int qp_live_epoch = 0;
     bool qp_tail_pending = false;              // stragglers run on stream2, results in tmpTall by slot
     // the residual projection of the dictionary SPG (spg.py:250-276: convergence flags only) runs on
     // the side stream beside the weights QP, on its own scratch set (launch_proj_side / join_side)
@@ -333,7 +338,7 @@ extern int g_qp_refill_min;       // kernels_qp.hip
 extern int g_qp_waves;            // kernels_qp.hip
 extern int g_qp_sort;             // kernels_qp.hip
 extern int g_qp_profile;          // kernels_qp.hip
-extern int g_qp_overlap_tail, g_qp_tail_cap;     // kernels_qp.hip
+extern int g_qp_overlap_tail, g_qp_tail_cap, g_qp_live, g_qp_live_blocks, g_qp_live_occ;     // kernels_qp.hip
 
 // ------------------------------------------------------------------ comm.hip
 int comm_unique_id(void *id128);

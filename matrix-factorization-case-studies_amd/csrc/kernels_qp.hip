@@ -122,7 +122,43 @@ struct QpHeader {
     unsigned int n_long;          // hybrid row/wave update: head of the sorted list that the
                                   // wave-per-sample kernel takes (predicted-long samples)
     unsigned int dbg_rounds, dbg_trips, dbg_waves, pad;   // qp_profile counters of the row kernel
+    unsigned int waves_done;      // live hand-over: producer waves (k_qp_quad) that have exited
+    unsigned int pad1, pad2, pad3;
 };
+
+// Live hand-over of parked samples (qp_live): k_qp_quad publishes a parked sample at once (its
+// iterate, its continuation record and its row go out with agent-scope stores, then ready[slot] =
+// epoch) and a consumer launch of k_qp_wave that runs BESIDE k_qp_quad on the side stream takes the
+// slots by ticket -- the dependent chain of the longest sample (100-450 passes at ~0.9 us) then starts
+// when that sample reaches the pass cap, not when the last batch of k_qp_quad has finished.
+// epoch: number of this update (flags of earlier updates never match: nothing to clear).
+// mode 0: off; 1: consumer (tickets, waits for producers); 2: clean-up after both kernels (static
+// slots, skips the ones a consumer finished: done[slot] == epoch).
+struct QpLive {
+    int mode, epoch;
+    unsigned int producer_waves;
+    unsigned int n;               // samples of this update: no slot beyond it can ever exist
+    int *ready, *done;
+};
+
+__device__ __forceinline__ void qp_store_agent(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double qp_load_agent(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(
+        reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void qp_store_agent(int *p, int v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int qp_load_agent(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ int qp_debug_wave_max(int v)   // maximum of v over the active lanes
 {
@@ -884,7 +920,7 @@ __device__ __forceinline__ double qw_matvec_bcast(const double (&Acol)[16], doub
 }
 
 template <int KQ>
-__global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*[KQ][KQ]*/,
+__device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ][KQ]*/,
                                                  const double *__restrict__ B, long stride_j,
                                                  long stride_t, const double *__restrict__ bscale,
                                                  double *__restrict__ Z, int ldz, long n_fresh,
@@ -897,7 +933,8 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
                                                  const unsigned int *__restrict__ count_ptr = nullptr,
                                                  int park_at = 1 << 30, unsigned int *__restrict__ n_parked = nullptr,
                                                  int *__restrict__ park_rows = nullptr,
-                                                 QpCarry *__restrict__ park = nullptr)
+                                                 QpCarry *__restrict__ park = nullptr,
+                                                 QpLive lv = QpLive{0, 0, 0u, 0u, nullptr, nullptr})
 {
     // park_at (continuation path): a sample still running after that many passes is written back
     // and appended to a second overflow list (n_parked / park_rows / park) -- the handful of
@@ -928,14 +965,51 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
                                          : (fresh_list ? hdr->n_long : (fresh ? (unsigned int)n_fresh : hdr->n_overflow));
 
     const unsigned int wave_id =
-        (unsigned int)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    const unsigned int n_waves = gridDim.x * 4;
+        (unsigned int)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const unsigned int n_waves = gridDim.x * (blockDim.x >> 6);
     unsigned long long wv_total = 0ull;      // pass statistics of this wave: one atomic pair at exit
     int wv_max = 0;
-    for (unsigned int slot = wave_id; slot < count; slot += n_waves) {
-        const long row = fresh_list ? (long)fresh_list[slot] : (fresh ? (long)slot : (long)ovf_rows[slot]);
+    unsigned int static_slot = wave_id;
+    // next slot of this wave, or 0xffffffff: static stride (mode 0 / 2), tickets (mode 1)
+    auto next_slot = [&]() -> unsigned int {
+        if (lv.mode != 1) {
+            while (static_slot < count) {
+                const unsigned int sl = static_slot;
+                static_slot += n_waves;
+                if (lv.mode == 2 && lv.done[sl] == lv.epoch) continue;      // a consumer finished it
+                return sl;
+            }
+            return 0xffffffffu;
+        }
+        unsigned int tk = 0u;
+        if (lane == 0) tk = atomicAdd(&hdr->next_overflow, 1u);
+        tk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
+        if (tk >= lv.n) return 0xffffffffu;          // (ready[] has lv.n entries)
+        // waiting waves stay out of the way: lowest issue priority, one flag load per nap (0.4 us at
+        // first, 3 us after the first 32), the producers' counters only every eighth nap
+        __builtin_amdgcn_s_setprio(0);
+        for (int spin = 0; spin < 400000; ++spin) {                    // bounded: the clean-up launch covers a give-up
+            if (qp_load_agent(&lv.ready[tk]) == lv.epoch) {
+                __builtin_amdgcn_s_setprio(3);
+                return tk;
+            }
+            if ((spin & 7) == 7 &&
+                __hip_atomic_load(&hdr->waves_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= lv.producer_waves) {
+                // every producer has exited, and published before it did: the slot exists or never will
+                if (tk >= __hip_atomic_load(&hdr->n_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    return 0xffffffffu;
+            }
+            if (spin < 32) __builtin_amdgcn_s_sleep(16);
+            else __builtin_amdgcn_s_sleep(127);
+        }
+        return 0xffffffffu;
+    };
+    for (unsigned int slot = next_slot(); slot != 0xffffffffu; slot = next_slot()) {
+        const bool shared = lv.mode == 1;           // the producer kernel is still running: coherent loads
+        const long row = fresh_list ? (long)fresh_list[slot]
+                                    : (fresh ? (long)slot : (long)(shared ? qp_load_agent(&ovf_rows[slot]) : ovf_rows[slot]));
 
-        double x = live ? Z[row * ldz + comp] : 0.0;
+        double x = live ? (shared ? qp_load_agent(&Z[row * ldz + comp]) : Z[row * ldz + comp]) : 0.0;
         const double b = live ? -B[comp * stride_j + row * stride_t] * (bscale ? bscale[comp] : 1.0) : 0.0;
         double f, alpha = 1.0, fmem[QW_MAXMEM];
         int n_iter, n_feval;
@@ -954,6 +1028,13 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             f = 0.5 * (xg + xb);
             n_iter = 0;
             n_feval = 1;
+        } else if (shared) {
+            const double *cd = reinterpret_cast<const double *>(&ovf[slot]);
+            alpha = qp_load_agent(cd);
+            f = qp_load_agent(cd + 1);
+            const long long packed = __double_as_longlong(qp_load_agent(cd + 2));
+            n_iter = (int)(packed & 0xffffffffll);
+            n_feval = (int)(packed >> 32);
         } else {
             const QpCarry cr = ovf[slot];
             f = cr.f;
@@ -1044,6 +1125,7 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
             continue;
         }
         if (lane == 0 && iters) iters[row] = n_iter;
+        if (lane == 0 && lv.mode == 1) lv.done[slot] = lv.epoch;    // read by the clean-up launch (next kernel)
         wv_total += (unsigned long long)n_iter;
         wv_max = n_iter > wv_max ? n_iter : wv_max;
     }
@@ -1052,6 +1134,27 @@ __global__ __launch_bounds__(256) void k_qp_wave(const double *__restrict__ A /*
         atomicMax(&hdr->max_passes, (unsigned long long)wv_max);
     }
 }
+
+#define QW_ARGS const double *__restrict__ A, const double *__restrict__ B, long stride_j, long stride_t,            \
+                const double *__restrict__ bscale, double *__restrict__ Z, int ldz, long n_fresh, int k,            \
+                aa_qp_params p, int *__restrict__ iters, QpHeader *__restrict__ hdr,                                \
+                const int *__restrict__ ovf_rows, const QpCarry *__restrict__ ovf, double *__restrict__ zslot,      \
+                const int *__restrict__ fresh_list = nullptr, const unsigned int *__restrict__ count_ptr = nullptr, \
+                int park_at = 1 << 30, unsigned int *__restrict__ n_parked = nullptr,                               \
+                int *__restrict__ park_rows = nullptr, QpCarry *__restrict__ park = nullptr,                        \
+                QpLive lv = QpLive{0, 0, 0u, 0u, nullptr, nullptr}
+#define QW_PASS A, B, stride_j, stride_t, bscale, Z, ldz, n_fresh, k, p, iters, hdr, ovf_rows, ovf, zslot,           \
+                fresh_list, count_ptr, park_at, n_parked, park_rows, park, lv
+template <int KQ>
+__global__ __launch_bounds__(256) void k_qp_wave(QW_ARGS) { qp_wave_body<KQ>(QW_PASS); }
+// the live consumers (QpLive mode 1): blocks of 16 waves that are launched with a whole CU's LDS
+// as (unused) dynamic shared memory while k_qp_quad asks for 1/12 of it per wave -- LDS becomes the
+// resource that keeps the two kernels on DIFFERENT CUs: the latency-bound chains of the consumers
+// (four per SIMD) do not share issue slots with the MFMA-heavy waves of k_qp_quad, which stretched
+// a consumer's pass from 0.9 to ~1.8 us when the two kernels were mixed on every SIMD
+__global__ __launch_bounds__(1024) void k_qp_wave_live(QW_ARGS) { qp_wave_body<32>(QW_PASS); }
+#undef QW_ARGS
+#undef QW_PASS
 
 // max_iterations <= 0: the reference's loop body never runs and x = P(x0) is returned.
 template <int KQ>
@@ -1659,7 +1762,8 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
                                              const aa_qp_params &p, int pass_cap, int *__restrict__ iters,
                                              QpHeader *__restrict__ hdr, int *__restrict__ ovf_rows,
                                              QpCarry *__restrict__ ovf, int refill_min,
-                                             const int *__restrict__ perm, long max_trips)
+                                             const int *__restrict__ perm, long max_trips,
+                                             int live_epoch, int *__restrict__ ovf_ready)
 {
     constexpr int J = 4 * MT;
     const int lane = threadIdx.x, sl = lane & 15, q = lane >> 4;
@@ -1861,23 +1965,43 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
             const bool conv = (sqrt(q2) < p.epsilon_two) || (qinf < p.epsilon_one);
             const bool finished = conv || n_feval > p.max_feval || n_iter >= p.max_iterations;
             if (finished || n_iter >= pass_cap) {
+                if (live_epoch && !finished) {
+                    // live hand-over: a consumer wave of k_qp_wave may pick this sample up while this
+                    // kernel is still running, possibly on another XCD: everything it reads goes out
+                    // with agent-scope stores, drained before the ready flag
 #pragma unroll
-                for (int j = 0; j < J; ++j)
-                    if (4 * j + q < k) Z[row * ldz + 4 * j + q] = x[j];
-                if (q == 0) {
-                    if (finished) {
-                        if (iters) iters[row] = n_iter;
-                        st_total += (unsigned long long)n_iter;
-                        st_max = n_iter > st_max ? n_iter : st_max;
-                    } else {
-                        const unsigned int slot = atomicAdd(&hdr->n_overflow, 1u);
-                        ovf_rows[slot] = (int)row;
-                        QpCarry cr;
-                        cr.alpha = alpha;
-                        cr.f = f;
-                        cr.n_iter = n_iter;
-                        cr.n_feval = n_feval;
-                        ovf[slot] = cr;
+                    for (int j = 0; j < J; ++j)
+                        if (4 * j + q < k) qp_store_agent(&Z[row * ldz + 4 * j + q], x[j]);
+                    unsigned int slot = 0u;
+                    if (q == 0) {
+                        slot = atomicAdd(&hdr->n_overflow, 1u);
+                        qp_store_agent(&ovf_rows[slot], (int)row);
+                        double *cd = reinterpret_cast<double *>(&ovf[slot]);
+                        qp_store_agent(cd, alpha);
+                        qp_store_agent(cd + 1, f);
+                        qp_store_agent(cd + 2, __longlong_as_double(((long long)n_feval << 32) | (unsigned int)n_iter));
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (q == 0) qp_store_agent(&ovf_ready[slot], live_epoch);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+                        if (4 * j + q < k) Z[row * ldz + 4 * j + q] = x[j];
+                    if (q == 0) {
+                        if (finished) {
+                            if (iters) iters[row] = n_iter;
+                            st_total += (unsigned long long)n_iter;
+                            st_max = n_iter > st_max ? n_iter : st_max;
+                        } else {
+                            const unsigned int slot = atomicAdd(&hdr->n_overflow, 1u);
+                            ovf_rows[slot] = (int)row;
+                            QpCarry cr;
+                            cr.alpha = alpha;
+                            cr.f = f;
+                            cr.n_iter = n_iter;
+                            cr.n_feval = n_feval;
+                            ovf[slot] = cr;
+                        }
                     }
                 }
                 active = false;
@@ -1898,6 +2022,10 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
             atomicMax(&hdr->max_passes, (unsigned long long)mx);
         }
     }
+    if (live_epoch) {                                  // every flag of this wave is out before it counts as done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) atomicAdd(&hdr->waves_done, 1u);
+    }
 }
 
 // The same body at three register budgets: OCC waves per SIMD (2: whatever the compiler likes,
@@ -1905,9 +2033,10 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
 #define QQ_ARGS const double *__restrict__ A, int lda, const double *__restrict__ B, long stride_j, long stride_t,   \
                 const double *__restrict__ bscale, double *__restrict__ Z, int ldz, long n, int k, aa_qp_params p, \
                 int pass_cap, int *__restrict__ iters, QpHeader *__restrict__ hdr, int *__restrict__ ovf_rows,      \
-                QpCarry *__restrict__ ovf, int refill_min, const int *__restrict__ perm, long max_trips
+                QpCarry *__restrict__ ovf, int refill_min, const int *__restrict__ perm, long max_trips,           \
+                int live_epoch, int *__restrict__ ovf_ready
 #define QQ_PASS A, lda, B, stride_j, stride_t, bscale, Z, ldz, n, k, p, pass_cap, iters, hdr, ovf_rows, ovf,        \
-                refill_min, perm, max_trips
+                refill_min, perm, max_trips, live_epoch, ovf_ready
 template <int MT, bool MEM1>
 __global__ __launch_bounds__(64) void k_qp_quad(QQ_ARGS) { qp_quad_body<MT, MEM1>(QQ_PASS); }
 template <int MT, bool MEM1>
@@ -1950,6 +2079,10 @@ int g_qp_quad_cap = 0;         // passes after which k_qp_quad parks a sample fo
                                // 32 from 65 536 samples per GPU (100 000: 1.985 against 2.010 ms per outer
                                // iteration), 24 below (12 500: 0.572 against 0.582)
 int g_qp_wave_blocks = 1024;   // blocks (4 waves each) of the wave-per-sample kernel when it finishes parked samples
+int g_qp_live = 0;             // k_qp_quad hands parked samples to a concurrent k_qp_wave launch (QpLive)
+int g_qp_live_occ = 3;         // register budget of k_qp_quad beside the consumers (waves per SIMD)
+int g_qp_live_blocks = 48;     // CUs given to the consumers (one block of 16 waves each)
+#define QP_LIVE_LDS 163840     // a CU's LDS
 int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
 int g_qp_tail_cap = 96;        // with qp_overlap_tail: only samples beyond this many passes go to the side stream (0: all parked ones)
@@ -2047,6 +2180,7 @@ __global__ __launch_bounds__(256) void k_qp_setup(QpHeader *__restrict__ hdr, do
         hdr->n_long = 0u;
         hdr->dbg_rounds = hdr->dbg_trips = hdr->dbg_waves = 0u;
         hdr->pad = 0u;
+        hdr->waves_done = 0u;
     }
     for (int e = t; e < KQ * KQ; e += 256) {
         const int i = e / KQ, j = e % KQ;
@@ -2205,28 +2339,82 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         long waves = (n + 15) / 16;
         if (waves > g_qp_quad_waves) waves = g_qp_quad_waves;
         const int *perm = nullptr;
-        if (will_sort) AA_CHECK(qp_order_rows(c, iters_dev, n, &perm, nullptr, 0, sort_hist != nullptr));
         hipStream_t s_main = c->stream;
         // watchdog only: a wave's slots take their samples one after the other, each at most
         // cap passes and a start-up trip
         const long rounds = (n + 16 * waves - 1) / (16 * waves);
         const long max_trips = 16 * rounds * ((long)cap + 2) + 16;
         const int refill = g_qp_quad_refill < 1 ? 1 : (g_qp_quad_refill > 16 ? 16 : g_qp_quad_refill);
+        // live hand-over (qp_live): the consumer launch of k_qp_wave goes out FIRST, on the side stream,
+        // so that its waves (80 VGPRs) are resident when k_qp_quad fills the rest of every SIMD --
+        // the quad kernel then runs at the four-waves-per-SIMD budget (128 VGPRs: 80 + 3 x 128 <= 512)
+        const bool live = g_qp_live && cap < p->max_iterations && c->stream3 && KW == 32 && !defer_tail;
+        QpLive lv{0, 0, 0u, 0u, nullptr, nullptr};
+        if (live) {
+            if ((long)c->qp_live_cap < n) {
+                AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+                AA_CHECK_HIP(hipStreamSynchronize(c->stream3));
+                AA_CHECK(c->qpLive.alloc((size_t)2 * n * sizeof(int)));       // zeroed: matches no epoch
+                c->qp_live_cap = n;
+                c->qp_live_epoch = 0;
+            }
+            if (c->qp_live_epoch == 0x7fffffff) {
+                AA_CHECK_HIP(hipMemsetAsync(c->qpLive.p, 0, c->qpLive.bytes, c->stream));
+                c->qp_live_epoch = 0;
+            }
+            lv.mode = 1;
+            lv.epoch = ++c->qp_live_epoch;
+            lv.producer_waves = (unsigned int)waves;
+            lv.n = (unsigned int)n;
+            lv.ready = c->qpLive.as<int>();
+            lv.done = lv.ready + c->qp_live_cap;
+            AA_CHECK_HIP(hipEventRecord(c->evFork, c->stream));
+            AA_CHECK_HIP(hipStreamWaitEvent(c->stream3, c->evFork, 0));
+            static bool lds_attr_set = false;
+            if (!lds_attr_set) {
+                AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_qp_wave_live),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, QP_LIVE_LDS));
+                lds_attr_set = true;
+            }
+            hipLaunchKernelGGL(k_qp_wave_live, dim3((unsigned)g_qp_live_blocks), dim3(1024), QP_LIVE_LDS, c->stream3, A2d, Btall,
+                               stride_j, stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
+                               (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr,
+                               (const int *)nullptr, (const unsigned int *)nullptr, 1 << 30,
+                               (unsigned int *)nullptr, (int *)nullptr, (QpCarry *)nullptr, lv);
+            AA_CHECK_HIP(hipEventRecord(c->evJoin, c->stream3));
+        }
+        // (the ordering kernels run while the cross-stream dependency of the consumers resolves: the
+        // consumers are resident on their CUs before k_qp_quad fills the chip)
+        if (will_sort) AA_CHECK(qp_order_rows(c, iters_dev, n, &perm, nullptr, 0, sort_hist != nullptr));
+        const int quad_occ = live ? g_qp_live_occ : g_qp_quad_occ;
+        // beside live consumers every wave of k_qp_quad asks for its share of a CU's LDS (see k_qp_wave_live)
+        const unsigned quad_lds = live ? (unsigned)((QP_LIVE_LDS / (4 * quad_occ)) & ~511) : 0u;
+        const int live_epoch = lv.epoch;
+        int *ovf_ready = lv.ready;
 #define QQK(KERN, MTV, M1V)                                                                         \
-    hipLaunchKernelGGL((KERN<MTV, M1V>), dim3((unsigned)waves), dim3(64), 0, s_main, A2d, KW, Btall,        \
+    hipLaunchKernelGGL((KERN<MTV, M1V>), dim3((unsigned)waves), dim3(64), quad_lds, s_main, A2d, KW, Btall, \
                        stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf,   \
-                       refill, perm, max_trips)
+                       refill, perm, max_trips, live_epoch, ovf_ready)
 #define QQL(MTV, M1V)                                                                               \
     do {                                                                                            \
-        if (g_qp_quad_occ >= 4) QQK(k_qp_quad_w4, MTV, M1V);                                        \
-        else if (g_qp_quad_occ == 3) QQK(k_qp_quad_w3, MTV, M1V);                                   \
+        if (quad_occ >= 4) QQK(k_qp_quad_w4, MTV, M1V);                                             \
+        else if (quad_occ == 3) QQK(k_qp_quad_w3, MTV, M1V);                                        \
         else QQK(k_qp_quad, MTV, M1V);                                                              \
     } while (0)
         if (k <= 16) { if (p->memory <= 1) QQL(1, true); else QQL(1, false); }
         else         { if (p->memory <= 1) QQL(2, true); else QQL(2, false); }
 #undef QQL
 #undef QQK
-        if (cap < p->max_iterations) {
+        if (live) {
+            // clean-up: whatever the consumers did not take (they give up after a bounded wait)
+            AA_CHECK_HIP(hipStreamWaitEvent(c->stream, c->evJoin, 0));
+            lv.mode = 2;
+            hipLaunchKernelGGL(k_qp_wave<32>, dim3(64), dim3(256), 0, c->stream, A2d, Btall,
+                               stride_j, stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
+                               (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr,
+                               (const int *)nullptr, (const unsigned int *)nullptr, 1 << 30,
+                               (unsigned int *)nullptr, (int *)nullptr, (QpCarry *)nullptr, lv);
+        } else if (cap < p->max_iterations) {
             // the parked samples, one wave each.  defer_tail: on the side stream, results to
             // tmpTall by slot; the caller's Z'X pass runs beside them on the weights as k_qp_quad
             // left them and launch_qp_tail_fixup adds the rank-m correction afterwards -- the

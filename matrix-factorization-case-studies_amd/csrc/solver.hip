@@ -21,6 +21,7 @@
 
 namespace aa {
 
+int g_outer_nosync = 0;
 int g_use_graph = 0;     // 1: aa_outer_iterations replays a captured pair of iterations (measured neutral)
 
 static thread_local std::string g_err;
@@ -511,6 +512,16 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "qp_wave_blocks")) {
         AA_REQUIRE(value >= 1 && value <= 8192, AA_ERR_ARG, "qp_wave_blocks must be in 1..8192");
         g_qp_wave_blocks = value;
+    } else if (!strcmp(name, "outer_nosync")) {
+        g_outer_nosync = value != 0;
+    } else if (!strcmp(name, "qp_live")) {
+        g_qp_live = value ? 1 : 0;
+    } else if (!strcmp(name, "qp_live_occ")) {
+        AA_REQUIRE(value >= 2 && value <= 4, AA_ERR_ARG, "qp_live_occ must be 2, 3 or 4");
+        g_qp_live_occ = value;
+    } else if (!strcmp(name, "qp_live_blocks")) {
+        AA_REQUIRE(value >= 1 && value <= 128, AA_ERR_ARG, "qp_live_blocks must be in 1..128");
+        g_qp_live_blocks = value;
     } else if (!strcmp(name, "qp_quad_occ")) {
         AA_REQUIRE(value >= 2 && value <= 4, AA_ERR_ARG, "qp_quad_occ must be 2, 3 or 4");
         g_qp_quad_occ = value;
@@ -567,6 +578,7 @@ int aa_ctx_create(aa_ctx **out, int device, int dtype)
         int lo = 0, hi = 0;                       // numerically lower = higher priority
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         e = hipStreamCreateWithPriority(&h->c.stream2, hipStreamDefault, hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->c.stream3, hipStreamDefault, hi);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->c.evFork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->c.evJoin, hipEventDisableTiming);
@@ -585,12 +597,13 @@ int aa_ctx_destroy(aa_ctx *h)
     Ctx *c = &h->c;
     (void)hipSetDevice(c->device);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->stream3) (void)hipStreamSynchronize(c->stream3);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     comm_destroy(c);
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->rlPartial, &c->redPartial,
                      &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->iterState, &c->snapC, &c->snapZ, &c->snapAlpha, &c->qpIters, &c->qpPerm,
-                     &c->qpStats, &c->tmpTall2, &c->redPartial2, &c->redOut2, &c->proj2, &c->projList2, &c->projSegCnt2};
+                     &c->qpStats, &c->qpLive, &c->tmpTall2, &c->redPartial2, &c->redOut2, &c->proj2, &c->projList2, &c->projSegCnt2};
     for (DevBuf *b : all) b->release();
     if (c->evFork2) (void)hipEventDestroy(c->evFork2);
     if (c->evJoin2) (void)hipEventDestroy(c->evJoin2);
@@ -599,6 +612,7 @@ int aa_ctx_destroy(aa_ctx *h)
     if (c->evFork) (void)hipEventDestroy(c->evFork);
     if (c->evJoin) (void)hipEventDestroy(c->evJoin);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete h;
     return AA_OK;
@@ -994,7 +1008,7 @@ int aa_outer_iterations(aa_ctx *h, int n_outer, const aa_spg_params *spg, const 
     // the gradient / Gram buffer pairs swap once per iteration -- are captured into a
     // hipGraph and replayed.  Single rank only (RCCL stays outside graphs).
     const bool graph = g_use_graph && c->world <= 1 && !c->force_comm && c->form == AA_FORM_DATA &&
-                       spg->max_iterations == 1 && n_outer >= 8 && !g_qp_overlap_tail;
+                       spg->max_iterations == 1 && n_outer >= 8 && !g_qp_overlap_tail && !g_qp_live;
     int i = 0;
     const int eager = graph ? 2 : n_outer;
     for (; i < eager; ++i) AA_CHECK(one_iteration());
@@ -1023,6 +1037,9 @@ int aa_outer_iterations(aa_ctx *h, int n_outer, const aa_spg_params *spg, const 
         i += 2 * pairs;
         for (; i < n_outer; ++i) AA_CHECK(one_iteration());
     }
+    // measurement only (tools/interleave_probe.py: several contexts enqueued round-robin by one host
+    // thread): return with the work in flight; the next blocking call of this context waits for it
+    if (g_outer_nosync && !costs) return AA_OK;
     if (costs && n_outer > 0)
         AA_CHECK_HIP(hipMemcpyAsync(costs, c->costDev.p, (size_t)2 * n_outer * sizeof(double),
                                     hipMemcpyDeviceToHost, c->stream));

@@ -39,4 +39,4 @@ with _backend.Context(dtype=os.environ.get("DTYPE", "float32")) as ctx:
                   (spec or "(defaults)", 1e3 * (t1 - t0) / 20, 20 / (t1 - t0), 1e3 * (t2 - t1) / 30, c1[-1], c2[-1]), flush=True)
             for name in opts:
                 _backend.set_option(name, {"qp_overlap_tail": 0, "row_local_acc64": 1, "qp_quad_cap": 0,
-                                            "fuse_finalize": 1, "qp_wave_blocks": 1024, "qp_tail_cap": 96, "proj_res_side": 1}.get(name, 0))
+                                            "fuse_finalize": 1, "qp_wave_blocks": 1024, "qp_tail_cap": 96, "proj_res_side": 1, "qp_live_blocks": 48, "qp_quad_occ": 3, "qp_live_occ": 3}.get(name, 0))
