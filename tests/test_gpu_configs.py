@@ -597,7 +597,58 @@ def test_two_ranks_match_one_rank(cdr):
     assert "MULTI_RANK_ESTIMATORS_OK world=2" in out.stdout, out.stdout[-3000:]
 
 
+def test_fit_restarts_over_two_devices(cdr, orc):
+    """fit_restarts(devices=[0, 1]): the workers are dealt over two GPUs, one resident copy of the
+    data per device; restart by restart the same costs and factors as on one device.  Skipped on a
+    box with one GPU."""
+    from convex_dim_red import _backend
+    if _backend.require_gpu() < 2:
+        pytest.skip("needs two GPUs")
+    rng = np.random.RandomState(8)
+    n, p, k, n_init = 900, 80, 5, 6
+    B = rng.standard_normal((k, p))
+    Zt = orc.right_stochastic_matrix((n, k), rng) ** 3
+    Zt /= Zt.sum(axis=1, keepdims=True)
+    X = Zt.dot(B) + 0.05 * rng.standard_normal((n, p))
+    kw = dict(init="random", tolerance=0, max_iterations=10, require_monotonic_cost_decrease=False,
+              dictionary_solver_kwargs=dict(max_iterations=1))
+    runs = []
+    for devices in ([0], [0, 1]):
+        shared = np.random.RandomState(2)
+        models, best = cdr.fit_restarts(lambda: cdr.ArchetypalAnalysis(k, random_state=shared, **kw), X, n_init,
+                                        n_jobs=2, devices=devices)
+        runs.append(([m.cost for m in models], [m.dictionary for m in models], best))
+    assert runs[0][0] == runs[1][0] and runs[0][2] == runs[1][2]
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.array_equal(a, b)
+
+
 # ------------------------------------------------------------------ driver preprocessing (SURVEY 8(f3))
+def test_driver_preprocessing_beyond_65535_rows(cdr):
+    """The preprocessing kernels walk the rows with grid-stride loops: more rows than a HIP grid has
+    y-blocks (65 535; round 2 launched one block row per data row and failed from there on), NaN
+    weights and 0 * inf products drop their columns like `weights * da` does in
+    bin/run_hadisst_aa.py:199-202."""
+    rng = np.random.RandomState(3)
+    n, p = 70001, 24
+    field = rng.standard_normal((n, p)).astype(np.float32)
+    field[69999, 5] = np.nan                      # missing once, in a row beyond 65 535
+    field[12, 7] = np.inf                         # times a zero weight: NaN
+    weights = np.linspace(0.5, 1.5, p)
+    weights[7] = 0.0
+    weights[11] = np.nan
+    with np.errstate(invalid="ignore"):
+        flat = weights * field.astype(np.float64)
+    missing = np.any(np.isnan(flat), axis=0)
+    assert missing.sum() == 3
+    with cdr.weight_and_flatten_on_device(field, weights, dtype="float32") as dev:
+        assert np.array_equal(dev.valid, np.logical_not(missing))
+        assert dev.shape == (n, p - 3)
+        got = dev.to_host()
+    want = flat[:, np.logical_not(missing)]
+    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_driver_preprocessing_on_device(cdr, orc, dtype):
     """bin/run_hadisst_aa.py:112-146,196-209 -- latitude weights, flattening, removal of the grid

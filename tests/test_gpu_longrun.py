@@ -190,6 +190,47 @@ def test_qp_quad_cap_invariance(cdr, cap):
     assert np.all(got >= 0) and np.allclose(got.sum(axis=1), 1, rtol=0, atol=1e-12)
 
 
+def test_qp_live_hand_over_is_bit_identical(cdr):
+    """qp_live (opt-in): k_qp_quad publishes a parked sample at once and a consumer launch of the
+    wave-per-sample kernel, resident on CUs of its own, continues it while k_qp_quad is still running.
+    Who continues a sample does not enter its arithmetic: weights and pass counts equal the
+    two-launch default bit for bit, on a QP batch and over outer iterations of a fit."""
+    from convex_dim_red import _backend
+    from oracle import aa_oracle as orc
+    import bench
+    rng = np.random.RandomState(5)
+    n, k, p = 20000, 32, 64
+    W = rng.standard_normal((k, p))
+    Zt = orc.right_stochastic_matrix((n, k), rng) ** 3
+    Zt /= Zt.sum(axis=1, keepdims=True)
+    Xs = Zt.dot(W) + 0.05 * rng.standard_normal((n, p))
+    A, B = W.dot(W.T), W.dot(Xs.T)
+    Z0 = orc.right_stochastic_matrix((n, k), rng)
+    X = bench.synthetic_rows(0, 20000)
+    C0, Zs = bench.start_factors(20000, K)
+    outs, traces = [], []
+    try:
+        _backend.set_option("qp_mode", 4)
+        for live in (0, 1, 1):
+            _backend.set_option("qp_live", live)
+            outs.append(_backend.qp_batch(A, B, Z0, "kn", return_iters=True))
+        _backend.set_option("qp_mode", 0)
+        with _backend.Context(dtype="float32") as ctx:
+            ctx.set_data(X)
+            for live in (0, 1):
+                _backend.set_option("qp_live", live)
+                ctx.set_state(C0, Zs, np.ones(K))
+                ctx.prepare()
+                traces.append(np.asarray(ctx.outer_iterations(12, dict(max_iterations=1), {})))
+    finally:
+        _backend.set_option("qp_live", 0)
+        _backend.set_option("qp_mode", 0)
+    assert outs[0][1].max() > 24                      # samples were handed over
+    for got, it in outs[1:]:
+        assert np.array_equal(got, outs[0][0]) and np.array_equal(it, outs[0][1])
+    assert np.array_equal(traces[0], traces[1])
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("n", [1500, 40000])
 def test_pass_kernels_against_numpy(cdr, dtype, n):
