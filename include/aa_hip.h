@@ -91,11 +91,22 @@ const char *aa_last_error(void);
 int aa_version(void);
 int aa_device_count(int *count);
 /* Process-wide tuning knobs (results are identical up to rounding for every setting):
- *   "row_local_variant" -1..8  float32 row-local GEMM: -1 (default) chosen by size (8 for
- *                               >= 32768 rows per GPU, else 4), 0 direct, 1 wave-private LDS, 2..7
- *                               block-tiled (2: 64-column tiles, 3: 64 double-buffered,
+ *   "row_local_variant" -1..9  float32 row-local GEMM: -1 (default) chosen by size (from 32768 rows
+ *                               per GPU: 9 for k <= 32, 8 for k <= 64; else 4), 0 direct, 1 wave-private
+ *                               LDS, 2..7 block-tiled (2: 64-column tiles, 3: 64 double-buffered,
  *                               4: 128, 5: 32 double-buffered, 6: 128 double-buffered, 7: 32),
- *                               8 wave-streaming (wave-private X tiles, shared B slabs)
+ *                               8 wave-streaming (wave-private X tiles, shared B slabs, register
+ *                               staged), 9 wave-streaming with both operands by LDS-DMA and float64
+ *                               sums of 32-column fp32 pieces
+ *   "row_local_acc64"   0..2   float32 row-local pass: 1 (default) = every fp32 accumulation chain ends
+ *                               after 32 columns and the pieces are summed in float64 (block-tiled
+ *                               kernels and variant 9; what keeps long float32 runs on the float64
+ *                               trajectory); 2 = also in variant 8 (half speed);
+ *                               0 = one fp32 chain per column chunk (round 2)
+ *   "row_local_split"   0|1    1 (default): block-tiled kernels split the contraction over column
+ *                               chunks when there are few row blocks
+ *   "row_local_ring"    0|8..12 variant 9: LDS pieces in a wave's ring (default 8; 0: what LDS allows)
+ *   "row_local_nt"      0|1    variant 9: non-temporal hint on the X stream (default 0)
  *   "f64_mfma"          0..3   float64 data: pass kernels on the f64 matrix cores (1, default: the
  *                               row-local one wave-streaming from 32768 rows per GPU, else
  *                               block-tiled; 2 / 3 force either) or on the f64 VALU (0)
@@ -151,6 +162,18 @@ int aa_device_count(int *count);
  *                               slower -- the two kernels take each other's issue slots)
  *   "qp_row_cap"        >= 1   passes after which the row kernel hands a sample to the
  *                               wave-per-sample kernel (default: never)
+ *   "qp_tail_cap"       >= 0   with qp_overlap_tail: only samples beyond this many passes go to the
+ *                               side stream (default 96; 0: all parked ones)
+ *   "qp_wave_blocks"    1..8192 grid of the wave-per-sample continuation launch (default 1024)
+ *   "qp_live"           0|1    1: the four-lane kernel hands parked samples to a consumer launch of the
+ *                               wave-per-sample kernel that is resident beside it on CUs of its own
+ *                               (bit-identical results; default 0: measured slower);
+ *                               "qp_live_blocks" 1..128 = CUs given to the consumers (default 48),
+ *                               "qp_live_occ" 2..4 = register budget of the four-lane kernel beside them
+ *   "proj_res_side"     0|1    1 (default): the residual projection of a one-iteration dictionary SPG
+ *                               (convergence flags only) runs on a side stream beside the weights QP
+ *   "outer_nosync"      0|1    measurement only (tools/interleave_probe.py): aa_outer_iterations called
+ *                               WITHOUT a cost buffer returns with its work in flight
  *   "fuse_finalize"     0|1    1 (default): fewer, fatter launches in the dictionary update (set-up
  *                               kernel, scalar stages inside the finalize kernels, two-launch line
  *                               search, x update inside the gradient kernel) */
