@@ -365,6 +365,28 @@ int aa_get_archetypes(aa_ctx *ctx, double *CX, long ld);
  * (form DATA) or the stored K (form KERNEL).  j is a GLOBAL row index. */
 int aa_distance_column(aa_ctx *ctx, long j, double *d);
 
+/* GPNH restarts side by side (the drivers' n_init loop, bin/run_jra55_pca_gpnh.py:112-138):
+ * R independent fits of k components each share one set of device arrays (R k <= 64) and every launch
+ * of an outer iteration -- restart r lives in component slots [r k, (r + 1) k).  Every restart gets
+ * the bits it gets from aa_gpnh_iterate on its own.
+ *   aa_gpnh_slots_begin   R empty slots; gp / qp as for aa_gpnh_iterate (both updates on)
+ *   aa_gpnh_slots_load    start factors of a restart into slot r (W': k x p, leading dimension ld;
+ *                         Z: n x k), its initial cost
+ *   aa_gpnh_slots_run     n_iters outer iterations of every slot; status[R] out.  A slot stops by its
+ *                         own stopping rule / monotonicity check / iteration cap; its factors of that
+ *                         iteration are kept while the others go on
+ *   aa_gpnh_slots_fetch   factors, cost record (2 (stop_iter + 1) values) and initial cost of a
+ *                         stopped slot; the slot can then be loaded again */
+typedef struct {
+    int stop, converged, error_stage, stop_iter;
+    int not_spd;            /* the slot's normal equations were not positive definite */
+    int iterations_run;     /* outer iterations this slot has been through since it was loaded */
+} aa_slot_status;
+int aa_gpnh_slots_begin(aa_ctx *ctx, int R, int k, const aa_gpnh_params *gp, const aa_qp_params *qp);
+int aa_gpnh_slots_load(aa_ctx *ctx, int r, const double *Wt, long ld, const double *Z);
+int aa_gpnh_slots_run(aa_ctx *ctx, int n_iters, aa_slot_status *status);
+int aa_gpnh_slots_fetch(aa_ctx *ctx, int r, double *Wt, long ld, double *Z, double *costs, double *cost0);
+
 /* ------------------------------------------------------------------ GPNH */
 /* Dictionary W (p x k) is passed transposed, Wt (k x p, leading dimension ld).
  * aa_gpnh_set_factors uploads Wt and/or Z (either may be NULL to keep the current

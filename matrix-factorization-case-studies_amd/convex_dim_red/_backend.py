@@ -78,6 +78,12 @@ class GPNHParams(ctypes.Structure):
     _fields_ = [("lambda_W", ctypes.c_double), ("loop", IterParams)]
 
 
+class SlotStatus(ctypes.Structure):
+    """aa_slot_status: one restart slot of aa_gpnh_slots_run."""
+    _fields_ = [("stop", ctypes.c_int), ("converged", ctypes.c_int), ("error_stage", ctypes.c_int),
+                ("stop_iter", ctypes.c_int), ("not_spd", ctypes.c_int), ("iterations_run", ctypes.c_int)]
+
+
 class QPStats(ctypes.Structure):
     _fields_ = [("total_passes", ctypes.c_long), ("max_passes", ctypes.c_int),
                 ("reserved", ctypes.c_int)]
@@ -133,6 +139,11 @@ _SIGNATURES = {
     "aa_gpnh_iterate": (ctypes.c_int, [_vp, ctypes.POINTER(GPNHParams), ctypes.POINTER(QPParams), _dp, _dp,
                                        ctypes.POINTER(IterStats)]),
     "aa_gpnh_get_dictionary": (ctypes.c_int, [_vp, _dp, ctypes.c_long]),
+    "aa_gpnh_slots_begin": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(GPNHParams),
+                                           ctypes.POINTER(QPParams)]),
+    "aa_gpnh_slots_load": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp]),
+    "aa_gpnh_slots_run": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(SlotStatus)]),
+    "aa_gpnh_slots_fetch": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp, _dp, _dp]),
     "aa_get_spg_scalars": (ctypes.c_int, [_vp, _dp]),
     "aa_pass_reduce_rows": (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, ctypes.c_long]),
     "aa_pass_row_local": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp]),
@@ -593,6 +604,41 @@ class Context(object):
         _check(self.lib.aa_gpnh_iterate(self.h, ctypes.byref(gp), ctypes.byref(qp), ctypes.byref(c0),
                                         _ptr(costs), ctypes.byref(st)))
         return c0.value, costs[:2 * (max(st.n_iter, -1) + 1)], st
+
+    # ---- GPNH restarts side by side (aa_gpnh_slots_*; restarts.fit_restarts drives them)
+    def gpnh_slots_begin(self, n_slots, k, lambda_W, max_outer, tolerance, stopping_criterion, require_monotonic,
+                         qp_kw, mono_tolerance=None):
+        crit = {"abs_delta_f": 0, "rel_delta_f": 1}.get(stopping_criterion)
+        if crit is None:
+            raise ValueError("unsupported stopping criterion '%s'" % stopping_criterion)
+        gp = GPNHParams(float(lambda_W), IterParams(
+            int(max_outer), float(tolerance), crit, int(bool(require_monotonic)),
+            float(tolerance if mono_tolerance is None else mono_tolerance), 1, 1, 8, 0.0))
+        qp = qp_params(**qp_kw)
+        _check(self.lib.aa_gpnh_slots_begin(self.h, int(n_slots), int(k), ctypes.byref(gp), ctypes.byref(qp)))
+        self.k = int(n_slots) * int(k)
+        self._slots = (int(n_slots), int(k), int(max_outer))
+
+    def gpnh_slots_load(self, r, W, Z):
+        """``W``: n_features x k (the reference's dictionary layout), ``Z``: n_samples x k."""
+        Wt = _c64(np.asarray(W).T)
+        Z = _c64(Z)
+        _check(self.lib.aa_gpnh_slots_load(self.h, int(r), _ptr(Wt), Wt.shape[1], _ptr(Z)))
+
+    def gpnh_slots_run(self, n_iters):
+        st = (SlotStatus * self._slots[0])()
+        _check(self.lib.aa_gpnh_slots_run(self.h, int(n_iters), st))
+        return list(st)
+
+    def gpnh_slots_fetch(self, r, stop_iter):
+        """(weights n x k, dictionary p x k, cost0, costs[2 (stop_iter + 1)]) of a stopped slot."""
+        _, k, _ = self._slots
+        Wt = np.empty((k, self.p))
+        Z = np.empty((self.n, k))
+        costs = np.zeros(2 * (int(stop_iter) + 1))
+        c0 = ctypes.c_double(0)
+        _check(self.lib.aa_gpnh_slots_fetch(self.h, int(r), _ptr(Wt), self.p, _ptr(Z), _ptr(costs), ctypes.byref(c0)))
+        return Z, Wt.T, c0.value, costs
 
     def gpnh_get_dictionary(self):
         """The reference's dictionary (p x k, returned like the reference returns it: the

@@ -306,7 +306,14 @@ class GPNHConvexCoding(object):
         n_samples, n_features = data.shape
         rng = self.random_state
         if init == 'random':                                   # reference :41-49
-            avg = np.sqrt(np.abs(data).mean() / self.n_components)
+            cache = kwargs.get('_cache')                       # restarts.fit_restarts: the same data every time
+            if cache is not None and 'abs_mean' in cache:
+                abs_mean = cache['abs_mean']
+            else:
+                abs_mean = np.abs(data).mean()
+                if cache is not None:
+                    cache['abs_mean'] = abs_mean
+            avg = np.sqrt(abs_mean / self.n_components)
             return avg * rng.randn(n_features, self.n_components)
         if init == 'furthest_sum':                             # reference :52-81
             start_index = kwargs.get('start_index', None)
@@ -358,6 +365,10 @@ class GPNHConvexCoding(object):
                              'positive; got (tolerance=%r)' % self.tolerance)
         k = self.n_components
         whom = '_gpnh_convex_coding'
+        if (kwargs.get('_draw_only', False) and not on_device and update_dictionary and update_weights
+                and self.init in (None, 'random')):
+            # restarts.fit_restarts: the start factors of a random start need no device
+            return self._initial_dictionary(None, data, kwargs), self._initial_weights(n_samples)
         # data resident across the drivers' n_init restarts (bin/run_jra55_pca_gpnh.py:123-136)
         distributed = _backend.distributed_env() is not None and not on_device   # see _backend.distributed_env
         with (data.borrow() if on_device else

@@ -23,29 +23,139 @@ from .gpnh_convex_coding import GPNHConvexCoding
 from .preprocessing import DeviceData
 
 
-def fit_restarts(make_model, data, n_init, n_jobs=4, devices=None):
+slots_profile = {}        # seconds spent loading / iterating / fetching in the last side-by-side run
+
+
+def _slots_eligible(models):
+    """GPNH restarts that can share one set of device arrays: same hyper-parameters, at least four
+    restarts of k components in the 64 component slots of the tall arrays."""
+    m0 = models[0]
+    if not all(isinstance(m, GPNHConvexCoding) for m in models) or len(models) < 2:
+        return False
+    keys = ("n_components", "lambda_W", "tolerance", "max_iterations", "stopping_criterion",
+            "require_monotonic_cost_decrease", "dtype", "weights_solver_kwargs", "dictionary_solver_kwargs")
+    if any(getattr(m, a) != getattr(m0, a) for m in models[1:] for a in keys):
+        return False
+    k = m0.n_components
+    return (isinstance(k, int) and 1 <= k <= 16 and not m0.dictionary_solver_kwargs and not m0.verbose
+            and m0.weights_solver_kwargs.get("memory", 1) <= 8
+            and m0.weights_solver_kwargs.get("max_iterations", 1000) >= 1
+            and _backend.distributed_env() is None)
+
+
+def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
+    """Up to 64 // k restarts side by side in ONE set of device arrays (aa_gpnh_slots_*): every outer
+    iteration's launches serve all of them, a restart that stops is taken out and the next pending
+    one takes its slot.  Restart by restart the result is the one the sequential loop gives, bit
+    for bit (each slot runs the single fit's arithmetic on its own columns).  Returns the indices
+    of restarts whose normal equations were not positive definite (the sequential path solves those
+    with lstsq like the reference)."""
+    import time
+    import warnings
+    m0 = models[0]
+    k = m0.n_components
+    n_slots = min((64 // k) if n_slots is None else int(n_slots), 64 // k, len(models))
+    n_samples = data.shape[0]
+    fallback, errors = [], {}
+    ctx = _backend.Context(dtype=m0.dtype, device=device)
+    try:
+        ctx.set_data(data)
+        mono_tol = m0.tolerance
+        if ctx.dtype_code == _backend.AA_F32:
+            mono_tol = max(m0.tolerance, 8 * 6e-8 * ctx.data_trace() / n_samples)
+        ctx.gpnh_slots_begin(n_slots, k, m0.lambda_W, m0.max_iterations, m0.tolerance, m0.stopping_criterion,
+                             m0.require_monotonic_cost_decrease, m0.weights_solver_kwargs, mono_tolerance=mono_tol)
+        pending = list(range(len(models)))
+        owner = [None] * n_slots
+        loaded_at = [0.0] * n_slots
+
+        prof = slots_profile
+        prof.update(load=0.0, run=0.0, fetch=0.0, polls=0, slots=n_slots)
+
+        def load(r):
+            i = pending.pop(0)
+            t0 = time.perf_counter()
+            ctx.gpnh_slots_load(r, starts[i]["dictionary"], starts[i]["weights"])
+            owner[r] = i
+            loaded_at[r] = time.perf_counter()
+            prof["load"] += loaded_at[r] - t0
+
+        for r in range(n_slots):
+            load(r)
+        while any(o is not None for o in owner):
+            t0 = time.perf_counter()
+            status = ctx.gpnh_slots_run(poll_every)
+            prof["run"] += time.perf_counter() - t0
+            prof["polls"] += 1
+            for r, st in enumerate(status):
+                i = owner[r]
+                if i is None:
+                    continue
+                if st.not_spd:
+                    fallback.append(i)
+                elif st.stop:
+                    m = models[i]
+                    if st.error_stage:
+                        errors[i] = RuntimeError('factorization cost increased after {} update'.format(
+                            'dictionary' if st.error_stage == 1 else 'weights'))
+                    else:
+                        t0 = time.perf_counter()
+                        Z, W, cost0, costs = ctx.gpnh_slots_fetch(r, st.stop_iter)
+                        prof["fetch"] += time.perf_counter() - t0
+                        finals = costs[1::2]
+                        begins = np.concatenate(([cost0], finals[:-1]))
+                        m.weights, m.dictionary = Z, W
+                        m.cost, m.n_iter = float(finals[-1]), int(st.stop_iter)
+                        m.cost_deltas = [float(d) for d in finals - begins]
+                        m.avg_time_per_iter = (time.perf_counter() - loaded_at[r]) / max(st.iterations_run, 1)
+                        if m.n_iter == m.max_iterations and m.tolerance > 0:
+                            warnings.warn('Maximum number of iterations %d reached.' % m.max_iterations, UserWarning)
+                else:
+                    continue
+                owner[r] = None
+                if pending:
+                    load(r)
+    finally:
+        ctx.close()
+    if errors:
+        raise errors[min(errors)]
+    return fallback
+
+
+def fit_restarts(make_model, data, n_init, n_jobs=4, devices=None, side_by_side=True, n_slots=None):
     """``make_model()`` returns a fresh ``ArchetypalAnalysis`` or ``GPNHConvexCoding`` (the drivers
     pass the shared ``RandomState`` as its ``random_state``, ``init`` 'random' or 'furthest_sum').
     ``devices``: GPU indices the worker threads are dealt over (default: the current one); the data
     matrix is uploaded ONCE per device and the workers of a device share that copy
     (``aa_share_data``), each with its own factors, streams and scratch.
+    ``side_by_side`` (GPNH models with the same hyper-parameters, k <= 16, one device): the restarts
+    run ``n_slots`` (default 64 // k) at a time in ONE set of device arrays and share every launch of
+    an outer iteration (``_fit_gpnh_slots``); ``n_jobs`` is not used then.
     Returns ``(models, best)``: the fitted models in restart order and the index of the first one
     with the lowest cost (the model the drivers' ``if cost < best_cost`` loop keeps)."""
     data = np.asarray(data)
     models, starts = [], []
+    cache = {}                                    # data-dependent constants of the initialisers
     for _ in range(n_init):                       # RNG draws in the sequential loop's order
         m = make_model()
         if isinstance(m, ArchetypalAnalysis):
             C0, Z0, a0 = m._aa(data, _draw_only=True)
             starts.append(dict(dictionary=C0, weights=Z0, alpha=a0))
         elif isinstance(m, GPNHConvexCoding):
-            W0, Z0 = m._gpnh_convex_coding(data, _draw_only=True)
+            W0, Z0 = m._gpnh_convex_coding(data, _draw_only=True, _cache=cache)
             starts.append(dict(dictionary=W0, weights=Z0))
         else:
             raise TypeError("fit_restarts handles ArchetypalAnalysis and GPNHConvexCoding models")
         models.append(m)
     _backend.release_device_cache()               # the workers bring their own contexts
     devices = [_backend.device_index()] if devices is None else [int(d) for d in devices]
+    todo = list(range(n_init))
+    if side_by_side and len(devices) == 1 and _slots_eligible(models):
+        # GPNH: the restarts share the launches of every outer iteration (aa_gpnh_slots_*)
+        todo = _fit_gpnh_slots(models, starts, data, devices[0], n_slots=n_slots)
+        if not todo:
+            costs = [m.cost for m in models]
+            return models, int(np.argmin(costs))
     local = threading.local()
     lock = threading.Lock()
     owners = {}                                   # device -> context that holds the data matrix
@@ -77,7 +187,8 @@ def fit_restarts(make_model, data, n_init, n_jobs=4, devices=None):
 
     try:
         with ThreadPoolExecutor(max_workers=max(1, int(n_jobs))) as pool:
-            costs = list(pool.map(run, range(n_init)))
+            list(pool.map(run, todo))
+        costs = [m.cost for m in models]
     finally:
         for ctx in sharers:                       # the aliases first, then the owners
             ctx.close()

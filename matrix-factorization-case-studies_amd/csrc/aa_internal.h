@@ -144,6 +144,11 @@ struct Ctx {
     hipStream_t stream3 = nullptr;             // the live consumers of parked QP samples (qp_live): a queue of
                                                // their own, stream2 may still hold the residual projection
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    // GPNH restarts side by side (aa_gpnh_slots_*): per-slot cost records, counters, status, initial costs
+    DevBuf slotCosts, slotCounters, slotStates, slotCost0;
+    int slots_R = 0, slots_k = 0, slots_stride = 0, slots_max_outer = 0;
+    aa_gpnh_params slots_gp;
+    aa_qp_params slots_qp;
     DevBuf qpLive;                             // ready[cap] | done[cap] flags of the live hand-over (QpLive)
     long qp_live_cap = 0;
     int qp_live_epoch = 0;
@@ -277,6 +282,11 @@ int launch_gather_weight(Ctx *c, const void *raw_dev, int host_dtype, long ld, l
                          const int *idx_dev, long p_valid, const double *w_dev);
 int launch_data_to_double(Ctx *c, double *out_dev);
 int launch_gpnh_solve(Ctx *c, double lambda, int *ok_dev);
+// R restarts side by side (kernels_tall.hip: GpnhSlots)
+int launch_gpnh_solve_slots(Ctx *c, double lambda);
+int launch_gpnh_cost_slots(Ctx *c, double lambda, unsigned mask, int what, const aa_iter_params *ip, bool form_gram);
+int launch_gpnh_snap_slots(Ctx *c);
+int launch_qp_slots(Ctx *c, int R, int k, const double *gram_dev, const aa_qp_params *p);   // kernels_qp.hip
 bool gpnh_cost_can_gram(const Ctx *c);
 int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter, bool from_wide = false,
                      bool gram_w = false, const GpnhJudge *judge = nullptr);

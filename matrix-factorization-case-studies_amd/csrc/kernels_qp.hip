@@ -407,8 +407,19 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
                                            QpHeader *__restrict__ hdr,
                                            int *__restrict__ ovf_rows, QpCarry *__restrict__ ovf,
                                            int g_refill, QpDebug *__restrict__ dbg,
-                                           const int *__restrict__ perm)
+                                           const int *__restrict__ perm, int rst_a = 0, int rst_b = 0,
+                                           int rst_z = 0)
 {
+    // restarts side by side (launch_qp_slots): blockIdx.y = slot; its Hessian, its columns of B and
+    // Z, its own header (sample queue, statistics) and pass counts
+    if (gridDim.y > 1) {
+        const int rst = blockIdx.y;
+        A += (long)rst * rst_a;
+        B += (long)rst * rst_b;
+        Z += (long)rst * rst_z;
+        hdr += rst;
+        if (iters) iters += (long)rst * n;
+    }
     constexpr bool SG = SGMV && KQ >= 16;              // mat-vec through the scalar unit
     constexpr bool MFMA = KQ >= 16 && !SG;
     constexpr int VS = MFMA ? QP_VS : 64;              // row stride of the direction buffer
@@ -2206,6 +2217,68 @@ static int qp_order_rows(Ctx *c, const int *iters_dev, long n, const int **perm_
     hipLaunchKernelGGL(k_qp_order_scatter, dim3(nblk), dim3(256), 0, c->stream, iters_dev, n,
                        (const int *)ghist, gcursor, pm, hdr, long_from);
     *perm_out = pm;
+    return AA_OK;
+}
+
+// R QPs per sample, one per restart slot (GPNH restarts side by side, kernels_tall.hip: GpnhSlots):
+// Hessian of slot r = diagonal block r of the KP x KP Gram, b and z = its k columns of the tall
+// arrays.  One set-up launch and ONE launch of the lane-per-sample kernel for all slots
+// (grid.y = R), every sample run to completion there (no pass cap: the drivers' setting is a single
+// SPG iteration per update, where this kernel is what the single fit uses too).
+__global__ __launch_bounds__(256) void k_qp_setup_slots(QpHeader *__restrict__ hdr, double *__restrict__ Ad,
+                                                        const double *__restrict__ gram, int k, int KQ, int KP)
+{
+    const int t = threadIdx.x, r = blockIdx.x, o = r * k;
+    if (t == 0) {
+        QpHeader *h = hdr + r;
+        h->total_passes = 0ull;
+        h->max_passes = 0ull;
+        h->next_row = 0u;
+        h->n_overflow = 0u;
+        h->next_overflow = 0u;
+        h->n_long = 0u;
+        h->dbg_rounds = h->dbg_trips = h->dbg_waves = 0u;
+        h->pad = 0u;
+        h->waves_done = 0u;
+    }
+    double *A = Ad + (size_t)r * KQ * KQ;
+    for (int e = t; e < KQ * KQ; e += 256) {
+        const int i = e / KQ, j = e % KQ;
+        A[e] = (i < k && j < k) ? 1.0 * gram[(o + i) * KP + o + j] * 1.0 : 0.0;
+    }
+}
+
+int launch_qp_slots(Ctx *c, int R, int k, const double *gram_dev, const aa_qp_params *p)
+{
+    int KQ = 4;
+    while (KQ < k) KQ *= 2;
+    AA_REQUIRE(KQ <= 32 && R >= 1 && R * k <= c->KP, AA_ERR_ARG, "QP slots: k = %d, R = %d unsupported", k, R);
+    AA_REQUIRE(p->memory <= QP_MAXMEM, AA_ERR_ARG, "QP slots: memory = %d > %d", p->memory, QP_MAXMEM);
+    const long n = c->n;
+    const size_t off_A = 64 * (size_t)R;                       // R headers of 64 bytes
+    const size_t bytes = off_A + (size_t)R * KQ * KQ * sizeof(double);
+    AA_CHECK(c->qpStats.alloc(bytes < 4096 ? 4096 : bytes));
+    unsigned char *base = reinterpret_cast<unsigned char *>(c->qpStats.p);
+    QpHeader *hdr = reinterpret_cast<QpHeader *>(base);
+    double *Ad = reinterpret_cast<double *>(base + off_A);
+    static_assert(sizeof(QpHeader) == 64, "one header per 64 bytes");
+    hipLaunchKernelGGL(k_qp_setup_slots, dim3((unsigned)R), dim3(256), 0, c->stream, hdr, Ad, gram_dev, k, KQ, c->KP);
+    long waves = (n + 63) / 64;
+    if (waves > g_qp_waves) waves = g_qp_waves;
+    const dim3 grid((unsigned)waves, (unsigned)R);
+    const int cap = p->max_iterations;
+    double *Zt = c->Zt.as<double>();
+    const double *Bt = c->Gr.as<double>();
+#define QPS(KQV, FULLV)                                                                                  \
+    hipLaunchKernelGGL((k_qp<KQV, FULLV, false, false>), grid, dim3(64), 0, c->stream, (const double *)Ad, Bt, \
+                       (long)1, (long)c->KP, (const double *)nullptr, Zt, c->KP, n, k, *p, cap, (int *)nullptr,  \
+                       hdr, (int *)nullptr, (QpCarry *)nullptr, g_qp_refill_min, (QpDebug *)nullptr,              \
+                       (const int *)nullptr, KQV * KQV, k, k)
+#define QPSK(KQV) do { if (k == KQV) QPS(KQV, true); else QPS(KQV, false); } while (0)
+    switch (KQ) { case 4: QPSK(4); break; case 8: QPSK(8); break; case 16: QPSK(16); break; default: QPSK(32); break; }
+#undef QPSK
+#undef QPS
+    AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
 

@@ -2551,6 +2551,237 @@ __global__ __launch_bounds__(256) void k_copy2(const IterState *__restrict__ st,
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long)gridDim.x * 256) sb[i] = b[i];
 }
 
+// ---------------------------------------------------------------- GPNH, R restarts side by side
+// (SURVEY 8(f1)).  The drivers fit the same matrix n_init times (bin/run_jra55_pca_gpnh.py:112-138);
+// one GPNH iteration on the C3 shape is 11 dependent launches of a few microseconds, which several
+// streams do not overlap.  The tall and wide arrays have KP = 32 component
+// slots of which a k = 10 fit uses ten, so R = floor(KP / k) restarts sit SIDE BY SIDE in one set
+// of arrays: Z (n x KP) holds restart r in columns [r k, (r + 1) k), W' (KP x p) in the same rows.
+// The passes over X (X W, Z'X), Z'Z and W'W are the kernels of the single fit, unchanged -- an
+// output element of theirs depends on its own column / row only, so every restart gets the bits
+// it gets alone -- and the steps that couple components (the k x k solve, the cost, the QP, the
+// judge, the snapshot) read the diagonal blocks only, restart by restart, with the arithmetic of
+// the single-fit kernels.  Every slot has its own cost record, slot counter and status record, and
+// takes its iteration index from its slot counter: slots start and stop independently (a stopped
+// slot keeps iterating until the host replaces it; its factors were saved at the stopping
+// iteration).
+struct GpnhSlots {
+    int R, k;
+    double *costs;        // [R][stride]
+    int stride;
+    int *counters;        // [R]
+    IterState *st;        // [R]
+    double *cost0;        // [R]
+    int max_outer;
+};
+
+template <int KM>
+__global__ __launch_bounds__(256) void k_gpnh_solve_slots(const double *__restrict__ ZtZ /*[KP][KP]*/,
+                                                          const double *__restrict__ ZtX /*[KP][ld]*/,
+                                                          int ld, int p, int KP, double n_samples,
+                                                          double lambda, double *__restrict__ Wt,
+                                                          float *__restrict__ WtF, GpnhSlots sl)
+{
+    extern __shared__ double L[];                 // k x k, row-major, lower triangle
+    __shared__ double dmax_s;
+    __shared__ int bad;
+    const int t = threadIdx.x, k = sl.k;
+    const double pref = k > 1 ? 4.0 / ((double)p * k * (k - 1)) : 0.0;
+    const int c = blockIdx.x * 256 + t;
+    {
+        const int r = blockIdx.y;                     // one slot per block row
+        const int o = r * k;
+        for (int e = t; e < k * k; e += 256) {
+            const int i = e / k, j = e % k;
+            L[e] = ZtZ[(o + i) * KP + o + j] / n_samples + lambda * pref * ((i == j ? (double)k : 0.0) - 1.0);
+        }
+        if (t == 0) bad = 0;
+        __syncthreads();
+        if (t == 0) {
+            double m = 0.0;
+            for (int i = 0; i < k; ++i) m = fmax(m, fabs(L[i * k + i]));
+            dmax_s = m;
+        }
+        __syncthreads();
+        for (int j = 0; j < k; ++j) {                 // right-looking Cholesky
+            if (t == 0) {
+                const double d = L[j * k + j];
+                if (!(d > 1e-13 * dmax_s)) bad = 1;
+                L[j * k + j] = sqrt(d > 0.0 ? d : 1.0);
+            }
+            __syncthreads();
+            const double piv = L[j * k + j];
+            for (int i = j + 1 + t; i < k; i += 256) L[i * k + j] /= piv;
+            __syncthreads();
+            for (int e = t; e < (k - j - 1) * (k - j - 1); e += 256) {
+                const int i = j + 1 + e / (k - j - 1), q = j + 1 + e % (k - j - 1);
+                if (q <= i) L[i * k + q] -= L[i * k + j] * L[q * k + j];
+            }
+            __syncthreads();
+        }
+        if (bad) {                                    // this slot only: its dictionary stays as it is
+            if (t == 0 && blockIdx.x == 0) sl.st[r].pad0 = 1;
+            return;
+        }
+        if (c >= ld) return;
+        double y[KM];
+#pragma unroll
+        for (int i = 0; i < KM; ++i) {                // L y = b
+            if (i < k) {
+                double v = c < p ? ZtX[(long)(o + i) * ld + c] / n_samples : 0.0;
+#pragma unroll
+                for (int q = 0; q < i; ++q) v -= L[i * k + q] * y[q];
+                y[i] = v / L[i * k + i];
+            } else {
+                y[i] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = KM - 1; i >= 0; --i) {           // L' w = y
+            if (i < k) {
+                double v = y[i];
+#pragma unroll
+                for (int q = i + 1; q < KM; ++q)
+                    if (q < k) v -= L[q * k + i] * y[q];
+                y[i] = v / L[i * k + i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KM; ++i) {
+            if (i < k) {
+                Wt[(long)(o + i) * ld + c] = y[i];
+                if (WtF) WtF[(long)(o + i) * ld + c] = (float)y[i];
+            }
+        }
+    }
+    // (component slots beyond R k are zero since aa_gpnh_slots_begin and are never written)
+}
+
+// cost of every slot in `mask` (k_gpnh_cost's arithmetic on the slot's diagonal blocks and rows):
+//   what = 0: initial cost of a freshly loaded slot -> cost0[r]
+//   what = 1: cost after the dictionary update -> the slot's record
+//   what = 2: cost after the weights update -> the record, then the slot's judge
+// form_gram: W'W of the slot is formed here first (what the single fit does after a dictionary update
+// when the factor is small enough, gpnh_cost_can_gram; otherwise, and for the initial cost, the wide
+// Gram kernel has left it in WtW)
+__global__ __launch_bounds__(256) void k_gpnh_cost_slots(const double *__restrict__ ZtZ, double *WtW,
+                                                         int KP, int p, double trace, double n_samples,
+                                                         double lambda, const double *__restrict__ ZtX,
+                                                         const double *__restrict__ Wt, int ld, GpnhSlots sl,
+                                                         unsigned mask, int what, double tol, double mono_tol,
+                                                         int criterion, int require, int form_gram)
+{
+    __shared__ double sm[256], sm2[256], sm3[256];
+    __shared__ double wl[4096 + 64];
+    const int t = threadIdx.x, k = sl.k;
+    {
+        const int r = blockIdx.x;                     // one slot per block
+        if (!((mask >> r) & 1u)) return;
+        const int o = r * k;
+        const double *Wr = Wt + (long)o * ld, *Xr = ZtX + (long)o * ld;
+        if (form_gram) {
+            // W'W of this slot (k x k), k_gpnh_cost's in-kernel Gram: W' through LDS, `parts` threads
+            // per output, combined in a fixed order
+            for (int e = t; e < k * ld; e += 256) wl[(e / ld) * (ld + 1) + e % ld] = Wr[e];
+            __syncthreads();
+            const int kk = k * k, parts = 256 / kk >= 4 ? 4 : (256 / kk >= 2 ? 2 : 1);
+            const int span = ld / parts;
+            double a4[4] = {0.0, 0.0, 0.0, 0.0};
+            if (t < kk * parts) {
+                const int e = t % kk, part = t / kk;
+                const double *wi = wl + (e / k) * (ld + 1) + part * span, *wj = wl + (e % k) * (ld + 1) + part * span;
+                for (int cc = 0; cc < span; cc += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a4[u] = fma(wi[cc + u], wj[cc + u], a4[u]);
+                }
+            }
+            sm[t] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+            __syncthreads();
+            for (int e = t; e < k * k; e += 256) {
+                const int i = e / k, j = e % k;
+                double v = 0.0;
+                for (int q = 0; q < parts; ++q) v += sm[q * kk + i * k + j];
+                WtW[(o + i) * KP + o + j] = v;
+            }
+            __syncthreads();
+        }
+        double cross;
+        {
+            double c4[4] = {0.0, 0.0, 0.0, 0.0};            // four chains, fixed order
+            const long total = (long)k * ld;                // padding columns are zero in both
+            long e = t;
+            for (; e + 3 * 256 < total; e += 4 * 256) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) c4[u] = fma(Xr[e + u * 256], Wr[e + u * 256], c4[u]);
+            }
+            for (; e < total; e += 256) c4[0] = fma(Xr[e], Wr[e], c4[0]);
+            cross = (c4[0] + c4[1]) + (c4[2] + c4[3]);
+        }
+        sm3[t] = cross;
+        double quad = 0.0, pen = 0.0;
+        for (int e = t; e < k * k; e += 256) {
+            const int i = e / k, j = e % k;
+            quad += ZtZ[(o + i) * KP + o + j] * WtW[(o + j) * KP + o + i];
+            if (j > i) pen += WtW[(o + i) * KP + o + i] + WtW[(o + j) * KP + o + j] - 2.0 * WtW[(o + i) * KP + o + j];
+        }
+        sm[t] = quad;
+        sm2[t] = pen;
+        __syncthreads();
+        for (int q = 128; q > 0; q >>= 1) {
+            if (t < q) {
+                sm[t] += sm[t + q];
+                sm2[t] += sm2[t + q];
+                sm3[t] += sm3[t + q];
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            double penalty = 0.0;
+            if (lambda != 0.0 && k > 1) penalty = lambda * (2.0 / ((double)k * p * (k - 1.0))) * sm2[0];
+            const double cost = 0.5 * (trace - 2.0 * sm3[0] + sm[0]) / n_samples + penalty;
+            if (what == 0) {
+                sl.cost0[r] = cost;
+            } else {
+                double *rec = sl.costs + (size_t)r * sl.stride;
+                int idx = sl.counters[r];
+                if (idx >= sl.stride) idx = sl.stride - 1;        // a finished slot waiting to be replaced
+                rec[idx] = cost;
+                sl.counters[r] = idx + 1;
+                if (what == 2) {
+                    const int it = idx / 2;
+                    iter_judge_thread0(it, sl.cost0[r], rec, &sl.st[r], tol, mono_tol, criterion, require, 1, 1,
+                                       nullptr, 0);
+                    // the iteration cap ends a slot like the stopping rule does (not converged)
+                    if (!sl.st[r].stop && it + 1 >= sl.max_outer) {
+                        sl.st[r].stop = 1;
+                        sl.st[r].stop_iter = it;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// the factors of every slot that has just stopped (status written by the judge above, in this
+// iteration): its columns of Z and its rows of W' into the snapshot arrays
+__global__ __launch_bounds__(256) void k_gpnh_snap_slots(const double *__restrict__ Zt, double *__restrict__ snapZ,
+                                                         long n_pad, int KP, const double *__restrict__ Wt,
+                                                         double *__restrict__ snapW, int ld, GpnhSlots sl)
+{
+    for (int r = 0; r < sl.R; ++r) {
+        const IterState st = sl.st[r];
+        const int it = sl.counters[r] / 2 - 1;
+        if (!st.stop || st.stop_iter != it) continue;    // (a full record stops counting at an index no stop has)
+        const int o = r * sl.k, k = sl.k;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n_pad * k; e += (long)gridDim.x * 256) {
+            const long row = e / k;
+            const int i = o + (int)(e % k);
+            snapZ[row * KP + i] = Zt[row * KP + i];
+        }
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)k * ld; e += (long)gridDim.x * 256)
+            snapW[(long)o * ld + e] = Wt[(long)o * ld + e];
+    }
+}
 int launch_gpnh_solve(Ctx *c, double lambda, int *ok_dev)
 {
     const size_t lds = (size_t)c->k * c->k * sizeof(double);
@@ -2599,6 +2830,58 @@ int launch_gpnh_judge(Ctx *c, int it, double cost0, const double *costs, IterSta
     hipLaunchKernelGGL(k_copy2, dim3(256), dim3(256), 0, c->stream, (const IterState *)st, it,
                        (const double *)c->Zt.as<double>(), c->snapZ.as<double>(), (long)c->n_pad * c->KP,
                        (const double *)c->P.as<double>(), c->snapC.as<double>(), (long)c->KP * c->p_pad);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+// ---- launchers of the slot kernels (solver.hip: aa_gpnh_slots_*)
+static GpnhSlots slots_of(Ctx *c)
+{
+    GpnhSlots sl;
+    sl.R = c->slots_R;
+    sl.k = c->slots_k;
+    sl.costs = c->slotCosts.as<double>();
+    sl.stride = c->slots_stride;
+    sl.counters = c->slotCounters.as<int>();
+    sl.st = c->slotStates.as<IterState>();
+    sl.cost0 = c->slotCost0.as<double>();
+    sl.max_outer = c->slots_max_outer;
+    return sl;
+}
+
+int launch_gpnh_solve_slots(Ctx *c, double lambda)
+{
+    const size_t lds = (size_t)c->slots_k * c->slots_k * sizeof(double);
+    const GpnhSlots sl = slots_of(c);
+#define GPS(KMV)                                                                                        \
+    hipLaunchKernelGGL(k_gpnh_solve_slots<KMV>, dim3((unsigned)((c->p_pad + 255) / 256), (unsigned)sl.R), dim3(256), lds, c->stream, \
+                       (const double *)c->gramState.as<double>(), (const double *)c->ZtX.as<double>(),      \
+                       (int)c->p_pad, (int)c->p, c->KP, (double)c->n_global, lambda, c->P.as<double>(),      \
+                       c->dtype == AA_F32 ? c->Pw.as<float>() : (float *)nullptr, sl)
+    if (c->slots_k <= 16) GPS(16);
+    else GPS(32);
+#undef GPS
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_gpnh_cost_slots(Ctx *c, double lambda, unsigned mask, int what, const aa_iter_params *ip, bool form_gram)
+{
+    double *gs = c->gramState.as<double>();
+    hipLaunchKernelGGL(k_gpnh_cost_slots, dim3((unsigned)c->slots_R), dim3(256), 0, c->stream, (const double *)gs,
+                       gs + (size_t)c->KP * c->KP, c->KP, (int)c->p, c->trace, (double)c->n_global, lambda,
+                       (const double *)c->ZtX.as<double>(), (const double *)c->P.as<double>(), (int)c->p_pad,
+                       slots_of(c), mask, what, ip ? ip->tolerance : 0.0, ip ? ip->mono_tolerance : 0.0,
+                       ip ? ip->criterion : 0, ip ? ip->require_monotonic : 0, form_gram ? 1 : 0);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_gpnh_snap_slots(Ctx *c)
+{
+    hipLaunchKernelGGL(k_gpnh_snap_slots, dim3(256), dim3(256), 0, c->stream, (const double *)c->Zt.as<double>(),
+                       c->snapZ.as<double>(), c->n_pad, c->KP, (const double *)c->P.as<double>(),
+                       c->snapC.as<double>(), (int)c->p_pad, slots_of(c));
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }

@@ -603,7 +603,7 @@ int aa_ctx_destroy(aa_ctx *h)
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->rlPartial, &c->redPartial,
                      &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->iterState, &c->snapC, &c->snapZ, &c->snapAlpha, &c->qpIters, &c->qpPerm,
-                     &c->qpStats, &c->qpLive, &c->tmpTall2, &c->redPartial2, &c->redOut2, &c->proj2, &c->projList2, &c->projSegCnt2};
+                     &c->qpStats, &c->qpLive, &c->slotCosts, &c->slotCounters, &c->slotStates, &c->slotCost0, &c->tmpTall2, &c->redPartial2, &c->redOut2, &c->proj2, &c->projList2, &c->projSegCnt2};
     for (DevBuf *b : all) b->release();
     if (c->evFork2) (void)hipEventDestroy(c->evFork2);
     if (c->evJoin2) (void)hipEventDestroy(c->evJoin2);
@@ -1409,6 +1409,155 @@ int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp,
         c->qp_iters_valid = false;
         AA_CHECK_HIP(hipStreamSynchronize(c->stream));
     }
+    return AA_OK;
+}
+
+// ------------------------------------------------------------------ GPNH restarts side by side
+// (kernels_tall.hip: GpnhSlots; convex_dim_red/restarts.py drives it).  begin: R empty slots of k
+// components each in one set of arrays; load: a restart's start factors into a slot, its initial
+// cost; run: outer iterations for all slots, status of every slot back; fetch: factors and cost
+// record of a slot that has stopped.  Single rank.
+int aa_gpnh_slots_begin(aa_ctx *h, int R, int k, const aa_gpnh_params *gp, const aa_qp_params *qp)
+{
+    AA_REQUIRE(h && gp && qp, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->have_data && c->form == AA_FORM_DATA, AA_ERR_STATE, "GPNH needs a data matrix");
+    AA_REQUIRE(c->world <= 1 && !c->force_comm, AA_ERR_STATE, "restart slots are single-rank");
+    AA_REQUIRE(R >= 1 && k >= 1 && k <= 32 && R * k <= AA_MAX_K && R <= 32, AA_ERR_ARG,
+               "slots: R = %d restarts of k = %d components do not fit", R, k);
+    const aa_iter_params *ip = &gp->loop;
+    AA_REQUIRE(ip->max_outer >= 1 && ip->update_dictionary && ip->update_weights, AA_ERR_ARG,
+               "slots: both updates, max_outer >= 1");
+    AA_REQUIRE(ip->criterion == 0 || ip->criterion == 1, AA_ERR_ARG, "bad stopping criterion");
+    AA_REQUIRE(qp->max_iterations >= 1 && qp->memory <= 8, AA_ERR_ARG, "slots: QP max_iterations >= 1, memory <= 8");
+    c->k = 0;                                         // force fresh, zeroed factor arrays
+    AA_CHECK(ensure_problem(c, R * k));
+    AA_CHECK(ensure_trace(c));
+    for (int i = 0; i < c->k; ++i) c->alpha[i] = 1.0;
+    AA_CHECK(upload_alpha(c));
+    c->slots_R = R;
+    c->slots_k = k;
+    c->slots_max_outer = ip->max_outer;
+    c->slots_stride = 2 * ip->max_outer + 64;
+    c->slots_gp = *gp;
+    c->slots_qp = *qp;
+    AA_CHECK(c->slotCosts.alloc((size_t)R * c->slots_stride * sizeof(double)));
+    AA_CHECK(c->slotCounters.alloc(64 * sizeof(int)));
+    AA_CHECK(c->slotStates.alloc(32 * sizeof(IterState)));
+    AA_CHECK(c->slotCost0.alloc(32 * sizeof(double)));
+    size_t snap_bytes = (size_t)c->n_pad * c->KP * sizeof(double);
+    if ((size_t)c->KP * c->p_pad * sizeof(double) > snap_bytes) snap_bytes = (size_t)c->KP * c->p_pad * sizeof(double);
+    AA_CHECK(c->snapC.alloc(snap_bytes));
+    AA_CHECK(c->snapZ.alloc(snap_bytes));
+    std::vector<IterState> st(32);
+    memset(st.data(), 0, st.size() * sizeof(IterState));
+    for (int r = 0; r < 32; ++r) st[r].stop = 1;      // empty: the judge leaves it alone
+    AA_CHECK_HIP(hipMemcpy(c->slotStates.p, st.data(), st.size() * sizeof(IterState), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(hipMemset(c->slotCounters.p, 0, 64 * sizeof(int)));
+    AA_CHECK_HIP(hipMemset(c->Zt.p, 0, (size_t)c->n_pad * c->KP * sizeof(double)));
+    AA_CHECK_HIP(hipMemset(c->P.p, 0, (size_t)c->KP * c->p_pad * sizeof(double)));
+    AA_CHECK_HIP(hipMemset(c->gramState.p, 0, (size_t)3 * c->KP * c->KP * sizeof(double)));
+    c->gpnh_valid = true;
+    c->have_state = true;
+    c->grams_valid = false;
+    c->ckz_valid = false;
+    c->host_grams_valid = false;
+    c->qp_iters_valid = false;
+    return AA_OK;
+}
+
+int aa_gpnh_slots_load(aa_ctx *h, int r, const double *Wt, long ld, const double *Z)
+{
+    AA_REQUIRE(h && Wt && Z, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->slots_R > 0 && r >= 0 && r < c->slots_R, AA_ERR_ARG, "slot %d out of range", r);
+    AA_REQUIRE(ld >= c->p, AA_ERR_ARG, "ld < p");
+    const int k = c->slots_k, o = r * k;
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    AA_CHECK_HIP(hipMemcpy2D(c->P.as<double>() + (size_t)o * c->p_pad, (size_t)c->p_pad * sizeof(double), Wt,
+                             (size_t)ld * sizeof(double), (size_t)c->p * sizeof(double), (size_t)k,
+                             hipMemcpyHostToDevice));
+    AA_CHECK_HIP(hipMemcpy2D(c->Zt.as<double>() + o, (size_t)c->KP * sizeof(double), Z, (size_t)k * sizeof(double),
+                             (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyHostToDevice));
+    IterState zero;
+    memset(&zero, 0, sizeof(zero));
+    AA_CHECK_HIP(hipMemcpy(c->slotStates.as<IterState>() + r, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(hipMemset(c->slotCounters.as<int>() + r, 0, sizeof(int)));
+    // the products of the stacked factors (the other slots' parts come out as they were) and this
+    // slot's initial cost, the way aa_gpnh_iterate forms it
+    AA_CHECK(launch_wide_to_T(c, c->P.as<double>(), operandT(c, c->P, c->Pw)));
+    AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));          // X W
+    AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
+    AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), dev_CKCt(c)));
+    AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), nullptr));
+    AA_CHECK(launch_gpnh_cost_slots(c, c->slots_gp.lambda_W, 1u << r, 0, nullptr, false));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return AA_OK;
+}
+
+int aa_gpnh_slots_run(aa_ctx *h, int n_iters, aa_slot_status *status)
+{
+    AA_REQUIRE(h && status && n_iters >= 1, AA_ERR_ARG, "bad argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->slots_R > 0, AA_ERR_STATE, "aa_gpnh_slots_begin first");
+    const int R = c->slots_R, k = c->slots_k;
+    const double lambda = c->slots_gp.lambda_W;
+    const aa_iter_params *ip = &c->slots_gp.loop;
+    const unsigned all = R >= 32 ? 0xffffffffu : ((1u << R) - 1u);
+    // the single fit forms W'W inside its cost kernel when the factor is small (gpnh_cost_can_gram
+    // with ITS k); the slots follow the same rule so that every restart sees the same bits
+    const bool gram_in_cost = k * k <= 256 && (long)k * c->p_pad <= 4096;
+    for (int it = 0; it < n_iters; ++it) {
+        AA_CHECK(launch_gpnh_solve_slots(c, lambda));                                      // W'
+        AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));       // X W
+        if (!gram_in_cost) AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), dev_CKCt(c)));
+        AA_CHECK(launch_gpnh_cost_slots(c, lambda, all, 1, ip, gram_in_cost));
+        AA_CHECK(launch_qp_slots(c, R, k, dev_CKCt(c), &c->slots_qp));
+        AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
+        AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), nullptr));
+        AA_CHECK(launch_gpnh_cost_slots(c, lambda, all, 2, ip, false));
+        AA_CHECK(launch_gpnh_snap_slots(c));
+    }
+    std::vector<IterState> st(R);
+    std::vector<int> cnt(R);
+    AA_CHECK_HIP(hipMemcpyAsync(st.data(), c->slotStates.p, (size_t)R * sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipMemcpyAsync(cnt.data(), c->slotCounters.p, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < R; ++r) {
+        status[r].stop = st[r].stop;
+        status[r].converged = st[r].converged;
+        status[r].error_stage = st[r].error_stage;
+        status[r].stop_iter = st[r].stop_iter;
+        status[r].not_spd = st[r].pad0;
+        status[r].iterations_run = cnt[r] / 2;
+    }
+    return AA_OK;
+}
+
+int aa_gpnh_slots_fetch(aa_ctx *h, int r, double *Wt, long ld, double *Z, double *costs, double *cost0)
+{
+    AA_REQUIRE(h && Wt && Z && costs && cost0, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->slots_R > 0 && r >= 0 && r < c->slots_R, AA_ERR_ARG, "slot %d out of range", r);
+    AA_REQUIRE(ld >= c->p, AA_ERR_ARG, "ld < p");
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    IterState st;
+    AA_CHECK_HIP(hipMemcpy(&st, c->slotStates.as<IterState>() + r, sizeof(st), hipMemcpyDeviceToHost));
+    AA_REQUIRE(st.stop, AA_ERR_STATE, "slot %d has not stopped", r);
+    const int k = c->slots_k, o = r * k;
+    // the factors of the stopping iteration (k_gpnh_snap_slots)
+    AA_CHECK_HIP(hipMemcpy2D(Wt, (size_t)ld * sizeof(double), c->snapC.as<double>() + (size_t)o * c->p_pad,
+                             (size_t)c->p_pad * sizeof(double), (size_t)c->p * sizeof(double), (size_t)k,
+                             hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(hipMemcpy2D(Z, (size_t)k * sizeof(double), c->snapZ.as<double>() + o, (size_t)c->KP * sizeof(double),
+                             (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(hipMemcpy(costs, c->slotCosts.as<double>() + (size_t)r * c->slots_stride,
+                           (size_t)2 * (st.stop_iter + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(hipMemcpy(cost0, c->slotCost0.as<double>() + r, sizeof(double), hipMemcpyDeviceToHost));
     return AA_OK;
 }
 

@@ -597,6 +597,50 @@ def test_two_ranks_match_one_rank(cdr):
     assert "MULTI_RANK_ESTIMATORS_OK world=2" in out.stdout, out.stdout[-3000:]
 
 
+@pytest.mark.parametrize("case", ["stopping_rule", "iteration_cap", "float32", "three_slots"])
+def test_gpnh_restarts_side_by_side(cdr, orc, case):
+    """fit_restarts on GPNH models (bin/run_jra55_pca_gpnh.py:112-138): the restarts sit
+    side by side in the component slots of ONE set of device arrays and share every launch of an
+    outer iteration (aa_gpnh_slots_*); a restart that stops hands its slot to the next pending one.
+    Restart by restart -- cost, n_iter, cost deltas, weights, dictionary -- the result is the
+    sequential loop's, bit for bit (every slot runs the single fit's arithmetic on its own columns),
+    and the sequential fits are pinned to the oracle elsewhere in this file."""
+    import warnings
+    from convex_dim_red import restarts
+    rng = np.random.RandomState(12)
+    n, p = 3000, 40
+    k = 10 if case == "three_slots" else 4
+    W0 = rng.standard_normal((p, k))
+    Zt = orc.right_stochastic_matrix((n, k), rng)
+    X = Zt.dot(W0.T) + 0.1 * rng.standard_normal((n, p))
+    dtype = "float32" if case == "float32" else "float64"
+    if dtype == "float32":
+        X = X.astype(np.float32)
+    kw = dict(lambda_W=0.5, init="random", tolerance=1e-5, max_iterations=400, stopping_criterion="rel_delta_f",
+              dtype=dtype, weights_solver_kwargs=dict(max_iterations=1))
+    if case == "iteration_cap":
+        kw.update(tolerance=0, max_iterations=13, require_monotonic_cost_decrease=False)
+    n_init = 9
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        shared = np.random.RandomState(3)
+        seq = []
+        for _ in range(n_init):
+            m = cdr.GPNHConvexCoding(k, random_state=shared, **kw)
+            m.fit_transform(X)
+            seq.append(m)
+        shared = np.random.RandomState(3)
+        models, best = cdr.fit_restarts(lambda: cdr.GPNHConvexCoding(k, random_state=shared, **kw), X, n_init,
+                                        n_slots=3 if case == "three_slots" else None)
+    assert restarts.slots_profile["slots"] == (3 if case == "three_slots" else n_init)   # the slots path ran
+    assert len({m.n_iter for m in seq}) > 1 or case == "iteration_cap"                   # slots stop at different times
+    for a, b in zip(seq, models):
+        assert a.cost == b.cost and a.n_iter == b.n_iter
+        assert list(a.cost_deltas) == list(b.cost_deltas)
+        assert np.array_equal(a.weights, b.weights) and np.array_equal(a.dictionary, b.dictionary)
+    assert best == int(np.argmin([m.cost for m in seq]))
+
+
 def test_fit_restarts_over_two_devices(cdr, orc):
     """fit_restarts(devices=[0, 1]): the workers are dealt over two GPUs, one resident copy of the
     data per device; restart by restart the same costs and factors as on one device.  Skipped on a

@@ -37,10 +37,18 @@ for name, (X, k), make in (
     os.environ.pop("CONVEX_DIM_RED_CACHE")
     print("%s: n_init=%d, %d outer iterations: %.2f s resident (%.0f it/s), %.2f s per-fit upload; identical costs: %s"
           % (name, n_init, it, t_res, it / t_res, t_up, c_res == c_up), flush=True)
-    for jobs in (1, 2, 4):                               # the same restarts, several fits at a time
+    for jobs in (1, 2, 4):                               # the same restarts, several fits at a time (threads)
         shared = np.random.RandomState(0)
         t0 = time.perf_counter()
-        models, best = cdr.fit_restarts(lambda: make(shared), X, n_init, n_jobs=jobs)
+        models, best = cdr.fit_restarts(lambda: make(shared), X, n_init, n_jobs=jobs, side_by_side=False)
         t = time.perf_counter() - t0
         print("   fit_restarts n_jobs=%d: %.2f s (%.0f it/s), identical costs: %s, best restart %d"
               % (jobs, t, it / t, [m.cost for m in models] == c_res, best), flush=True)
+    if name.startswith("C3"):                            # GPNH: restarts side by side in one set of arrays
+        for slots in (3, 6):
+            shared = np.random.RandomState(0)
+            t0 = time.perf_counter()
+            models, best = cdr.fit_restarts(lambda: make(shared), X, n_init, n_slots=slots)
+            t = time.perf_counter() - t0
+            print("   fit_restarts side by side, %d slots: %.3f s (%.0f it/s) = %.2fx the sequential loop, identical costs: %s, best restart %d"
+                  % (slots, t, it / t, t_res / t, [m.cost for m in models] == c_res, best), flush=True)
