@@ -6,9 +6,17 @@ and keep the one with the lowest cost.  For the problems those drivers run (161 
 matrices) one fit leaves most of an MI355X idle -- an outer iteration is a few dozen dependent
 launches of a few microseconds each -- so ``fit_restarts`` draws the starting factors of all
 restarts first, in the drivers' order (so every restart starts exactly where it would in the
-sequential loop), and then runs the fits ``n_jobs`` at a time, each worker thread on its own
-device context; the contexts of a device share one resident copy of the data.  Every model ends
-with the attributes the sequential loop gives it; results are identical, restart by restart.
+sequential loop), and then
+
+* GPNH models: lays the restarts SIDE BY SIDE in the component slots of one set of device arrays,
+  where they share every launch of an outer iteration (``_fit_gpnh_slots``, aa_gpnh_slots_*):
+  about three times the sequential loop's speed on the JRA-55-shaped problem;
+* AA models: runs the fits on worker threads, each on its own device context; the contexts of a
+  device share one resident copy of the data (useful with ``devices=[...]``: whole restarts dealt
+  over GPUs; on ONE GPU several fits at a time are not faster).
+
+Every model ends with the attributes the sequential loop gives it; results are identical, restart
+by restart.
 """
 from __future__ import absolute_import, division
 
@@ -122,9 +130,11 @@ def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
     return fallback
 
 
-def fit_restarts(make_model, data, n_init, n_jobs=4, devices=None, side_by_side=True, n_slots=None):
+def fit_restarts(make_model, data, n_init, n_jobs=None, devices=None, side_by_side=True, n_slots=None):
     """``make_model()`` returns a fresh ``ArchetypalAnalysis`` or ``GPNHConvexCoding`` (the drivers
     pass the shared ``RandomState`` as its ``random_state``, ``init`` 'random' or 'furthest_sum').
+    ``n_jobs``: worker threads (default: one per device -- more than one fit at a time on a GPU has
+    not been faster).
     ``devices``: GPU indices the worker threads are dealt over (default: the current one); the data
     matrix is uploaded ONCE per device and the workers of a device share that copy
     (``aa_share_data``), each with its own factors, streams and scratch.
@@ -185,6 +195,10 @@ def fit_restarts(make_model, data, n_init, n_jobs=4, devices=None, side_by_side=
             m.init = init
         return m.cost
 
+    if n_jobs is None:
+        # one worker per device: several fits at a time on ONE GPU are not faster (their launch chains
+        # do not overlap: profiles/round3_restarts_threads.txt, round3_stream_interleave.txt)
+        n_jobs = len(devices)
     try:
         with ThreadPoolExecutor(max_workers=max(1, int(n_jobs))) as pool:
             list(pool.map(run, todo))

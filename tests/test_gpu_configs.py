@@ -641,6 +641,40 @@ def test_gpnh_restarts_side_by_side(cdr, orc, case):
     assert best == int(np.argmin([m.cost for m in seq]))
 
 
+def test_gpnh_slot_with_singular_normal_equations_goes_to_the_sequential_path(cdr, orc):
+    """A start whose weights have an all-zero column (lambda_W = 0: no Cholesky factor) is reported
+    by its slot and left to the sequential path, which solves with lstsq like the reference
+    (gpnh_convex_coding.py:224); the other slots are not disturbed."""
+    import warnings
+    from convex_dim_red import restarts
+    rng = np.random.RandomState(4)
+    n, p, k = 600, 20, 4
+    X = orc.right_stochastic_matrix((n, k), rng).dot(rng.standard_normal((k, p))) + 0.1 * rng.standard_normal((n, p))
+    kw = dict(lambda_W=0.0, init="custom", tolerance=1e-6, max_iterations=30, stopping_criterion="rel_delta_f",
+              weights_solver_kwargs=dict(max_iterations=1))
+    starts = []
+    for i in range(4):
+        Z0 = orc.right_stochastic_matrix((n, k), rng)
+        if i == 2:
+            Z0[:, 1] = 0.0
+            Z0 /= Z0.sum(axis=1, keepdims=True)
+        starts.append(dict(dictionary=rng.standard_normal((p, k)), weights=Z0))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        seq = []
+        for st in starts:
+            m = cdr.GPNHConvexCoding(k, **kw)
+            m.fit_transform(X, dictionary=st["dictionary"].copy(), weights=st["weights"].copy())
+            seq.append(m)
+        models = [cdr.GPNHConvexCoding(k, **kw) for _ in starts]
+        left = restarts._fit_gpnh_slots(models, starts, X, None)
+    assert left == [2]
+    for i in (0, 1, 3):
+        assert models[i].cost == seq[i].cost and models[i].n_iter == seq[i].n_iter
+        assert np.array_equal(models[i].weights, seq[i].weights)
+        assert np.array_equal(models[i].dictionary, seq[i].dictionary)
+
+
 def test_fit_restarts_over_two_devices(cdr, orc):
     """fit_restarts(devices=[0, 1]): the workers are dealt over two GPUs, one resident copy of the
     data per device; restart by restart the same costs and factors as on one device.  Skipped on a
