@@ -144,6 +144,14 @@ _SIGNATURES = {
     "aa_gpnh_slots_load": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp]),
     "aa_gpnh_slots_run": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(SlotStatus)]),
     "aa_gpnh_slots_fetch": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp, _dp, _dp]),
+    "aa_slots_begin": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IterParams),
+                                      ctypes.POINTER(SPGParams), ctypes.POINTER(QPParams)]),
+    "aa_slots_load": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp]),
+    "aa_slots_run": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(SlotStatus)]),
+    "aa_slots_finish": (ctypes.c_int, [_vp]),
+    "aa_slots_fetch": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_int,
+                                      _dp, _dp]),
+    "aa_slots_end": (ctypes.c_int, [_vp]),
     "aa_get_spg_scalars": (ctypes.c_int, [_vp, _dp]),
     "aa_pass_reduce_rows": (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, ctypes.c_long]),
     "aa_pass_row_local": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp]),
@@ -639,6 +647,48 @@ class Context(object):
         c0 = ctypes.c_double(0)
         _check(self.lib.aa_gpnh_slots_fetch(self.h, int(r), _ptr(Wt), self.p, _ptr(Z), _ptr(costs), ctypes.byref(c0)))
         return Z, Wt.T, c0.value, costs
+
+    # ---- AA restarts side by side (aa_slots_*)
+    def aa_slots_begin(self, n_slots, k, max_outer, tolerance, stopping_criterion, require_monotonic, spg_kw, qp_kw,
+                       mono_tolerance=None):
+        crit = {"abs_delta_f": 0, "rel_delta_f": 1}.get(stopping_criterion)
+        if crit is None:
+            raise ValueError("unsupported stopping criterion '%s'" % stopping_criterion)
+        ip = IterParams(int(max_outer), float(tolerance), crit, int(bool(require_monotonic)),
+                        float(tolerance if mono_tolerance is None else mono_tolerance), 1, 1, 8, 0.0)
+        sp, qp = spg_params(**spg_kw), qp_params(**qp_kw)
+        _check(self.lib.aa_slots_begin(self.h, int(n_slots), int(k), ctypes.byref(ip), ctypes.byref(sp),
+                                       ctypes.byref(qp)))
+        self.k = int(n_slots) * int(k)
+        self._slots = (int(n_slots), int(k), int(max_outer))
+
+    def aa_slots_load(self, r, C, Z):
+        C, Z = _c64(C), _c64(Z)
+        _check(self.lib.aa_slots_load(self.h, int(r), _ptr(C), C.shape[1], _ptr(Z)))
+
+    def aa_slots_run(self, n_iters):
+        st = (SlotStatus * self._slots[0])()
+        _check(self.lib.aa_slots_run(self.h, int(n_iters), st))
+        return list(st)
+
+    def aa_slots_finish(self):
+        _check(self.lib.aa_slots_finish(self.h))
+
+    def aa_slots_fetch(self, r, stop_iter, carried):
+        """(weights n x k, dictionary k x n, C X k x p, cost0, costs[2 (stop_iter + 1)]) of a stopped slot."""
+        _, k, _ = self._slots
+        C = np.empty((k, self.n))
+        Z = np.empty((self.n, k))
+        CX = np.empty((k, self.p))
+        costs = np.zeros(2 * (int(stop_iter) + 1))
+        c0 = ctypes.c_double(0)
+        _check(self.lib.aa_slots_fetch(self.h, int(r), _ptr(C), self.n, _ptr(Z), _ptr(CX), self.p, int(bool(carried)),
+                                       _ptr(costs), ctypes.byref(c0)))
+        return Z, C, CX, c0.value, costs
+
+    def aa_slots_end(self):
+        _check(self.lib.aa_slots_end(self.h))
+        self._slots = None
 
     def gpnh_get_dictionary(self):
         """The reference's dictionary (p x k, returned like the reference returns it: the

@@ -408,6 +408,16 @@ def _fit_on_data_matrix(self, data, linear_kernel, label, dictionary=None, weigh
         self.n_components = data.shape[1]
     self._check_hyper_parameters()
     shape_only = _ShapeOnly(n_samples)
+    if (kwargs.get('_draw_only', False) and self.init == 'random' and not on_device and dictionary is None
+            and weights is None and alpha is None and update_dictionary and update_weights):
+        # restarts.fit_restarts: the start factors of a random start need no device (and no checksum of
+        # the data matrix per restart)
+        return self._resolve_factors(
+            n_samples, None, None, None, True, True,
+            lambda: _initialize_kernel_aa_dictionary(shape_only, self.n_components, init='random',
+                                                     random_state=self.random_state),
+            lambda: _initialize_kernel_aa_weights(shape_only, self.n_components, init='random',
+                                                  random_state=self.random_state))
 
     # the data matrix stays on the device between fits of the same array (the drivers' n_init
     # restarts, bin/run_hadisst_aa.py:158-172): only the start factors travel

@@ -130,6 +130,100 @@ def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
     return fallback
 
 
+def _aa_slots_eligible(models, data):
+    """AA restarts that can share one set of device arrays (aa_slots_*): production settings -- one SPG
+    iteration per dictionary update, delta = 0 -- same hyper-parameters, at most 4096 samples, k <= 16."""
+    m0 = models[0]
+    if not all(type(m) is ArchetypalAnalysis for m in models) or len(models) < 2:
+        return False
+    keys = ("n_components", "delta", "tolerance", "max_iterations", "stopping_criterion",
+            "require_monotonic_cost_decrease", "dtype", "weights_solver_kwargs", "dictionary_solver_kwargs",
+            "scale_factors_solver_kwargs")
+    if any(getattr(m, a) != getattr(m0, a) for m in models[1:] for a in keys):
+        return False
+    k = m0.n_components
+    dkw = dict(m0.dictionary_solver_kwargs)
+    return (isinstance(k, int) and 1 <= k <= 16 and m0.delta == 0 and not m0.verbose and data.shape[0] <= 4096
+            and dkw.get("max_iterations", 1000) == 1 and dkw.get("memory", 1) <= 16
+            and m0.weights_solver_kwargs.get("memory", 1) <= 1
+            and m0.weights_solver_kwargs.get("max_iterations", 1000) >= 1
+            and _backend.distributed_env() is None)
+
+
+def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
+    """Groups of up to 32 // k AA restarts side by side in ONE set of device arrays (aa_slots_*): every
+    launch of an outer iteration serves the whole group; a restart that stops keeps its factors of that
+    iteration while the rest of its group goes on (a group starts together: the first dictionary update
+    of a fit differs from the later ones).  Restart by restart the result is the sequential loop's,
+    bit for bit."""
+    import time
+    import warnings
+    from .archetypal_analysis import _warn_from_spg_flags, _DEVICE_LOOP_BATCH
+
+    class _Flags(object):
+        def __init__(self, flags):
+            self.spg_flags = flags
+
+    m0 = models[0]
+    k = m0.n_components
+    n_slots = min((32 // k) if n_slots is None else int(n_slots), 32 // k, len(models))
+    n_samples = data.shape[0]
+    prof = slots_profile
+    prof.update(load=0.0, run=0.0, fetch=0.0, polls=0, slots=n_slots)
+    ctx = _backend.Context(dtype=m0.dtype, device=device)
+    errors = {}
+    try:
+        ctx.set_data(data)
+        mono_tol = m0.tolerance
+        if ctx.dtype_code == _backend.AA_F32:
+            mono_tol = max(m0.tolerance, 8 * 6e-8 * ctx.data_trace() / n_samples)
+        for g0 in range(0, len(models), n_slots):
+            group = list(range(g0, min(g0 + n_slots, len(models))))
+            t0 = time.perf_counter()
+            ctx.aa_slots_begin(len(group), k, m0.max_iterations, m0.tolerance, m0.stopping_criterion,
+                               m0.require_monotonic_cost_decrease, m0.dictionary_solver_kwargs,
+                               m0.weights_solver_kwargs, mono_tolerance=mono_tol)
+            for r, i in enumerate(group):
+                ctx.aa_slots_load(r, starts[i]["dictionary"], starts[i]["weights"])
+            t1 = time.perf_counter()
+            prof["load"] += t1 - t0
+            while True:
+                status = ctx.aa_slots_run(poll_every)
+                prof["polls"] += 1
+                if all(st.stop for st in status):
+                    break
+            t2 = time.perf_counter()
+            prof["run"] += t2 - t1
+            ctx.aa_slots_finish()
+            ran = max(max(st.iterations_run for st in status), 1)
+            for r, i in enumerate(group):
+                st, m = status[r], models[i]
+                _warn_from_spg_flags(_Flags(st.not_spd))
+                if st.error_stage:
+                    errors[i] = RuntimeError('factorization cost increased after {} update'.format(
+                        {1: 'dictionary', 2: 'weights', 3: 'scale factors'}[st.error_stage]))
+                    continue
+                # aa_iterate rebuilds the products only when it ran past the stopping iteration
+                carried = (st.stop_iter + 1) % _DEVICE_LOOP_BATCH == 0 or st.stop_iter + 1 == m.max_iterations
+                Z, C, CX, cost0, costs = ctx.aa_slots_fetch(r, st.stop_iter, carried)
+                finals = costs[1::2]
+                begins = np.concatenate(([cost0], finals[:-1]))
+                m.weights, m.dictionary, m.alpha = Z, C, np.ones(k)
+                m.cost, m.n_iter = float(finals[-1]), int(st.stop_iter)
+                m.cost_deltas = [d for d in finals - begins]
+                m.avg_time_per_iter = (t2 - t1) / ran
+                m.archetypes = CX
+                if m.n_iter == m.max_iterations and m.tolerance > 0:
+                    warnings.warn('Maximum number of iterations %d reached.' % m.max_iterations, UserWarning)
+            prof["fetch"] += time.perf_counter() - t2
+        ctx.aa_slots_end()
+    finally:
+        ctx.close()
+    if errors:
+        raise errors[min(errors)]
+    return []
+
+
 def fit_restarts(make_model, data, n_init, n_jobs=None, devices=None, side_by_side=True, n_slots=None):
     """``make_model()`` returns a fresh ``ArchetypalAnalysis`` or ``GPNHConvexCoding`` (the drivers
     pass the shared ``RandomState`` as its ``random_state``, ``init`` 'random' or 'furthest_sum').
@@ -160,6 +254,12 @@ def fit_restarts(make_model, data, n_init, n_jobs=None, devices=None, side_by_si
     _backend.release_device_cache()               # the workers bring their own contexts
     devices = [_backend.device_index()] if devices is None else [int(d) for d in devices]
     todo = list(range(n_init))
+    if side_by_side and len(devices) == 1 and _aa_slots_eligible(models, data):
+        # AA: groups of restarts share the launches of every outer iteration (aa_slots_*)
+        todo = _fit_aa_slots(models, starts, data, devices[0], n_slots=n_slots)
+        if not todo:
+            costs = [m.cost for m in models]
+            return models, int(np.argmin(costs))
     if side_by_side and len(devices) == 1 and _slots_eligible(models):
         # GPNH: the restarts share the launches of every outer iteration (aa_gpnh_slots_*)
         todo = _fit_gpnh_slots(models, starts, data, devices[0], n_slots=n_slots)

@@ -129,6 +129,8 @@ struct ProjState {          // per projection, device memory
     int list_max[4];              // longest gathered list (over the columns) of the last projection per kind
 };
 
+#define AA_SC_STRIDE 64      // doubles per slot of the per-slot scalar blocks (>= SC_COUNT)
+
 struct IterState {          // aa_iterate: device-side loop status
     int stop, converged, error_stage, stop_iter, last_iter, spg_flags, pad0, pad1;
 };
@@ -147,6 +149,12 @@ struct Ctx {
     // GPNH restarts side by side (aa_gpnh_slots_*): per-slot cost records, counters, status, initial costs
     DevBuf slotCosts, slotCounters, slotStates, slotCost0;
     int slots_R = 0, slots_k = 0, slots_stride = 0, slots_max_outer = 0;
+    // AA restarts side by side (aa_slots_*): the launchers of the coupled steps pick their per-slot
+    // forms while this is set; per-slot SPG scalars [R][AA_SC_STRIDE]
+    bool slots_aa = false, slots_started = false;
+    DevBuf slotScal, slotSnapP;
+    aa_iter_params slots_ip;
+    aa_spg_params slots_sp;
     aa_gpnh_params slots_gp;
     aa_qp_params slots_qp;
     DevBuf qpLive;                             // ready[cap] | done[cap] flags of the live hand-over (QpLive)
@@ -286,6 +294,9 @@ int launch_gpnh_solve(Ctx *c, double lambda, int *ok_dev);
 int launch_gpnh_solve_slots(Ctx *c, double lambda);
 int launch_gpnh_cost_slots(Ctx *c, double lambda, unsigned mask, int what, const aa_iter_params *ip, bool form_gram);
 int launch_gpnh_snap_slots(Ctx *c);
+int launch_aa_cost_slots(Ctx *c, int what, const aa_iter_params *ip);
+int launch_aa_snap_slots(Ctx *c);
+int launch_qp_slots_aa(Ctx *c, const aa_qp_params *p);      // kernels_qp.hip: quad + wave kernels, grid.y = slot
 int launch_qp_slots(Ctx *c, int R, int k, const double *gram_dev, const aa_qp_params *p);   // kernels_qp.hip
 bool gpnh_cost_can_gram(const Ctx *c);
 int launch_gpnh_cost(Ctx *c, double lambda, double *out_dev, int *slot_counter, bool from_wide = false,

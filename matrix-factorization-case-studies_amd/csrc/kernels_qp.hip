@@ -945,8 +945,20 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
                                                  int park_at = 1 << 30, unsigned int *__restrict__ n_parked = nullptr,
                                                  int *__restrict__ park_rows = nullptr,
                                                  QpCarry *__restrict__ park = nullptr,
-                                                 QpLive lv = QpLive{0, 0, 0u, 0u, nullptr, nullptr})
+                                                 QpLive lv = QpLive{0, 0, 0u, 0u, nullptr, nullptr},
+                                                 int rst_b = 0, long rst_n = 0)
 {
+    if (gridDim.y > 1) {                               // restarts side by side: blockIdx.y = slot
+        const int rst = blockIdx.y;
+        A += (long)rst * KQ * KQ;
+        if (bscale) bscale += rst * 64;
+        B += (long)rst * rst_b;
+        Z += (long)rst * rst_b;
+        hdr += rst;
+        ovf_rows += rst * rst_n;
+        ovf += rst * rst_n;
+        if (iters) iters += rst * rst_n;
+    }
     // park_at (continuation path): a sample still running after that many passes is written back
     // and appended to a second overflow list (n_parked / park_rows / park) -- the handful of
     // samples with hundreds of passes, which a later launch finishes beside the next pass over X
@@ -1153,9 +1165,9 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
                 const int *__restrict__ fresh_list = nullptr, const unsigned int *__restrict__ count_ptr = nullptr, \
                 int park_at = 1 << 30, unsigned int *__restrict__ n_parked = nullptr,                               \
                 int *__restrict__ park_rows = nullptr, QpCarry *__restrict__ park = nullptr,                        \
-                QpLive lv = QpLive{0, 0, 0u, 0u, nullptr, nullptr}
+                QpLive lv = QpLive{0, 0, 0u, 0u, nullptr, nullptr}, int rst_b = 0, long rst_n = 0
 #define QW_PASS A, B, stride_j, stride_t, bscale, Z, ldz, n_fresh, k, p, iters, hdr, ovf_rows, ovf, zslot,           \
-                fresh_list, count_ptr, park_at, n_parked, park_rows, park, lv
+                fresh_list, count_ptr, park_at, n_parked, park_rows, park, lv, rst_b, rst_n
 template <int KQ>
 __global__ __launch_bounds__(256) void k_qp_wave(QW_ARGS) { qp_wave_body<KQ>(QW_PASS); }
 // the live consumers (QpLive mode 1): blocks of 16 waves that are launched with a whole CU's LDS
@@ -1774,8 +1786,21 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
                                              QpHeader *__restrict__ hdr, int *__restrict__ ovf_rows,
                                              QpCarry *__restrict__ ovf, int refill_min,
                                              const int *__restrict__ perm, long max_trips,
-                                             int live_epoch, int *__restrict__ ovf_ready)
+                                             int live_epoch, int *__restrict__ ovf_ready, int rst_b, long rst_n)
 {
+    // restarts side by side (launch_qp_slots_aa): blockIdx.y = slot -- its Hessian (lda x lda), scale
+    // vector, columns of B and Z, header and overflow lists
+    if (gridDim.y > 1) {
+        const int rst = blockIdx.y;
+        A += (long)rst * lda * lda;
+        if (bscale) bscale += rst * 64;
+        B += (long)rst * rst_b;
+        Z += (long)rst * rst_b;
+        hdr += rst;
+        ovf_rows += rst * rst_n;
+        ovf += rst * rst_n;
+        if (iters) iters += rst * rst_n;
+    }
     constexpr int J = 4 * MT;
     const int lane = threadIdx.x, sl = lane & 15, q = lane >> 4;
     double H[MT][J];                                // A's operand tiles (constant)
@@ -2045,9 +2070,9 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
                 const double *__restrict__ bscale, double *__restrict__ Z, int ldz, long n, int k, aa_qp_params p, \
                 int pass_cap, int *__restrict__ iters, QpHeader *__restrict__ hdr, int *__restrict__ ovf_rows,      \
                 QpCarry *__restrict__ ovf, int refill_min, const int *__restrict__ perm, long max_trips,           \
-                int live_epoch, int *__restrict__ ovf_ready
+                int live_epoch, int *__restrict__ ovf_ready, int rst_b, long rst_n
 #define QQ_PASS A, lda, B, stride_j, stride_t, bscale, Z, ldz, n, k, p, pass_cap, iters, hdr, ovf_rows, ovf,        \
-                refill_min, perm, max_trips, live_epoch, ovf_ready
+                refill_min, perm, max_trips, live_epoch, ovf_ready, rst_b, rst_n
 template <int MT, bool MEM1>
 __global__ __launch_bounds__(64) void k_qp_quad(QQ_ARGS) { qp_quad_body<MT, MEM1>(QQ_PASS); }
 template <int MT, bool MEM1>
@@ -2282,6 +2307,84 @@ int launch_qp_slots(Ctx *c, int R, int k, const double *gram_dev, const aa_qp_pa
     return AA_OK;
 }
 
+// AA restarts side by side: the weights QPs of R slots in ONE launch of the four-lanes-per-sample kernel
+// and ONE of the wave-per-sample kernel (grid.y = slot), each slot with its own Hessian
+// D C K C' D (diagonal block of the Gram state), scale vector, header and overflow list -- per
+// sample the arithmetic of the single fit (launch_qp, quad mode, no sample ordering).
+__global__ __launch_bounds__(256) void k_qp_setup_slots_aa(QpHeader *__restrict__ hdr, double *__restrict__ A2d,
+                                                           double *__restrict__ bsd, const double *__restrict__ gram,
+                                                           const double *__restrict__ alpha, int k, int KP)
+{
+    const int t = threadIdx.x, r = blockIdx.x, o = r * k;
+    if (t == 0) {
+        QpHeader *h = hdr + r;
+        h->total_passes = 0ull;
+        h->max_passes = 0ull;
+        h->next_row = 0u;
+        h->n_overflow = 0u;
+        h->next_overflow = 0u;
+        h->n_long = 0u;
+        h->dbg_rounds = h->dbg_trips = h->dbg_waves = 0u;
+        h->pad = 0u;
+        h->waves_done = 0u;
+    }
+    double *A2 = A2d + (size_t)r * 32 * 32;
+    for (int e = t; e < 32 * 32; e += 256) {
+        const int i = e / 32, j = e % 32;
+        A2[e] = (i < k && j < k) ? alpha[o + i] * gram[(o + i) * KP + o + j] * alpha[o + j] : 0.0;
+    }
+    if (t < 64) bsd[r * 64 + t] = t < k ? alpha[o + t] : 1.0;
+}
+
+int launch_qp_slots_aa(Ctx *c, const aa_qp_params *p)
+{
+    const int R = c->slots_R, k = c->slots_k;
+    AA_REQUIRE(k <= 16 && p->memory <= 1 && p->max_iterations >= 1, AA_ERR_ARG,
+               "AA slots: k <= 16, QP memory 1");
+    const long n = c->n;
+    AA_REQUIRE(n <= 4096, AA_ERR_ARG, "AA slots: at most 4096 samples (no sample ordering)");
+    const long n_al = round_up(n, 16);
+    const size_t off_A = 64 * (size_t)R;
+    const size_t off_bs = off_A + (size_t)R * 32 * 32 * sizeof(double);
+    const size_t off_rows = off_bs + (size_t)R * 64 * sizeof(double);
+    const size_t off_ovf = off_rows + (size_t)R * n_al * sizeof(int);
+    const size_t bytes = off_ovf + (size_t)R * n_al * sizeof(QpCarry);
+    AA_CHECK(c->qpStats.alloc(bytes));
+    unsigned char *base = reinterpret_cast<unsigned char *>(c->qpStats.p);
+    QpHeader *hdr = reinterpret_cast<QpHeader *>(base);
+    double *A2d = reinterpret_cast<double *>(base + off_A);
+    double *bsd = reinterpret_cast<double *>(base + off_bs);
+    int *ovf_rows = reinterpret_cast<int *>(base + off_rows);
+    QpCarry *ovf = reinterpret_cast<QpCarry *>(base + off_ovf);
+    const double *gram = c->gramState.as<double>() + (size_t)c->KP * c->KP;          // C K C'
+    hipLaunchKernelGGL(k_qp_setup_slots_aa, dim3((unsigned)R), dim3(256), 0, c->stream, hdr, A2d, bsd, gram,
+                       (const double *)c->alphaDev.as<double>(), k, c->KP);
+    int cap = g_qp_quad_cap > 0 ? g_qp_quad_cap : 24;
+    if (p->max_iterations <= cap) cap = p->max_iterations;
+    const long waves = (n + 15) / 16;
+    const long max_trips = 16 * ((long)cap + 2) + 16;
+    const int refill = g_qp_quad_refill < 1 ? 1 : (g_qp_quad_refill > 16 ? 16 : g_qp_quad_refill);
+    const double *Bt = c->Gr.as<double>();
+    double *Zt = c->Zt.as<double>();
+    const dim3 grid((unsigned)waves, (unsigned)R);
+#define QQS(KERN)                                                                                         \
+    hipLaunchKernelGGL((KERN<1, true>), grid, dim3(64), 0, c->stream, (const double *)A2d, 32, Bt, (long)1,      \
+                       (long)c->KP, (const double *)bsd, Zt, c->KP, n, k, *p, cap, (int *)nullptr, hdr, ovf_rows, \
+                       ovf, refill, (const int *)nullptr, max_trips, 0, (int *)nullptr, k, n_al)
+    if (g_qp_quad_occ >= 4) QQS(k_qp_quad_w4);
+    else if (g_qp_quad_occ == 3) QQS(k_qp_quad_w3);
+    else QQS(k_qp_quad);
+#undef QQS
+    if (cap < p->max_iterations)
+        hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)g_qp_wave_blocks, (unsigned)R), dim3(256), 0, c->stream,
+                           (const double *)A2d, Bt, (long)1, (long)c->KP, (const double *)bsd, Zt, c->KP, (long)-1, k,
+                           *p, (int *)nullptr, hdr, (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr,
+                           (const int *)nullptr, (const unsigned int *)nullptr, 1 << 30, (unsigned int *)nullptr,
+                           (int *)nullptr, (QpCarry *)nullptr, QpLive{0, 0, 0u, 0u, nullptr, nullptr}, k, n_al);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
 int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, long stride_t,
               const double *bscale_host, double *Ztall, int ldz, long n, int k,
               const aa_qp_params *p, int *iters_dev, aa_qp_stats *stats, const double *gram_dev,
@@ -2467,7 +2570,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
 #define QQK(KERN, MTV, M1V)                                                                         \
     hipLaunchKernelGGL((KERN<MTV, M1V>), dim3((unsigned)waves), dim3(64), quad_lds, s_main, A2d, KW, Btall, \
                        stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf,   \
-                       refill, perm, max_trips, live_epoch, ovf_ready)
+                       refill, perm, max_trips, live_epoch, ovf_ready, 0, 0L)
 #define QQL(MTV, M1V)                                                                               \
     do {                                                                                            \
         if (quad_occ >= 4) QQK(k_qp_quad_w4, MTV, M1V);                                             \

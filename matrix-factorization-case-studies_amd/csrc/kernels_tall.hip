@@ -55,6 +55,11 @@ __device__ __forceinline__ double load_a(double a_const, const double *scal, int
 {
     return a_slot >= 0 ? scal[a_slot] : a_const;
 }
+// restarts side by side (kslot > 0: components per slot): column `comp` takes the scalar of ITS slot
+__device__ __forceinline__ double load_a(double a_const, const double *scal, int a_slot, int comp, int kslot)
+{
+    return a_slot >= 0 ? scal[(kslot > 0 ? (comp / kslot) * AA_SC_STRIDE : 0) + a_slot] : a_const;
+}
 
 #define PROJ_NT 1024       // threads per block of the first / finish passes of a projection
 
@@ -141,12 +146,12 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_finish(int mode, const double 
                                                      long rows_pb, int k,
                                                      const ProjState *__restrict__ ps,
                                                      double *__restrict__ out,
-                                                     double *__restrict__ partial)
+                                                     double *__restrict__ partial, int kslot = 0)
 {
     __shared__ double sm[4 * PROJ_NT];
     constexpr int RS = PROJ_NT / KP;
     const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
-    const double a = load_a(a_const, scal, a_slot);
+    const double a = load_a(a_const, scal, a_slot, comp, kslot);
     const long rb = (long)blockIdx.x * rows_pb;
     long re = rb + rows_pb;
     if (re > n) re = n;
@@ -452,12 +457,13 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
 __global__ __launch_bounds__(256) void k_proj_small(const double *__restrict__ x,
                                                     const double *__restrict__ g, double a_const,
                                                     const double *__restrict__ scal, int a_slot, long n,
-                                                    int KP, int warm_slot, ProjState *__restrict__ ps)
+                                                    int KP, int warm_slot, ProjState *__restrict__ ps,
+                                                    int kslot = 0)
 {
     __shared__ double rs[4];
     __shared__ int rm[4];
     const int comp = blockIdx.x, t = threadIdx.x;
-    const double a = load_a(a_const, scal, a_slot);
+    const double a = load_a(a_const, scal, a_slot, comp, kslot);
     double w[PROJ_SMALL_RPT];
     double mx = -INFINITY;
 #pragma unroll
@@ -677,6 +683,55 @@ __device__ void post_step(int kind, int mode, const double *__restrict__ red, in
     }
 }
 
+// Restarts side by side: the scalar part of POST_FIN / POST_SCALAR_SUM once per slot -- wave w takes
+// the slots w, w + 16, ...; the slot's kslot column results sit in lanes 0 .. kslot - 1 of the xor
+// tree exactly as a single fit's k columns do (same association, same bits) -- and the scalar
+// stage that follows, once per slot on the slot's scalar block.
+__device__ void post_step_slots(int kind, int mode, const double *__restrict__ red, int KP, int kslot, int R,
+                                ProjState *__restrict__ ps, double *__restrict__ scal, int slot,
+                                int stage_after, const aa_spg_params &sp)
+{
+    const int i = threadIdx.x, lane = i & 63, nw = (int)blockDim.x >> 6;
+    if (kind == POST_FIN && i < kslot * R && mode > 0 && mode < 4) ps->warm[mode][i] = ps->t[i];
+    for (int r = i >> 6; r < R; r += nw) {
+        double *sc = scal + (size_t)r * AA_SC_STRIDE;
+        const bool col = lane < kslot;
+        const int idx = r * kslot + lane;
+        if (kind == POST_FIN) {
+            double s0 = col ? red[idx] : 0.0, s1 = col ? red[KP + idx] : 0.0;
+            double s2 = col ? red[2 * KP + idx] : 0.0, m3 = col ? red[3 * KP + idx] : 0.0;
+            const bool conv_all = __ballot(col && !ps->shrunk[col ? idx : 0]) == 0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                s0 += __shfl_xor(s0, o, 64);
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+                m3 = fmax(m3, __shfl_xor(m3, o, 64));
+            }
+            if (lane == 0) {
+                if (mode == PROJ_DIR) {
+                    sc[SC_DELTA] = s0;
+                    sc[SC_DD] = s1;
+                    sc[SC_S1D] = s2;
+                } else if (mode == PROJ_RES) {
+                    sc[SC_RES2] = s0;
+                    sc[SC_RESINF] = m3;
+                } else if (mode == PROJ_ALPHA) {
+                    sc[SC_AINV] = m3;
+                }
+                if (!conv_all) sc[SC_FLAGS] = (double)((int)sc[SC_FLAGS] | AA_SPG_FLAG_PROJ_UNCONV);
+            }
+        } else if (kind == POST_SCALAR_SUM) {
+            double s = col ? red[idx] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) sc[slot] = s;
+        }
+        if (stage_after >= 0 && lane == 0) scalar_stage_simple(stage_after, sc, sp);
+    }
+    if (kind == POST_FIN && i == 0 && ps->passes < 0) ps->done = 1;
+}
+
 // partial [nb][NV][KP] -> red [NV][KP], fixed order; all FIN_NT threads of one block; sm holds
 // 4 * FIN_NT doubles.  `gather`: multi-rank slot buffer (see k_finalize_sum).
 __device__ __forceinline__ void finalize_sum_block(const double *__restrict__ partial, int nb, int NV,
@@ -737,11 +792,16 @@ __global__ __launch_bounds__(FIN_NT) void k_finalize_sum(const double *__restric
                                                          ProjState *__restrict__ ps,
                                                          double *__restrict__ scal, int slot,
                                                          double *__restrict__ gather, int rank,
-                                                         int world, int stage_after, aa_spg_params sp)
+                                                         int world, int stage_after, aa_spg_params sp,
+                                                         int kslot = 0, int R = 0)
 {
     if (ps_gate && ps_gate->done) return;
     __shared__ double sm[4 * FIN_NT];
     finalize_sum_block(partial, nb, NV, KP, max_mask, red, sm, gather, rank, world);
+    if (kslot > 0 && (kind == POST_FIN || kind == POST_SCALAR_SUM)) {      // restarts side by side
+        post_step_slots(kind, mode, red, KP, kslot, R, ps, scal, slot, stage_after, sp);
+        return;
+    }
     if (kind != POST_NONE) post_step(kind, mode, red, KP, k, ps, scal, slot);
     // the scalar stage that consumes these reductions (ST_ALPHA / ST_BB / ST_CONV) rides along
     // instead of being its own ~5 us launch
@@ -800,7 +860,7 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
                                               const double *__restrict__ d,
                                               double *__restrict__ partial,
                                               double *__restrict__ xupd,
-                                              const double *__restrict__ scalw)
+                                              const double *__restrict__ scalw, int kslot = 0, int nslot = 0)
 {
     constexpr int T = KP / 16;       // component tiles
     constexpr int S = KP / 4;        // contraction steps
@@ -820,7 +880,13 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
     double dot = 0.0;
     // xupd: x <- x + lambda d for the rows of this block (the accepted SPG step, spg.py:208-222;
     // d is read for <d, g_new> anyway)
-    const double lam = xupd ? scalw[SC_LAMBDA] : 0.0;
+    // (restarts side by side: the step of the slot a column belongs to)
+    double lamv[T];
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti) {
+        const int sl = kslot > 0 ? (16 * ti + lc) / kslot : 0;
+        lamv[ti] = xupd ? scalw[(size_t)(sl < nslot ? sl : 0) * AA_SC_STRIDE + SC_LAMBDA] : 0.0;
+    }
     // Two 16-row tiles (r0 and r0 + 64) per step, every load of both -- the A operands, and H,
     // d, x of the epilogue -- issued before the first MFMA: with one tile in flight a wave waited
     // out a full memory latency three times per 16 rows (35 us per launch).
@@ -875,7 +941,7 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
                         if (d) {
                             const double de = dv[u][ti][reg];
                             dot += de * ge;
-                            if (xupd) xupd[e] = xv[u][ti][reg] + lam * de;
+                            if (xupd) xupd[e] = xv[u][ti][reg] + lamv[ti] * de;
                         }
                     }
                 }
@@ -892,6 +958,55 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
         }
         if (threadIdx.x < KP) partial[(size_t)blockIdx.x * KP + threadIdx.x] = threadIdx.x == 0 ? sm[0] : 0.0;
     }
+}
+
+// restarts side by side: <d, g_new> of slot blockIdx.y, summed in EXACTLY the order k_grad sums it for
+// a single fit of k components (same grid, same thread -> element map with the slot's columns in the
+// place of columns 0 .. k-1, same tree): the BB step of every slot gets the bits it gets alone.
+// partial [blocks][KP]: the slot's dot in component slot `r k`, zeros in the rest of its columns.
+template <int KP>
+__global__ __launch_bounds__(256) void k_grad_dot_slots(const double *__restrict__ g, const double *__restrict__ d,
+                                                        long n, long rows_pb, int k, int R,
+                                                        double *__restrict__ partial)
+{
+    constexpr int T = KP / 16;
+    __shared__ double sm[256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lr = lane >> 4, lc = lane & 15;
+    const int r = blockIdx.y, o = r * k;
+    const long rb = (long)blockIdx.x * rows_pb;
+    long re = rb + rows_pb;
+    double dot = 0.0;
+    for (long r0 = rb + 16 * wave; r0 < re; r0 += 128) {
+        if (r0 >= n) break;
+        const bool two = (r0 + 64 < re) && (r0 + 64 < n);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) continue;
+            const long ru = r0 + 64 * u;
+#pragma unroll
+            for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const long row = ru + lr + 4 * reg;
+                    const int comp = 16 * ti + lc;
+                    if (row < n && comp < k) {
+                        const long e = row * KP + o + comp;
+                        dot += d[e] * g[e];
+                    }
+                }
+        }
+    }
+    sm[threadIdx.x] = dot;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if ((int)threadIdx.x < q) sm[threadIdx.x] += sm[threadIdx.x + q];
+        __syncthreads();
+    }
+    double *dst = partial + (size_t)blockIdx.x * KP;
+    if ((int)threadIdx.x < k) dst[o + threadIdx.x] = threadIdx.x == 0 ? sm[0] : 0.0;
+    if (r == 0)
+        for (int i = R * k + threadIdx.x; i < KP; i += 256) dst[i] = 0.0;
 }
 
 // v0 = sum x * H * alpha   (tr(C * H D), archetypal_analysis.py:267,279)
@@ -929,10 +1044,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_wide_axpy(double *__restrict__ P,
                                                    const double *__restrict__ Q,
                                                    const double *__restrict__ scal, long elems,
-                                                   T *__restrict__ PT)
+                                                   T *__restrict__ PT, long ld = 0, int kslot = 0, int R = 0)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < elems) {
+        if (kslot > 0) {                     // restarts side by side: row i / ld belongs to slot row / kslot
+            const int r = (int)((i / ld) / kslot);
+            scal += (size_t)(r < R ? r : 0) * AA_SC_STRIDE;
+        }
         const double v = P[i] + scal[SC_LAMBDA] * Q[i];
         P[i] = v;
         if (PT) PT[i] = (T)v;
@@ -1203,6 +1322,12 @@ __global__ __launch_bounds__(256) void k_scalar_stage(int stage, double *__restr
 {
     __shared__ double sm[256];
     const int GS = KP * KP;
+    if (gridDim.x > 1) {                 // restarts side by side: block = slot, its diagonal blocks and scalars
+        const size_t off = (size_t)(blockIdx.x * k) * KP + blockIdx.x * k;
+        sc += (size_t)blockIdx.x * AA_SC_STRIDE;
+        gram += off;
+        M += off;
+    }
     double tr0 = 0.0, tr1 = 0.0, tr2 = 0.0;
     if (stage == ST_INIT_F) {
         tr0 = block_trace_MG(M, gram, k, KP, false, sm);
@@ -1391,6 +1516,82 @@ __global__ __launch_bounds__(1024) void k_linesearch_fin(const double *__restric
     }
 }
 
+// restarts side by side: k_linesearch_fin with the traces, the line search, the cost and the Gram of
+// the accepted point once per slot, on the slot's diagonal blocks and scalar block
+struct SlotRecords {        // per-slot cost records (aa_slots_*, aa_gpnh_slots_*)
+    double *costs;          // [R][stride]
+    int stride;
+    int *counters;          // [R]
+};
+__global__ __launch_bounds__(1024) void k_linesearch_fin_slots(const double *__restrict__ partial, int nb,
+                                                               int KP, double *__restrict__ gram,
+                                                               const double *__restrict__ M,
+                                                               double *__restrict__ scal, aa_spg_params sp,
+                                                               int k, int R, double *__restrict__ ckct_state,
+                                                               double n_global, SlotRecords rec)
+{
+    __shared__ double smt[256];
+    __shared__ double smt2[256];
+    const int GS = KP * KP, t = threadIdx.x;
+    for (int e = t; e < 2 * GS; e += 1024) {
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        int b = 0;
+        for (; b + 15 < nb; b += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(b + u) * 2 * GS + e];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s4[u & 3] += v[u];
+        }
+        for (; b < nb; ++b) s4[b & 3] += partial[(size_t)b * 2 * GS + e];
+        gram[GS + e] = ((s4[0] + s4[1]) + s4[2]) + s4[3];
+    }
+    __syncthreads();
+    for (int r = 0; r < R; ++r) {
+        const size_t off = (size_t)(r * k) * KP + r * k;
+        const double *Mr = M + off, *G1 = gram + GS + off, *G2 = gram + 2 * GS + off;
+        double *sc = scal + (size_t)r * AA_SC_STRIDE;
+        double a1 = 0.0, a2 = 0.0;
+        if (t < 256)
+            for (int e = t; e < k * k; e += 256) {
+                const int i = e / k, j = e % k;
+                const double m = Mr[i * KP + j];
+                a1 += m * (G1[j * KP + i] + G1[i * KP + j]);
+                a2 += m * G2[j * KP + i];
+            }
+        if (t < 256) {
+            smt[t] = a1;
+            smt2[t] = a2;
+        }
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (t < o) {
+                smt[t] += smt[t + o];
+                smt2[t] += smt2[t + o];
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            linesearch_thread0(sc, sp, smt[0], smt2[0]);
+            double *cr = rec.costs + (size_t)r * rec.stride;
+            int idx = rec.counters[r];
+            if (idx >= rec.stride) idx = rec.stride - 1;          // a finished slot waiting to be replaced
+            cr[idx] = 0.5 * (sc[SC_TRACE] - 2.0 * sc[SC_S1] + sc[SC_A0]) / n_global;
+            rec.counters[r] = idx + 1;
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < GS; e += 1024) {
+        const int row = e / KP, q = e % KP;
+        const int r = row / k;
+        if (r >= R || q / k != r) continue;                       // diagonal blocks only
+        const double lam = scal[(size_t)r * AA_SC_STRIDE + SC_LAMBDA];
+        const double v = gram[e] + lam * (gram[GS + e] + gram[GS + q * KP + row]) + lam * lam * gram[2 * GS + e];
+        gram[e] = v;
+        if (ckct_state) ckct_state[e] = v;
+    }
+}
+
 // Start of a dictionary update whose inputs are already on the device (the state a weights
 // update leaves: Z'Z, C K C', C K Z in the Gram state): M = D Z'Z D
 // (archetypal_analysis.py:310,330), gram[0] = C K C', the scalars, tr(C H D) = sum_i
@@ -1415,6 +1616,48 @@ __global__ __launch_bounds__(256) void k_dict_setup(const double *__restrict__ s
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (t < o) sm[t] += sm[t + o];
+        __syncthreads();
+    }
+    if (t == 0) {
+        sc[SC_TRACE] = trace;
+        sc[SC_FNORM] = fnorm;
+        sc[SC_S1] = sm[0];
+        sc[SC_A0] = a0;
+        sc[SC_F_OLD] = 0.5 * (trace - 2.0 * sm[0] + a0) / fnorm;
+        sc[SC_NFEVAL] = 1.0;
+        sc[SC_FLAGS] = 0.0;
+        for (int i = 0; i < 16; ++i) sc[SC_FMEM0 + i] = 0.0;   // f_mem = zeros (spg.py:153)
+        sc[SC_ALPHA_SET] = (sp.alpha0 >= 0.0) ? 1.0 : 0.0;
+        sc[SC_ALPHA] = sp.alpha0;
+    }
+}
+
+// restarts side by side: block r sets up slot r from the diagonal blocks of the Gram state -- the
+// arithmetic of k_dict_setup on its k x k block (the off-diagonal blocks of M stay zero since
+// aa_slots_begin: the gradient kernel then sees a block-diagonal M and the slots do not mix)
+__global__ __launch_bounds__(256) void k_dict_setup_slots(const double *__restrict__ state /*ZtZ|CKCt|CKZ*/,
+                                                          const double *__restrict__ alpha, int k, int KP,
+                                                          double trace, double fnorm, double *__restrict__ Mout,
+                                                          double *__restrict__ gram, double *__restrict__ scal,
+                                                          aa_spg_params sp)
+{
+    __shared__ double sm[256];
+    const int GS = KP * KP, t = threadIdx.x, r = blockIdx.x, o = r * k;
+    const size_t off = (size_t)o * KP + o;
+    const double *ZtZ = state + off, *CKCt = state + GS + off, *CKZ = state + 2 * GS + off;
+    const double *al = alpha + o;
+    double *M = Mout + off, *G = gram + off, *sc = scal + (size_t)r * AA_SC_STRIDE;
+    for (int e = t; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        M[i * KP + j] = al[i] * ZtZ[i * KP + j] * al[j];
+        G[i * KP + j] = CKCt[i * KP + j];
+    }
+    __syncthreads();
+    const double a0 = block_trace_MG(M, G, k, KP, false, sm);
+    sm[t] = t < k ? al[t] * CKZ[t * KP + t] : 0.0;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (t < q) sm[t] += sm[t + q];
         __syncthreads();
     }
     if (t == 0) {
@@ -1629,7 +1872,8 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
     if ((c->world <= 1 && !c->force_comm)) {
         hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(FIN_NT), 0, c->stream, part, nb, NV,
                            c->KP, max_mask, red, gate, kind, mode, c->k, ps, c->scalars.as<double>(),
-                           slot, (double *)nullptr, 0, 1, stage_after, spv);
+                           slot, (double *)nullptr, 0, 1, stage_after, spv, c->slots_aa ? c->slots_k : 0,
+                           c->slots_aa ? c->slots_R : 0);
     } else {
         // one sum all-reduce of a [world][NV][KP] buffer in which every rank fills its own
         // slot, whatever mix of sums and maxima the NV values are; the ranks' values are
@@ -1751,7 +1995,7 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     }
     if (g_proj_mode == 0 && !multi && g_proj_small && c->n <= 256L * PROJ_SMALL_RPT) {
         hipLaunchKernelGGL(k_proj_small, dim3(c->k), dim3(256), 0, c->stream, x, g, a_const, (const double *)scal,
-                           a_slot, c->n, c->KP, c->projWarm[mode] ? mode : 0, ps);
+                           a_slot, c->n, c->KP, c->projWarm[mode] ? mode : 0, ps, c->slots_aa ? c->slots_k : 0);
     } else if (g_proj_mode == 0) {
         const int RS = 256 / c->KP;
         const long nseg = (long)c->tallBlocks * RS, segcap = rpb / RS;
@@ -1814,7 +2058,7 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     if (mode == PROJ_DIR) out = c->Dt.as<double>();
     TALL_DISPATCH_NT(PROJ_NT, k_proj_finish, mode, x, g, a_const, (const double *)scal, a_slot,
                   (const double *)c->H.as<double>(), (const double *)c->alphaDev.as<double>(), c->n, rpb,
-                  c->k, (const ProjState *)ps, out, part);
+                  c->k, (const ProjState *)ps, out, part, c->slots_aa ? c->slots_k : 0);
     if (sp && stage_after >= 0 && !g_fuse_finalize) {
         AA_CHECK(finalize_and_post(c, 4, 8u, POST_FIN, mode, 0, false));
         AA_CHECK(launch_scalar_stage(c, stage_after, sp, 0));
@@ -1883,16 +2127,27 @@ int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, doubl
     const int nb = (int)((c->n + rpb - 1) / rpb);
     double *part = c->redPartial.as<double>();
     double *pdot = d_for_dot ? part : (double *)nullptr;
+    const int kslot = c->slots_aa ? c->slots_k : 0;
+    if (kslot && d_for_dot) pdot = c->tmpTall.as<double>();      // k_grad's mixed dot is not used: per slot below
     if (c->KP == 32)
         hipLaunchKernelGGL(k_grad<32>, dim3(nb), dim3(256), 0, c->stream, Graw, H,
                            (const double *)c->Mdev.as<double>(), (const double *)c->alphaDev.as<double>(),
                            scale, c->n, rpb, c->k, gout, d_for_dot, pdot, xupd,
-                           (const double *)c->scalars.as<double>());
+                           (const double *)c->scalars.as<double>(), kslot, c->slots_R);
     else
         hipLaunchKernelGGL(k_grad<64>, dim3(nb), dim3(256), 0, c->stream, Graw, H,
                            (const double *)c->Mdev.as<double>(), (const double *)c->alphaDev.as<double>(),
                            scale, c->n, rpb, c->k, gout, d_for_dot, pdot, xupd,
-                           (const double *)c->scalars.as<double>());
+                           (const double *)c->scalars.as<double>(), kslot, c->slots_R);
+    if (kslot && d_for_dot) {
+        const dim3 gd((unsigned)nb, (unsigned)c->slots_R);
+        if (c->KP == 32)
+            hipLaunchKernelGGL(k_grad_dot_slots<32>, gd, dim3(256), 0, c->stream, (const double *)gout, d_for_dot,
+                               c->n, rpb, kslot, c->slots_R, part);
+        else
+            hipLaunchKernelGGL(k_grad_dot_slots<64>, gd, dim3(256), 0, c->stream, (const double *)gout, d_for_dot,
+                               c->n, rpb, kslot, c->slots_R, part);
+    }
     AA_CHECK_HIP(hipGetLastError());
     if (d_for_dot) {
         if (sp && stage_after >= 0 && !g_fuse_finalize) {
@@ -1945,12 +2200,13 @@ int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev)
 // 310,330 and the QP Hessian D C K C' D of :387), zero outside k x k
 __global__ __launch_bounds__(256) void k_scale_gram(double *__restrict__ dst,
                                                     const double *__restrict__ src,
-                                                    const double *__restrict__ alpha, int k, int KP)
+                                                    const double *__restrict__ alpha, int k, int KP, int kslot = 0)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= KP * KP) return;
     const int i = e / KP, j = e % KP;
-    dst[e] = (i < k && j < k) ? alpha[i] * src[e] * alpha[j] : 0.0;
+    // kslot > 0 (restarts side by side): the diagonal blocks only -- M is block diagonal
+    dst[e] = (i < k && j < k && (kslot == 0 || i / kslot == j / kslot)) ? alpha[i] * src[e] * alpha[j] : 0.0;
 }
 
 // 0.5 (tr K - 2 tr(D C K Z) + tr(D Z'Z D C K C')) / n   (archetypal_analysis.py:553-556),
@@ -1994,11 +2250,11 @@ __global__ __launch_bounds__(256) void k_aa_cost(const double *__restrict__ stat
     }
 }
 
-__global__ void k_set_scalars(double *__restrict__ sc, double trace, double fnorm)
+__global__ void k_set_scalars(double *__restrict__ sc, double trace, double fnorm, int R = 1)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        sc[SC_TRACE] = trace;
-        sc[SC_FNORM] = fnorm;
+    if ((int)threadIdx.x < R && blockIdx.x == 0) {      // R > 1: one scalar block per restart slot
+        sc[(size_t)threadIdx.x * AA_SC_STRIDE + SC_TRACE] = trace;
+        sc[(size_t)threadIdx.x * AA_SC_STRIDE + SC_FNORM] = fnorm;
     }
 }
 
@@ -2834,6 +3090,77 @@ int launch_gpnh_judge(Ctx *c, int it, double cost0, const double *costs, IterSta
     return AA_OK;
 }
 
+// AA restarts side by side: cost of slot blockIdx.x from the diagonal blocks of the Gram state
+// (k_aa_cost's arithmetic); what = 0: initial cost -> cost0[r]; what = 2: the cost after the weights
+// update -> the slot's record, then its judge (the iteration index is the record's)
+__global__ __launch_bounds__(256) void k_aa_cost_slots(const double *__restrict__ state,
+                                                       const double *__restrict__ alpha, int KP, double trace,
+                                                       double n_global, const double *__restrict__ scal,
+                                                       GpnhSlots sl, int what, double tol, double mono_tol,
+                                                       int criterion, int require)
+{
+    __shared__ double sm[256];
+    const int t = threadIdx.x, r = blockIdx.x, k = sl.k, o = r * k;
+    const size_t off = (size_t)o * KP + o;
+    const double *ZtZ = state + off, *CKCt = state + KP * KP + off, *CKZ = state + 2 * KP * KP + off;
+    const double *al = alpha + o;
+    double acc = 0.0;
+    for (int e = t; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        acc += al[i] * ZtZ[i * KP + j] * al[j] * CKCt[j * KP + i];
+    }
+    if (t < k) acc -= 2.0 * (al[t] * CKZ[t * KP + t]);
+    sm[t] = acc;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (t < q) sm[t] += sm[t + q];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double cost = 0.5 * (trace + sm[0]) / n_global;
+        if (what == 0) {
+            sl.cost0[r] = cost;
+        } else {
+            double *rec = sl.costs + (size_t)r * sl.stride;
+            int idx = sl.counters[r];
+            if (idx >= sl.stride) idx = sl.stride - 1;
+            rec[idx] = cost;
+            sl.counters[r] = idx + 1;
+            const int it = idx / 2;
+            iter_judge_thread0(it, sl.cost0[r], rec, &sl.st[r], tol, mono_tol, criterion, require, 1, 1,
+                               scal + (size_t)r * AA_SC_STRIDE, 1);
+            if (!sl.st[r].stop && it + 1 >= sl.max_outer) {
+                sl.st[r].stop = 1;
+                sl.st[r].stop_iter = it;
+            }
+        }
+    }
+}
+
+// the factors of every slot that has just stopped: its columns of C' and Z (both n x KP)
+__global__ __launch_bounds__(256) void k_aa_snap_slots(const double *__restrict__ Ct, double *__restrict__ snapC,
+                                                       const double *__restrict__ Zt, double *__restrict__ snapZ,
+                                                       long n_pad, int KP, const double *__restrict__ P,
+                                                       double *__restrict__ snapP, int ld, GpnhSlots sl)
+{
+    for (int r = 0; r < sl.R; ++r) {
+        const IterState st = sl.st[r];
+        const int it = sl.counters[r] / 2 - 1;
+        if (!st.stop || st.stop_iter != it) continue;
+        const int o = r * sl.k, k = sl.k;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n_pad * k; e += (long)gridDim.x * 256) {
+            const long row = e / k;
+            const int i = o + (int)(e % k);
+            snapC[row * KP + i] = Ct[row * KP + i];
+            snapZ[row * KP + i] = Zt[row * KP + i];
+        }
+        // C X as the loop carries it (P + lambda Q, update after update): what aa_get_archetypes returns
+        // when the loop stops on the last iteration of a batch (no restore, no recomputation)
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)k * ld; e += (long)gridDim.x * 256)
+            snapP[(long)o * ld + e] = P[(long)o * ld + e];
+    }
+}
+
 // ---- launchers of the slot kernels (solver.hip: aa_gpnh_slots_*)
 static GpnhSlots slots_of(Ctx *c)
 {
@@ -2847,6 +3174,26 @@ static GpnhSlots slots_of(Ctx *c)
     sl.cost0 = c->slotCost0.as<double>();
     sl.max_outer = c->slots_max_outer;
     return sl;
+}
+
+int launch_aa_cost_slots(Ctx *c, int what, const aa_iter_params *ip)
+{
+    hipLaunchKernelGGL(k_aa_cost_slots, dim3((unsigned)c->slots_R), dim3(256), 0, c->stream,
+                       (const double *)c->gramState.as<double>(), (const double *)c->alphaDev.as<double>(), c->KP,
+                       c->trace, (double)c->n_global, (const double *)c->scalars.as<double>(), slots_of(c), what,
+                       ip ? ip->tolerance : 0.0, ip ? ip->mono_tolerance : 0.0, ip ? ip->criterion : 0,
+                       ip ? ip->require_monotonic : 0);
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_aa_snap_slots(Ctx *c)
+{
+    hipLaunchKernelGGL(k_aa_snap_slots, dim3(256), dim3(256), 0, c->stream, (const double *)c->Ct.as<double>(),
+                       c->snapC.as<double>(), (const double *)c->Zt.as<double>(), c->snapZ.as<double>(), c->n_pad,
+                       c->KP, (const double *)c->P.as<double>(), c->slotSnapP.as<double>(), (int)c->p_pad, slots_of(c));
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
 }
 
 int launch_gpnh_solve_slots(Ctx *c, double lambda)
@@ -2890,7 +3237,7 @@ int launch_scale_gram(Ctx *c, double *dst, const double *src)
 {
     const int elems = c->KP * c->KP;
     hipLaunchKernelGGL(k_scale_gram, dim3((elems + 255) / 256), dim3(256), 0, c->stream, dst, src,
-                       (const double *)c->alphaDev.as<double>(), c->k, c->KP);
+                       (const double *)c->alphaDev.as<double>(), c->k, c->KP, c->slots_aa ? c->slots_k : 0);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
@@ -2911,7 +3258,8 @@ int launch_aa_cost(Ctx *c, double *out_dev, int *slot_counter_dev, const GpnhJud
 
 int launch_set_scalars(Ctx *c, double trace, double fnorm)
 {
-    hipLaunchKernelGGL(k_set_scalars, dim3(1), dim3(64), 0, c->stream, c->scalars.as<double>(), trace, fnorm);
+    hipLaunchKernelGGL(k_set_scalars, dim3(1), dim3(64), 0, c->stream, c->scalars.as<double>(), trace,
+                       c->slots_aa ? (double)c->slots_k : fnorm, c->slots_aa ? c->slots_R : 1);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
@@ -2949,6 +3297,15 @@ int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, i
         hipLaunchKernelGGL(k_gram_wide_pq<64>, dim3(nb), dim3(256), 0, c->stream,
                            (const double *)c->P.as<double>(), (const double *)c->Q.as<double>(),
                            (int)c->p_pad, part, cpb, c->k);
+    if (c->slots_aa) {
+        SlotRecords rec;
+        rec.costs = c->slotCosts.as<double>();
+        rec.stride = c->slots_stride;
+        rec.counters = c->slotCounters.as<int>();
+        hipLaunchKernelGGL(k_linesearch_fin_slots, dim3(1), dim3(1024), 0, c->stream, (const double *)part, nb, c->KP,
+                           c->gramOut.as<double>(), (const double *)c->Mdev.as<double>(), c->scalars.as<double>(),
+                           *sp, c->slots_k, c->slots_R, ckct, (double)c->n_global, rec);
+    } else
     hipLaunchKernelGGL(k_linesearch_fin, dim3(1), dim3(1024), 0, c->stream, (const double *)part, nb, c->KP,
                        c->gramOut.as<double>(), (const double *)c->Mdev.as<double>(),
                        c->scalars.as<double>(), *sp, c->k, ckct, (double)c->n_global, cost_out, cost_slot);
@@ -2958,6 +3315,14 @@ int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, i
 
 int launch_dict_setup(Ctx *c, const aa_spg_params *sp, double fnorm)
 {
+    if (c->slots_aa) {
+        hipLaunchKernelGGL(k_dict_setup_slots, dim3((unsigned)c->slots_R), dim3(256), 0, c->stream,
+                           (const double *)c->gramState.as<double>(), (const double *)c->alphaDev.as<double>(),
+                           c->slots_k, c->KP, c->trace, (double)c->slots_k, c->Mdev.as<double>(),
+                           c->gramOut.as<double>(), c->scalars.as<double>(), *sp);
+        AA_CHECK_HIP(hipGetLastError());
+        return AA_OK;
+    }
     hipLaunchKernelGGL(k_dict_setup, dim3(1), dim3(256), 0, c->stream,
                        (const double *)c->gramState.as<double>(), (const double *)c->alphaDev.as<double>(),
                        c->k, c->KP, c->trace, fnorm, c->Mdev.as<double>(), c->gramOut.as<double>(),
@@ -2972,11 +3337,13 @@ int launch_wide_axpy_lambda(Ctx *c, double *P, const double *Q, void *PT)
     dim3 grid((unsigned)((elems + 255) / 256));
     if (c->dtype == AA_F32)
         hipLaunchKernelGGL(k_wide_axpy<float>, grid, dim3(256), 0, c->stream, P, Q,
-                           c->scalars.as<double>(), elems, reinterpret_cast<float *>(PT));
+                           c->scalars.as<double>(), elems, reinterpret_cast<float *>(PT), (long)c->p_pad,
+                           c->slots_aa ? c->slots_k : 0, c->slots_R);
     else
         hipLaunchKernelGGL(k_wide_axpy<double>, grid, dim3(256), 0, c->stream, P, Q,
                            c->scalars.as<double>(), elems,
-                           (PT == (void *)P) ? (double *)nullptr : reinterpret_cast<double *>(PT));
+                           (PT == (void *)P) ? (double *)nullptr : reinterpret_cast<double *>(PT), (long)c->p_pad,
+                           c->slots_aa ? c->slots_k : 0, c->slots_R);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
@@ -3022,6 +3389,11 @@ int launch_transpose_tall_to_wide(Ctx *c, const double *tall, double *wide, void
 
 int launch_scalar_stage(Ctx *c, int stage, const aa_spg_params *sp, int cross2_is_transpose)
 {
+    if (c->slots_aa)
+        hipLaunchKernelGGL(k_scalar_stage, dim3((unsigned)c->slots_R), dim3(256), 0, c->stream, stage,
+                           c->scalars.as<double>(), c->gramOut.as<double>(), c->Mdev.as<double>(),
+                           c->slots_k, c->KP, *sp, cross2_is_transpose);
+    else
     hipLaunchKernelGGL(k_scalar_stage, dim3(1), dim3(256), 0, c->stream, stage,
                        c->scalars.as<double>(), c->gramOut.as<double>(), c->Mdev.as<double>(),
                        c->k, c->KP, *sp, cross2_is_transpose);

@@ -405,6 +405,13 @@ static int weights_update(Ctx *c, const aa_qp_params *qp, aa_qp_stats *stats)
     // Hessian D C K C' D (archetypal_analysis.py:387) and b-scale D are set up on the device
     const bool defer = g_qp_overlap_tail && c->form == AA_FORM_DATA;
     AA_CHECK(c->qpIters.alloc((size_t)c->n * sizeof(int)));
+    if (c->slots_aa) {                           // restarts side by side: one QP per sample and slot
+        AA_CHECK(launch_qp_slots_aa(c, qp));
+        c->qp_iters_valid = false;
+        AA_CHECK(refresh_after_weights(c));
+        AA_CHECK(join_side(c));
+        return AA_OK;
+    }
     AA_CHECK(launch_qp(c, nullptr, c->Gr.as<double>(), 1, c->KP, nullptr, c->Zt.as<double>(), c->KP, c->n,
                        c->k, qp, c->qpIters.as<int>(), stats, dev_CKCt(c), defer));
     c->qp_iters_valid = true;
@@ -603,7 +610,7 @@ int aa_ctx_destroy(aa_ctx *h)
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->rlPartial, &c->redPartial,
                      &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->iterState, &c->snapC, &c->snapZ, &c->snapAlpha, &c->qpIters, &c->qpPerm,
-                     &c->qpStats, &c->qpLive, &c->slotCosts, &c->slotCounters, &c->slotStates, &c->slotCost0, &c->tmpTall2, &c->redPartial2, &c->redOut2, &c->proj2, &c->projList2, &c->projSegCnt2};
+                     &c->qpStats, &c->qpLive, &c->slotCosts, &c->slotCounters, &c->slotStates, &c->slotCost0, &c->slotSnapP, &c->tmpTall2, &c->redPartial2, &c->redOut2, &c->proj2, &c->projList2, &c->projSegCnt2};
     for (DevBuf *b : all) b->release();
     if (c->evFork2) (void)hipEventDestroy(c->evFork2);
     if (c->evJoin2) (void)hipEventDestroy(c->evJoin2);
@@ -1409,6 +1416,228 @@ int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp,
         c->qp_iters_valid = false;
         AA_CHECK_HIP(hipStreamSynchronize(c->stream));
     }
+    return AA_OK;
+}
+
+// ------------------------------------------------------------------ AA restarts side by side
+// (bin/run_hadisst_aa.py:149-174).  R independent fits of k components each in the
+// component slots of ONE set of device arrays (restart r: columns [r k, (r + 1) k) of C' and Z): the
+// passes over X, the Gram kernels, the gradient kernel (block-diagonal M) and the column
+// projections are the single fit's launches on the stacked arrays -- an output column of theirs
+// depends on its own column only -- and everything that couples the components of a fit (the SPG
+// scalars, the line search, the QP Hessian, the cost, the judge) exists once per slot (ctx->slots_aa
+// makes the launchers pick those forms; dictionary_update / weights_update themselves are the
+// single fit's).  Every slot gets the bits it gets from aa_iterate on its own.  Production
+// settings only: data form, one SPG iteration per dictionary update, delta = 0, single rank,
+// at most 4096 samples (one-kernel threshold search, no sample ordering), k <= 16.
+int aa_slots_begin(aa_ctx *h, int R, int k, const aa_iter_params *ip, const aa_spg_params *spg,
+                   const aa_qp_params *qp)
+{
+    AA_REQUIRE(h && ip && spg && qp, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->have_data && c->form == AA_FORM_DATA && !c->linear_kernel, AA_ERR_STATE, "AA slots need a data matrix");
+    AA_REQUIRE(c->world <= 1 && !c->force_comm, AA_ERR_STATE, "restart slots are single-rank");
+    // R k <= 32: the tall kernels sum a column's rows in KP-dependent interleaved chains, so the slots
+    // must run the kernels a single fit of k <= 16 components runs (KP = 32) to get its bits
+    AA_REQUIRE(R >= 1 && k >= 1 && k <= 16 && R * k <= 32, AA_ERR_ARG,
+               "slots: R = %d restarts of k = %d components do not fit 32 component slots", R, k);
+    AA_REQUIRE(c->n <= 256L * 32 && c->n <= 4096, AA_ERR_ARG, "AA slots: at most 4096 samples");
+    AA_REQUIRE(ip->max_outer >= 1 && ip->update_dictionary && ip->update_weights && ip->delta == 0.0, AA_ERR_ARG,
+               "slots: both updates, delta = 0");
+    AA_REQUIRE(spg->max_iterations == 1 && spg->memory <= 16, AA_ERR_ARG, "slots: one SPG iteration per dictionary update");
+    AA_REQUIRE(g_fuse_finalize && g_proj_mode == 0 && g_proj_small, AA_ERR_STATE, "slots: default projection options");
+    c->slots_aa = false;
+    c->k = 0;                                         // fresh, zeroed factor arrays
+    AA_CHECK(ensure_problem(c, R * k));
+    AA_CHECK(ensure_trace(c));
+    for (int i = 0; i < c->k; ++i) c->alpha[i] = 1.0;
+    AA_CHECK(upload_alpha(c));
+    c->slots_R = R;
+    c->slots_k = k;
+    c->slots_max_outer = ip->max_outer;
+    c->slots_stride = 2 * ip->max_outer + 64;
+    c->slots_ip = *ip;
+    c->slots_sp = *spg;
+    c->slots_qp = *qp;
+    AA_CHECK(c->slotCosts.alloc((size_t)R * c->slots_stride * sizeof(double)));
+    AA_CHECK(c->slotCounters.alloc(64 * sizeof(int)));
+    AA_CHECK(c->slotStates.alloc(32 * sizeof(IterState)));
+    AA_CHECK(c->slotCost0.alloc(32 * sizeof(double)));
+    c->scalars.release();
+    AA_CHECK(c->scalars.alloc((size_t)(R + 1) * AA_SC_STRIDE * sizeof(double)));      // one block per slot
+    const size_t tall_bytes = (size_t)c->n_pad * c->KP * sizeof(double);
+    AA_CHECK(c->snapC.alloc(tall_bytes));
+    AA_CHECK(c->snapZ.alloc(tall_bytes));
+    AA_CHECK(c->slotSnapP.alloc((size_t)c->KP * c->p_pad * sizeof(double)));
+    AA_CHECK_HIP(hipMemset(c->snapC.p, 0, tall_bytes));
+    AA_CHECK_HIP(hipMemset(c->snapZ.p, 0, tall_bytes));
+    std::vector<IterState> st(32);
+    memset(st.data(), 0, st.size() * sizeof(IterState));
+    for (int r = 0; r < 32; ++r) st[r].stop = 1;      // empty
+    AA_CHECK_HIP(hipMemcpy(c->slotStates.p, st.data(), st.size() * sizeof(IterState), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(hipMemset(c->slotCounters.p, 0, 64 * sizeof(int)));
+    AA_CHECK_HIP(hipMemset(c->Ct.p, 0, tall_bytes));
+    AA_CHECK_HIP(hipMemset(c->Zt.p, 0, tall_bytes));
+    AA_CHECK_HIP(hipMemset(c->Mdev.p, 0, (size_t)c->KP * c->KP * sizeof(double)));
+    AA_CHECK_HIP(hipMemset(c->gramOut.p, 0, (size_t)4 * c->KP * c->KP * sizeof(double)));
+    c->slots_aa = true;
+    c->have_state = true;
+    c->grams_valid = false;
+    c->products_valid = false;
+    c->ckz_valid = false;
+    c->dict_inputs_overridden = false;
+    c->x_feasible = false;
+    c->qp_iters_valid = false;
+    for (int m = 0; m < 4; ++m) {                     // as aa_set_state: every fit starts its projections cold
+        c->projWarm[m] = c->projWarm2[m] = false;
+        c->projPassHint[m] = c->projPassHint2[m] = 0;
+        c->projListShort[m] = false;
+    }
+    c->slots_started = false;
+    return AA_OK;
+}
+
+// start factors of a restart into slot r (C: k x n, leading dimension ldc; Z: n x k), the products of
+// the stacked state rebuilt (aa_prepare's passes), the slot's initial cost
+int aa_slots_load(aa_ctx *h, int r, const double *C, long ldc, const double *Z)
+{
+    AA_REQUIRE(h && C && Z, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->slots_aa && r >= 0 && r < c->slots_R, AA_ERR_ARG, "slot %d out of range", r);
+    AA_REQUIRE(ldc >= c->n, AA_ERR_ARG, "ldc < n");
+    const int k = c->slots_k, o = r * k;
+    AA_CHECK(join_side(c));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    std::vector<double> ct((size_t)c->n * k);
+    for (long row = 0; row < c->n; ++row)
+        for (int i = 0; i < k; ++i) ct[(size_t)row * k + i] = C[(size_t)i * ldc + row];
+    AA_CHECK_HIP(hipMemcpy2D(c->Ct.as<double>() + o, (size_t)c->KP * sizeof(double), ct.data(), (size_t)k * sizeof(double),
+                             (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyHostToDevice));
+    AA_CHECK_HIP(hipMemcpy2D(c->Zt.as<double>() + o, (size_t)c->KP * sizeof(double), Z, (size_t)k * sizeof(double),
+                             (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyHostToDevice));
+    IterState zero;
+    memset(&zero, 0, sizeof(zero));
+    AA_CHECK_HIP(hipMemcpy(c->slotStates.as<IterState>() + r, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(hipMemset(c->slotCounters.as<int>() + r, 0, sizeof(int)));
+    c->products_valid = false;
+    c->grams_valid = false;
+    c->slots_started = false;
+    return AA_OK;
+}
+
+// n_iters outer iterations of every slot; status[R] out.  The first call after the loads prepares the
+// stacked state the way aa_set_state + aa_prepare prepare a single fit (all slots of a group start
+// together: the first dictionary update of a fit projects the caller's factors and recomputes the
+// products, later ones start from the previous update's -- a host-side choice that the slots share,
+// which is why a group is loaded as a whole and a finished slot waits for the others).
+int aa_slots_run(aa_ctx *h, int n_iters, aa_slot_status *status)
+{
+    AA_REQUIRE(h && status && n_iters >= 1, AA_ERR_ARG, "bad argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->slots_aa && c->slots_R > 0, AA_ERR_STATE, "aa_slots_begin first");
+    const int R = c->slots_R;
+    if (!c->slots_started) {
+        c->x_feasible = false;
+        AA_CHECK(prepare(c, nullptr));
+        AA_CHECK(launch_aa_cost_slots(c, 0, nullptr));
+        c->slots_started = true;
+    }
+    bool recorded = false;
+    for (int it = 0; it < n_iters; ++it) {
+        AA_CHECK(dictionary_update(c, &c->slots_sp, nullptr, true, c->slotCosts.as<double>(),
+                                   c->slotCounters.as<int>(), &recorded));
+        AA_REQUIRE(recorded, AA_ERR_STATE, "AA slots: the fused line search did not record the cost");
+        AA_CHECK(weights_update(c, &c->slots_qp, nullptr));
+        AA_CHECK(launch_aa_cost_slots(c, 2, &c->slots_ip));
+        AA_CHECK(launch_aa_snap_slots(c));
+    }
+    std::vector<IterState> st(R);
+    std::vector<int> cnt(R);
+    AA_CHECK_HIP(hipMemcpyAsync(st.data(), c->slotStates.p, (size_t)R * sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipMemcpyAsync(cnt.data(), c->slotCounters.p, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < R; ++r) {
+        status[r].stop = st[r].stop;
+        status[r].converged = st[r].converged;
+        status[r].error_stage = st[r].error_stage;
+        status[r].stop_iter = st[r].stop_iter;
+        status[r].not_spd = st[r].spg_flags;          // AA: the SPG warning flags of the slot
+        status[r].iterations_run = cnt[r] / 2;
+    }
+    return AA_OK;
+}
+
+// every slot has stopped: the factors of the stopping iterations back into the working arrays and the
+// products rebuilt from them (what aa_iterate does for a fit that ran past its stopping iteration)
+int aa_slots_finish(aa_ctx *h)
+{
+    AA_REQUIRE(h, AA_ERR_ARG, "null ctx");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->slots_aa && c->slots_started, AA_ERR_STATE, "nothing to finish");
+    AA_CHECK(join_side(c));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    const size_t tall_bytes = (size_t)c->n_pad * c->KP * sizeof(double);
+    AA_CHECK_HIP(hipMemcpy(c->Ct.p, c->snapC.p, tall_bytes, hipMemcpyDeviceToDevice));
+    AA_CHECK_HIP(hipMemcpy(c->Zt.p, c->snapZ.p, tall_bytes, hipMemcpyDeviceToDevice));
+    c->products_valid = false;
+    c->grams_valid = false;
+    AA_CHECK(prepare(c, nullptr));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return AA_OK;
+}
+
+// factors (C: k x n with leading dimension ldc, Z: n x k), C X (k x p, leading dimension ldx: recomputed
+// from the fetched C after aa_slots_finish, or -- carried != 0 -- as the loop carried it at the stopping
+// iteration), cost record and initial cost of a stopped slot
+int aa_slots_fetch(aa_ctx *h, int r, double *C, long ldc, double *Z, double *CX, long ldx, int carried,
+                   double *costs, double *cost0)
+{
+    AA_REQUIRE(h && C && Z && costs && cost0 && CX, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->slots_aa && r >= 0 && r < c->slots_R, AA_ERR_ARG, "slot %d out of range", r);
+    AA_REQUIRE(ldc >= c->n, AA_ERR_ARG, "ldc < n");
+    AA_CHECK(join_side(c));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    IterState st;
+    AA_CHECK_HIP(hipMemcpy(&st, c->slotStates.as<IterState>() + r, sizeof(st), hipMemcpyDeviceToHost));
+    AA_REQUIRE(st.stop, AA_ERR_STATE, "slot %d has not stopped", r);
+    const int k = c->slots_k, o = r * k;
+    std::vector<double> ct((size_t)c->n * k);
+    AA_CHECK_HIP(hipMemcpy2D(ct.data(), (size_t)k * sizeof(double), c->snapC.as<double>() + o, (size_t)c->KP * sizeof(double),
+                             (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyDeviceToHost));
+    for (long row = 0; row < c->n; ++row)
+        for (int i = 0; i < k; ++i) C[(size_t)i * ldc + row] = ct[(size_t)row * k + i];
+    AA_CHECK_HIP(hipMemcpy2D(Z, (size_t)k * sizeof(double), c->snapZ.as<double>() + o, (size_t)c->KP * sizeof(double),
+                             (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(hipMemcpy(costs, c->slotCosts.as<double>() + (size_t)r * c->slots_stride,
+                           (size_t)2 * (st.stop_iter + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(hipMemcpy(cost0, c->slotCost0.as<double>() + r, sizeof(double), hipMemcpyDeviceToHost));
+    AA_REQUIRE(ldx >= c->p, AA_ERR_ARG, "ldx < p");
+    const double *src = (carried ? c->slotSnapP.as<double>() : c->P.as<double>()) + (size_t)o * c->p_pad;
+    AA_CHECK_HIP(hipMemcpy2D(CX, (size_t)ldx * sizeof(double), src, (size_t)c->p_pad * sizeof(double),
+                             (size_t)c->p * sizeof(double), (size_t)k, hipMemcpyDeviceToHost));
+    return AA_OK;
+}
+
+// leaves the slot mode (the context can be used for single fits again)
+int aa_slots_end(aa_ctx *h)
+{
+    AA_REQUIRE(h, AA_ERR_ARG, "null ctx");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_CHECK(join_side(c));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    c->slots_aa = false;
+    c->slots_R = 0;
+    c->k = 0;                                         // the next aa_set_state sizes the arrays afresh
+    c->have_state = false;
+    c->grams_valid = false;
+    c->products_valid = false;
     return AA_OK;
 }
 

@@ -641,6 +641,49 @@ def test_gpnh_restarts_side_by_side(cdr, orc, case):
     assert best == int(np.argmin([m.cost for m in seq]))
 
 
+@pytest.mark.parametrize("case", ["stopping_rule", "iteration_cap", "float32", "furthest_sum"])
+def test_aa_restarts_side_by_side(cdr, orc, case):
+    """fit_restarts on ArchetypalAnalysis models with the drivers' settings (bin/run_hadisst_aa.py:149-174:
+    one SPG iteration per dictionary update, delta = 0): groups of 32 // k restarts sit side by side in
+    the component slots of ONE set of device arrays (aa_slots_*) -- the passes over X, the Gram kernels,
+    the gradient kernel (block-diagonal M) and the column projections are the single fit's launches,
+    the SPG scalars, the line search, the QP Hessian, the cost and the judge exist once per slot.
+    Restart by restart -- cost, n_iter, cost deltas, weights, dictionary, archetypes -- the result is
+    the sequential loop's, bit for bit (14 restarts of k = 5: three groups, the last one partial)."""
+    import warnings
+    from convex_dim_red import restarts
+    rng = np.random.RandomState(31)
+    n, p, k, n_init = 900, 260, 5, 14
+    B = rng.standard_normal((k, p))
+    Zt = orc.right_stochastic_matrix((n, k), rng) ** 4
+    Zt /= Zt.sum(axis=1, keepdims=True)
+    X = Zt.dot(B) + 0.05 * rng.standard_normal((n, p))
+    dtype = "float32" if case == "float32" else "float64"
+    if dtype == "float32":
+        X = X.astype(np.float32)
+    kw = dict(init="furthest_sum" if case == "furthest_sum" else "random", tolerance=1e-5, max_iterations=500,
+              dtype=dtype, dictionary_solver_kwargs=dict(max_iterations=1))
+    if case == "iteration_cap":
+        kw.update(tolerance=0, max_iterations=11, require_monotonic_cost_decrease=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        shared = np.random.RandomState(6)
+        seq = []
+        for _ in range(n_init):
+            m = cdr.ArchetypalAnalysis(k, random_state=shared, **kw)
+            m.fit_transform(X)
+            seq.append(m)
+        shared = np.random.RandomState(6)
+        models, best = cdr.fit_restarts(lambda: cdr.ArchetypalAnalysis(k, random_state=shared, **kw), X, n_init)
+    assert restarts.slots_profile["slots"] == 6                       # the slots path ran, 32 // 5 at a time
+    for a, b in zip(seq, models):
+        assert a.cost == b.cost and a.n_iter == b.n_iter
+        assert list(a.cost_deltas) == list(b.cost_deltas)
+        assert np.array_equal(a.weights, b.weights) and np.array_equal(a.dictionary, b.dictionary)
+        assert np.array_equal(a.archetypes, b.archetypes) and np.array_equal(a.alpha, b.alpha)
+    assert best == int(np.argmin([m.cost for m in seq]))
+
+
 def test_gpnh_slot_with_singular_normal_equations_goes_to_the_sequential_path(cdr, orc):
     """A start whose weights have an all-zero column (lambda_W = 0: no Cholesky factor) is reported
     by its slot and left to the sequential path, which solves with lstsq like the reference

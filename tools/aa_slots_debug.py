@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Where does a slot of an AA group leave the single fit?  Cost records (after the dictionary update,
+after the weights update, per outer iteration) of one group of restarts against aa_iterate on each
+start alone."""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_R, "matrix-factorization-case-studies_amd"))
+sys.path.insert(0, _R)
+import convex_dim_red as cdr  # noqa: E402
+from convex_dim_red import _backend  # noqa: E402
+from oracle import aa_oracle as orc  # noqa: E402
+
+warnings.simplefilter("ignore")
+n, p, k = 1610, 25000, 5
+rng = np.random.RandomState(0)
+B = rng.standard_normal((k, p))
+Zt = orc.right_stochastic_matrix((n, k), rng) ** 4
+Zt /= Zt.sum(axis=1, keepdims=True)
+X = Zt.dot(B) + 0.05 * rng.standard_normal((n, p))
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+T = 24
+shared = np.random.RandomState(0)
+starts = []
+for _ in range(R):
+    m = cdr.ArchetypalAnalysis(k, init="random", tolerance=0, max_iterations=T, random_state=shared,
+                               dictionary_solver_kwargs=dict(max_iterations=1), require_monotonic_cost_decrease=False)
+    C0, Z0, a0 = m._aa(X, _draw_only=True)
+    starts.append((C0, Z0))
+dkw, qkw = dict(max_iterations=1), {}
+single = []
+with _backend.Context(dtype="float64") as ctx:
+    ctx.set_data(X)
+    for C0, Z0 in starts:
+        ctx.set_state(C0, Z0, np.ones(k))
+        c0 = ctx.prepare()
+        costs, st = ctx.iterate(c0, T, 0.0, "abs_delta_f", False, True, True, dkw, qkw)
+        single.append((c0, np.asarray(costs)))
+with _backend.Context(dtype="float64") as ctx:
+    ctx.set_data(X)
+    ctx.aa_slots_begin(R, k, T, 0.0, "abs_delta_f", False, dkw, qkw)
+    for r, (C0, Z0) in enumerate(starts):
+        ctx.aa_slots_load(r, C0, Z0)
+    for _ in range(T // 8):
+        status = ctx.aa_slots_run(8)
+    ctx.aa_slots_finish()
+    for r in range(R):
+        Z, C, CX, c0, costs = ctx.aa_slots_fetch(r, status[r].stop_iter, False)
+        a0, ac = single[r]
+        m = min(len(ac), len(costs))
+        diff = np.nonzero(ac[:m] != costs[:m])[0]
+        print("slot %2d: cost0 equal %s; records equal up to index %s of %d (index 2t: after the dictionary update of iteration t, 2t+1: after the weights update)%s"
+              % (r, a0 == c0, diff[0] if len(diff) else "all", m,
+                 "  single %.17g slots %.17g" % (ac[diff[0]], costs[diff[0]]) if len(diff) else ""), flush=True)
+    ctx.aa_slots_end()
