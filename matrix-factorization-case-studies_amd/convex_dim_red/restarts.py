@@ -232,9 +232,12 @@ def fit_restarts(make_model, data, n_init, n_jobs=None, devices=None, side_by_si
     ``devices``: GPU indices the worker threads are dealt over (default: the current one); the data
     matrix is uploaded ONCE per device and the workers of a device share that copy
     (``aa_share_data``), each with its own factors, streams and scratch.
-    ``side_by_side`` (GPNH models with the same hyper-parameters, k <= 16, one device): the restarts
-    run ``n_slots`` (default 64 // k) at a time in ONE set of device arrays and share every launch of
-    an outer iteration (``_fit_gpnh_slots``); ``n_jobs`` is not used then.
+    ``side_by_side`` (models with the same hyper-parameters; GPNH with k <= 16, AA with the drivers'
+    settings -- one SPG iteration per dictionary update, delta = 0, at most 4096 samples, k <= 16):
+    the restarts run ``n_slots`` at a time (default: 64 // k for GPNH, 32 // k for AA) in ONE set of
+    device arrays per device and share every launch of an outer iteration (``_fit_gpnh_slots``,
+    ``_fit_aa_slots``); with several ``devices`` restart i runs on device i mod G; ``n_jobs`` is not
+    used then.
     Returns ``(models, best)``: the fitted models in restart order and the index of the first one
     with the lowest cost (the model the drivers' ``if cost < best_cost`` loop keeps)."""
     data = np.asarray(data)
@@ -254,15 +257,27 @@ def fit_restarts(make_model, data, n_init, n_jobs=None, devices=None, side_by_si
     _backend.release_device_cache()               # the workers bring their own contexts
     devices = [_backend.device_index()] if devices is None else [int(d) for d in devices]
     todo = list(range(n_init))
-    if side_by_side and len(devices) == 1 and _aa_slots_eligible(models, data):
-        # AA: groups of restarts share the launches of every outer iteration (aa_slots_*)
-        todo = _fit_aa_slots(models, starts, data, devices[0], n_slots=n_slots)
-        if not todo:
-            costs = [m.cost for m in models]
-            return models, int(np.argmin(costs))
-    if side_by_side and len(devices) == 1 and _slots_eligible(models):
-        # GPNH: the restarts share the launches of every outer iteration (aa_gpnh_slots_*)
-        todo = _fit_gpnh_slots(models, starts, data, devices[0], n_slots=n_slots)
+    slot_fit = None
+    if side_by_side and _aa_slots_eligible(models, data):
+        slot_fit = _fit_aa_slots          # AA: groups of restarts share every launch (aa_slots_*)
+    elif side_by_side and _slots_eligible(models):
+        slot_fit = _fit_gpnh_slots        # GPNH: slots refilled as restarts stop (aa_gpnh_slots_*)
+    if slot_fit is not None:
+        # the restarts are dealt over the devices (restart i on device i mod G), every device runs its
+        # share side by side on its own copy of the data; no collective anywhere
+        shares = [list(range(d, n_init, len(devices))) for d in range(len(devices))]
+        shares = [sh for sh in shares if sh]
+
+        def on_device(d):
+            idx = shares[d]
+            left = slot_fit([models[i] for i in idx], [starts[i] for i in idx], data, devices[d], n_slots=n_slots)
+            return [idx[j] for j in left]
+
+        if len(shares) == 1:
+            todo = on_device(0)
+        else:
+            with ThreadPoolExecutor(max_workers=len(shares)) as pool:
+                todo = sorted(i for left in pool.map(on_device, range(len(shares))) for i in left)
         if not todo:
             costs = [m.cost for m in models]
             return models, int(np.argmin(costs))

@@ -684,6 +684,37 @@ def test_aa_restarts_side_by_side(cdr, orc, case):
     assert best == int(np.argmin([m.cost for m in seq]))
 
 
+@pytest.mark.parametrize("family", ["aa", "gpnh"])
+def test_restarts_side_by_side_over_devices(cdr, orc, family):
+    """devices=[...]: restart i goes to device i mod G and every device runs its share side by side
+    (two contexts on the one GPU of the development box stand in for two devices): same results as on
+    one device, restart by restart."""
+    import warnings
+    rng = np.random.RandomState(17)
+    n, p, k, n_init = 700, 60, 4, 9
+    X = orc.right_stochastic_matrix((n, k), rng).dot(rng.standard_normal((k, p))) + 0.1 * rng.standard_normal((n, p))
+    if family == "aa":
+        def make(rs):
+            return cdr.ArchetypalAnalysis(k, init="random", tolerance=1e-5, max_iterations=300, random_state=rs,
+                                          dictionary_solver_kwargs=dict(max_iterations=1))
+    else:
+        def make(rs):
+            return cdr.GPNHConvexCoding(k, lambda_W=0.3, init="random", tolerance=1e-5, max_iterations=300,
+                                        random_state=rs, stopping_criterion="rel_delta_f",
+                                        weights_solver_kwargs=dict(max_iterations=1))
+    runs = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for devices in ([0], [0, 0]):
+            shared = np.random.RandomState(2)
+            models, best = cdr.fit_restarts(lambda: make(shared), X, n_init, devices=devices)
+            runs.append((models, best))
+    assert runs[0][1] == runs[1][1]
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert a.cost == b.cost and a.n_iter == b.n_iter
+        assert np.array_equal(a.weights, b.weights) and np.array_equal(a.dictionary, b.dictionary)
+
+
 def test_gpnh_slot_with_singular_normal_equations_goes_to_the_sequential_path(cdr, orc):
     """A start whose weights have an all-zero column (lambda_W = 0: no Cholesky factor) is reported
     by its slot and left to the sequential path, which solves with lstsq like the reference
