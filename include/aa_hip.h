@@ -388,18 +388,25 @@ int aa_gpnh_slots_run(aa_ctx *ctx, int n_iters, aa_slot_status *status);
 int aa_gpnh_slots_fetch(aa_ctx *ctx, int r, double *Wt, long ld, double *Z, double *costs, double *cost0);
 
 /* The same for archetypal analysis (bin/run_hadisst_aa.py:149-174; archetypal_analysis.py:534-670 per
- * restart): R fits of k components in the component slots of one set of arrays, production settings
- * only (data form, one SPG iteration per dictionary update, delta = 0, at most 4096 samples, k <= 16,
- * single rank).  A GROUP of restarts is loaded as a whole (aa_slots_begin, aa_slots_load x R), iterated
- * until every slot has stopped (aa_slots_run: a stopped slot's factors are kept while the others go on),
- * finished (aa_slots_finish) and fetched (C X: recomputed from the fetched C, or -- carried != 0 -- as the
- * loop carried it at the stopping iteration, which is what aa_get_archetypes returns after an aa_iterate
- * that stopped on the last iteration of a batch); aa_slots_end returns the context to single fits.  status[r].not_spd carries the slot's
- * SPG warning flags (AA_SPG_FLAG_*).  Every restart gets the bits aa_iterate gives it on its own. */
+ * restart): R fits of k components in the component slots of one set of arrays (R k <= 32), production
+ * settings only (data form, one SPG iteration per dictionary update, delta = 0, at most 4096 samples,
+ * k <= 16, single rank).  aa_slots_begin + aa_slots_load x R start the first restarts together;
+ * aa_slots_run iterates every slot and reports its status (a stopped slot's factors of that iteration
+ * are kept while the others go on); aa_slots_fetch returns a stopped slot's factors, cost record and
+ * C X -- recomputed from the fetched C, or (carried != 0) as the loop carried it at the stopping
+ * iteration, which is what aa_get_archetypes returns after an aa_iterate that stopped on the last
+ * iteration of a batch; aa_slots_reload puts the next restart into the freed slot (its first dictionary
+ * update is the cold one of a fit, the running slots keep the products they carry); aa_slots_finish
+ * (optional, all slots stopped) restores the stopping-iteration factors and rebuilds the products;
+ * aa_slots_end returns the context to single fits.  status[r].not_spd carries the slot's SPG warning
+ * flags (AA_SPG_FLAG_*).  Every restart gets the bits aa_iterate gives it on its own. */
 int aa_slots_begin(aa_ctx *ctx, int R, int k, const aa_iter_params *loop, const aa_spg_params *spg,
                    const aa_qp_params *qp);
 int aa_slots_load(aa_ctx *ctx, int r, const double *C, long ldc, const double *Z);
 int aa_slots_run(aa_ctx *ctx, int n_iters, aa_slot_status *status);
+/* a new restart into slot r of a RUNNING group (its previous occupant has stopped and been fetched): the
+ * other slots keep the products they carry; the slot's next dictionary update is the cold one of a fit */
+int aa_slots_reload(aa_ctx *ctx, int r, const double *C, long ldc, const double *Z);
 int aa_slots_finish(aa_ctx *ctx);     /* all slots stopped: stopping-iteration factors restored, products rebuilt */
 int aa_slots_fetch(aa_ctx *ctx, int r, double *C, long ldc, double *Z, double *CX, long ldx, int carried,
                    double *costs, double *cost0);

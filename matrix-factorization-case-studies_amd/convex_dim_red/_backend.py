@@ -148,6 +148,7 @@ _SIGNATURES = {
                                       ctypes.POINTER(SPGParams), ctypes.POINTER(QPParams)]),
     "aa_slots_load": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp]),
     "aa_slots_run": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(SlotStatus)]),
+    "aa_slots_reload": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp]),
     "aa_slots_finish": (ctypes.c_int, [_vp]),
     "aa_slots_fetch": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_int,
                                       _dp, _dp]),
@@ -665,6 +666,10 @@ class Context(object):
     def aa_slots_load(self, r, C, Z):
         C, Z = _c64(C), _c64(Z)
         _check(self.lib.aa_slots_load(self.h, int(r), _ptr(C), C.shape[1], _ptr(Z)))
+
+    def aa_slots_reload(self, r, C, Z):
+        C, Z = _c64(C), _c64(Z)
+        _check(self.lib.aa_slots_reload(self.h, int(r), _ptr(C), C.shape[1], _ptr(Z)))
 
     def aa_slots_run(self, n_iters):
         st = (SlotStatus * self._slots[0])()

@@ -151,11 +151,10 @@ def _aa_slots_eligible(models, data):
 
 
 def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
-    """Groups of up to 32 // k AA restarts side by side in ONE set of device arrays (aa_slots_*): every
-    launch of an outer iteration serves the whole group; a restart that stops keeps its factors of that
-    iteration while the rest of its group goes on (a group starts together: the first dictionary update
-    of a fit differs from the later ones).  Restart by restart the result is the sequential loop's,
-    bit for bit."""
+    """Up to 32 // k AA restarts side by side in ONE set of device arrays (aa_slots_*): every launch of
+    an outer iteration serves all of them; a restart that stops is taken out and the next pending one
+    takes its slot (its first dictionary update is the cold one of a fit while the others carry on:
+    aa_slots_reload).  Restart by restart the result is the sequential loop's, bit for bit."""
     import time
     import warnings
     from .archetypal_analysis import _warn_from_spg_flags, _DEVICE_LOOP_BATCH
@@ -177,45 +176,56 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
         mono_tol = m0.tolerance
         if ctx.dtype_code == _backend.AA_F32:
             mono_tol = max(m0.tolerance, 8 * 6e-8 * ctx.data_trace() / n_samples)
-        for g0 in range(0, len(models), n_slots):
-            group = list(range(g0, min(g0 + n_slots, len(models))))
+        pending = list(range(len(models)))
+        owner = [None] * n_slots
+        loaded_at = [0.0] * n_slots
+        t0 = time.perf_counter()
+        ctx.aa_slots_begin(n_slots, k, m0.max_iterations, m0.tolerance, m0.stopping_criterion,
+                           m0.require_monotonic_cost_decrease, m0.dictionary_solver_kwargs,
+                           m0.weights_solver_kwargs, mono_tolerance=mono_tol)
+        for r in range(n_slots):                  # the first group starts together
+            i = pending.pop(0)
+            ctx.aa_slots_load(r, starts[i]["dictionary"], starts[i]["weights"])
+            owner[r] = i
+            loaded_at[r] = time.perf_counter()
+        prof["load"] += time.perf_counter() - t0
+        while any(o is not None for o in owner):
             t0 = time.perf_counter()
-            ctx.aa_slots_begin(len(group), k, m0.max_iterations, m0.tolerance, m0.stopping_criterion,
-                               m0.require_monotonic_cost_decrease, m0.dictionary_solver_kwargs,
-                               m0.weights_solver_kwargs, mono_tolerance=mono_tol)
-            for r, i in enumerate(group):
-                ctx.aa_slots_load(r, starts[i]["dictionary"], starts[i]["weights"])
-            t1 = time.perf_counter()
-            prof["load"] += t1 - t0
-            while True:
-                status = ctx.aa_slots_run(poll_every)
-                prof["polls"] += 1
-                if all(st.stop for st in status):
-                    break
-            t2 = time.perf_counter()
-            prof["run"] += t2 - t1
-            ctx.aa_slots_finish()
-            ran = max(max(st.iterations_run for st in status), 1)
-            for r, i in enumerate(group):
-                st, m = status[r], models[i]
+            status = ctx.aa_slots_run(poll_every)
+            prof["run"] += time.perf_counter() - t0
+            prof["polls"] += 1
+            for r, st in enumerate(status):
+                i = owner[r]
+                if i is None or not st.stop:
+                    continue
+                m = models[i]
+                t0 = time.perf_counter()
                 _warn_from_spg_flags(_Flags(st.not_spd))
                 if st.error_stage:
                     errors[i] = RuntimeError('factorization cost increased after {} update'.format(
                         {1: 'dictionary', 2: 'weights', 3: 'scale factors'}[st.error_stage]))
-                    continue
-                # aa_iterate rebuilds the products only when it ran past the stopping iteration
-                carried = (st.stop_iter + 1) % _DEVICE_LOOP_BATCH == 0 or st.stop_iter + 1 == m.max_iterations
-                Z, C, CX, cost0, costs = ctx.aa_slots_fetch(r, st.stop_iter, carried)
-                finals = costs[1::2]
-                begins = np.concatenate(([cost0], finals[:-1]))
-                m.weights, m.dictionary, m.alpha = Z, C, np.ones(k)
-                m.cost, m.n_iter = float(finals[-1]), int(st.stop_iter)
-                m.cost_deltas = [d for d in finals - begins]
-                m.avg_time_per_iter = (t2 - t1) / ran
-                m.archetypes = CX
-                if m.n_iter == m.max_iterations and m.tolerance > 0:
-                    warnings.warn('Maximum number of iterations %d reached.' % m.max_iterations, UserWarning)
-            prof["fetch"] += time.perf_counter() - t2
+                else:
+                    # aa_iterate rebuilds the products only when it ran past the stopping iteration
+                    carried = (st.stop_iter + 1) % _DEVICE_LOOP_BATCH == 0 or st.stop_iter + 1 == m.max_iterations
+                    Z, C, CX, cost0, costs = ctx.aa_slots_fetch(r, st.stop_iter, carried)
+                    finals = costs[1::2]
+                    begins = np.concatenate(([cost0], finals[:-1]))
+                    m.weights, m.dictionary, m.alpha = Z, C, np.ones(k)
+                    m.cost, m.n_iter = float(finals[-1]), int(st.stop_iter)
+                    m.cost_deltas = [d for d in finals - begins]
+                    m.avg_time_per_iter = (time.perf_counter() - loaded_at[r]) / max(st.iterations_run, 1)
+                    m.archetypes = CX
+                    if m.n_iter == m.max_iterations and m.tolerance > 0:
+                        warnings.warn('Maximum number of iterations %d reached.' % m.max_iterations, UserWarning)
+                prof["fetch"] += time.perf_counter() - t0
+                owner[r] = None
+                if pending:
+                    t0 = time.perf_counter()
+                    i = pending.pop(0)
+                    ctx.aa_slots_reload(r, starts[i]["dictionary"], starts[i]["weights"])
+                    owner[r] = i
+                    loaded_at[r] = time.perf_counter()
+                    prof["load"] += loaded_at[r] - t0
         ctx.aa_slots_end()
     finally:
         ctx.close()

@@ -152,6 +152,11 @@ struct Ctx {
     // AA restarts side by side (aa_slots_*): the launchers of the coupled steps pick their per-slot
     // forms while this is set; per-slot SPG scalars [R][AA_SC_STRIDE]
     bool slots_aa = false, slots_started = false;
+    unsigned slots_cold = 0;                   // slots loaded since the last iteration: their next dictionary
+                                               // update is the cold one of a fit (projection of the caller's
+                                               // factors, products recomputed); slots_cold_cols: their columns
+    unsigned slots_cold_cols = 0xffffffffu;
+    DevBuf slotSaveP, slotSaveGr;              // C X and (C X X')' of the running slots across a reload
     DevBuf slotScal, slotSnapP;
     aa_iter_params slots_ip;
     aa_spg_params slots_sp;
@@ -278,7 +283,7 @@ int launch_transpose_wide_to_tall(Ctx *c, const double *wide, double *tall); // 
 int launch_transpose_tall_to_wide(Ctx *c, const double *tall, double *wide, void *wideT);
 int launch_scalar_stage(Ctx *c, int stage, const aa_spg_params *sp, int it);
 int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, int *cost_slot);
-int launch_dict_setup(Ctx *c, const aa_spg_params *sp, double fnorm);
+int launch_dict_setup(Ctx *c, const aa_spg_params *sp, double fnorm, unsigned slotmask = 0xffffffffu);
 int launch_iter_judge(Ctx *c, int it, double cost0, const double *costs, IterState *st,
                       const aa_iter_params *ip, bool judged = false);
 int launch_cost_carry(Ctx *c, double *costs, int *slot, double cost0);

@@ -146,7 +146,8 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_finish(int mode, const double 
                                                      long rows_pb, int k,
                                                      const ProjState *__restrict__ ps,
                                                      double *__restrict__ out,
-                                                     double *__restrict__ partial, int kslot = 0)
+                                                     double *__restrict__ partial, int kslot = 0,
+                                                     unsigned colmask = 0xffffffffu)
 {
     __shared__ double sm[4 * PROJ_NT];
     constexpr int RS = PROJ_NT / KP;
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_finish(int mode, const double 
             const double w = g ? xe - a * ge : xe;
             const double pr = fmax(w - th, 0.0);
             if (mode == PROJ_FEAS) {
-                out[e] = pr;
+                // (restart slots: only the columns of freshly loaded slots are projected -- colmask)
+                if ((colmask >> (comp & 31)) & 1u) out[e] = pr;
             } else {
                 const double d = pr - xe;
                 if (mode == PROJ_DIR) {
@@ -1639,10 +1641,11 @@ __global__ __launch_bounds__(256) void k_dict_setup_slots(const double *__restri
                                                           const double *__restrict__ alpha, int k, int KP,
                                                           double trace, double fnorm, double *__restrict__ Mout,
                                                           double *__restrict__ gram, double *__restrict__ scal,
-                                                          aa_spg_params sp)
+                                                          aa_spg_params sp, unsigned slotmask)
 {
     __shared__ double sm[256];
     const int GS = KP * KP, t = threadIdx.x, r = blockIdx.x, o = r * k;
+    if (!((slotmask >> r) & 1u)) return;
     const size_t off = (size_t)o * KP + o;
     const double *ZtZ = state + off, *CKCt = state + GS + off, *CKZ = state + 2 * GS + off;
     const double *al = alpha + o;
@@ -2058,7 +2061,8 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     if (mode == PROJ_DIR) out = c->Dt.as<double>();
     TALL_DISPATCH_NT(PROJ_NT, k_proj_finish, mode, x, g, a_const, (const double *)scal, a_slot,
                   (const double *)c->H.as<double>(), (const double *)c->alphaDev.as<double>(), c->n, rpb,
-                  c->k, (const ProjState *)ps, out, part, c->slots_aa ? c->slots_k : 0);
+                  c->k, (const ProjState *)ps, out, part, c->slots_aa ? c->slots_k : 0,
+                  (c->slots_aa && mode == PROJ_FEAS) ? c->slots_cold_cols : 0xffffffffu);
     if (sp && stage_after >= 0 && !g_fuse_finalize) {
         AA_CHECK(finalize_and_post(c, 4, 8u, POST_FIN, mode, 0, false));
         AA_CHECK(launch_scalar_stage(c, stage_after, sp, 0));
@@ -3313,13 +3317,13 @@ int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, i
     return AA_OK;
 }
 
-int launch_dict_setup(Ctx *c, const aa_spg_params *sp, double fnorm)
+int launch_dict_setup(Ctx *c, const aa_spg_params *sp, double fnorm, unsigned slotmask)
 {
     if (c->slots_aa) {
         hipLaunchKernelGGL(k_dict_setup_slots, dim3((unsigned)c->slots_R), dim3(256), 0, c->stream,
                            (const double *)c->gramState.as<double>(), (const double *)c->alphaDev.as<double>(),
                            c->slots_k, c->KP, c->trace, (double)c->slots_k, c->Mdev.as<double>(),
-                           c->gramOut.as<double>(), c->scalars.as<double>(), *sp);
+                           c->gramOut.as<double>(), c->scalars.as<double>(), *sp, slotmask);
         AA_CHECK_HIP(hipGetLastError());
         return AA_OK;
     }

@@ -261,6 +261,35 @@ static int prepare(Ctx *c, double *cost)
     return AA_OK;
 }
 
+// ----------------------------------------------------------------- restart slots: mixed cold / warm groups
+// A slot that has just been loaded (slots_cold) goes through the COLD dictionary update of a fit --
+// factors projected, C X, (C X)(C X)' and C X X' recomputed -- while the other slots of the group
+// are in the middle of theirs and must keep the products they carry (C X is updated as P + lambda Q:
+// recomputing it gives other bits).  The recomputing kernels run on the stacked arrays; these
+// helpers put the warm slots' parts back afterwards.
+static unsigned slots_all_mask(const Ctx *c) { return c->slots_R >= 32 ? 0xffffffffu : ((1u << c->slots_R) - 1u); }
+static bool slots_mixed(const Ctx *c) { return c->slots_aa && c->slots_cold != 0 && c->slots_cold != slots_all_mask(c); }
+
+static int slots_save_P(Ctx *c)
+{
+    const size_t wide = (size_t)c->KP * c->p_pad * sizeof(double);
+    AA_CHECK(c->slotSaveP.alloc(wide));
+    AA_CHECK_HIP(hipMemcpyAsync(c->slotSaveP.p, c->P.p, wide, hipMemcpyDeviceToDevice, c->stream));
+    return AA_OK;
+}
+static int slots_restore_P_warm(Ctx *c)
+{
+    const int k = c->slots_k;
+    for (int r = 0; r < c->slots_R; ++r) {
+        if ((c->slots_cold >> r) & 1u) continue;
+        const size_t off = (size_t)r * k * c->p_pad;
+        AA_CHECK_HIP(hipMemcpyAsync(c->P.as<double>() + off, c->slotSaveP.as<double>() + off,
+                                    (size_t)k * c->p_pad * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (c->dtype == AA_F32) AA_CHECK(launch_wide_to_T(c, c->P.as<double>(), operandT(c, c->P, c->Pw)));
+    return AA_OK;
+}
+
 // ----------------------------------------------------------------- dictionary SPG
 // cost_out / cost_slot (device, nullable): where the cost after the update is recorded.
 // *cost_recorded tells the caller whether that happened inside the update (fused line search,
@@ -309,7 +338,10 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
         if (!c->x_feasible) AA_CHECK(launch_proj(c, x, nullptr, 0.0, -1, PROJ_FEAS));
         if (!warm) {
             if (data) {
+                const bool mixed = slots_mixed(c);
+                if (mixed) AA_CHECK(slots_save_P(c));
                 AA_CHECK(launch_reduce_rows(c, x, c->P.as<double>(), operandT(c, c->P, c->Pw)));
+                if (mixed) AA_CHECK(slots_restore_P_warm(c));
                 AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), gram));
             } else {
                 AA_CHECK(launch_reduce_rows(c, x, c->wideScratch.as<double>(), nullptr));
@@ -321,6 +353,8 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
         }
         AA_CHECK(launch_tall_dot_scaled(c, x, c->H.as<double>(), c->alphaDev.as<double>(), SC_S1));
         AA_CHECK(launch_scalar_stage(c, ST_INIT_F, sp, 0));                     // spg.py:156
+        // the slots that are in the middle of their fits start this update the way they always do
+        if (slots_mixed(c)) AA_CHECK(launch_dict_setup(c, sp, (double)k, slots_all_mask(c) & ~c->slots_cold));
         if (data && !warm) AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));
     }
     c->products_valid = false;
@@ -610,7 +644,7 @@ int aa_ctx_destroy(aa_ctx *h)
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->rlPartial, &c->redPartial,
                      &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->iterState, &c->snapC, &c->snapZ, &c->snapAlpha, &c->qpIters, &c->qpPerm,
-                     &c->qpStats, &c->qpLive, &c->slotCosts, &c->slotCounters, &c->slotStates, &c->slotCost0, &c->slotSnapP, &c->tmpTall2, &c->redPartial2, &c->redOut2, &c->proj2, &c->projList2, &c->projSegCnt2};
+                     &c->qpStats, &c->qpLive, &c->slotCosts, &c->slotCounters, &c->slotStates, &c->slotCost0, &c->slotSnapP, &c->slotSaveP, &c->slotSaveGr, &c->tmpTall2, &c->redPartial2, &c->redOut2, &c->proj2, &c->projList2, &c->projSegCnt2};
     for (DevBuf *b : all) b->release();
     if (c->evFork2) (void)hipEventDestroy(c->evFork2);
     if (c->evJoin2) (void)hipEventDestroy(c->evJoin2);
@@ -1527,6 +1561,87 @@ int aa_slots_load(aa_ctx *h, int r, const double *C, long ldc, const double *Z)
     return AA_OK;
 }
 
+// a new restart into slot r of a RUNNING group (its previous occupant has stopped and been fetched):
+// the factors, the products aa_prepare computes -- for this slot; the other slots keep the products
+// they carry -- its initial cost; its next dictionary update is the cold one of a fit.
+int aa_slots_reload(aa_ctx *h, int r, const double *C, long ldc, const double *Z)
+{
+    AA_REQUIRE(h && C && Z, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    AA_REQUIRE(c->slots_aa && c->slots_started && r >= 0 && r < c->slots_R, AA_ERR_ARG, "slot %d out of range", r);
+    AA_REQUIRE(ldc >= c->n, AA_ERR_ARG, "ldc < n");
+    const int k = c->slots_k, o = r * k, KP = c->KP;
+    AA_CHECK(join_side(c));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    std::vector<double> ct((size_t)c->n * k);
+    for (long row = 0; row < c->n; ++row)
+        for (int i = 0; i < k; ++i) ct[(size_t)row * k + i] = C[(size_t)i * ldc + row];
+    AA_CHECK_HIP(hipMemcpy2D(c->Ct.as<double>() + o, (size_t)KP * sizeof(double), ct.data(), (size_t)k * sizeof(double),
+                             (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyHostToDevice));
+    AA_CHECK_HIP(hipMemcpy2D(c->Zt.as<double>() + o, (size_t)KP * sizeof(double), Z, (size_t)k * sizeof(double),
+                             (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyHostToDevice));
+    IterState zero;
+    memset(&zero, 0, sizeof(zero));
+    AA_CHECK_HIP(hipMemcpy(c->slotStates.as<IterState>() + r, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(hipMemset(c->slotCounters.as<int>() + r, 0, sizeof(int)));
+    // a fit starts its projections cold (aa_set_state): a warm threshold of +inf selects nothing, which
+    // is the cold start of k_proj_small -- for this slot's columns, in both projection states
+    {
+        std::vector<double> inf(k, INFINITY);
+        DevBuf *states[2] = {&c->proj, &c->proj2};
+        for (DevBuf *b : states) {
+            if (!b->p) continue;
+            ProjState *ps = b->as<ProjState>();
+            for (int m = 1; m < 4; ++m)
+                AA_CHECK_HIP(hipMemcpy(&ps->warm[m][o], inf.data(), (size_t)k * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
+    // products: aa_prepare's passes on the stacked state; what the RUNNING slots carry (C X, (C X X')',
+    // (C X)(C X)') is put back afterwards -- the rest (Z'Z, X X'Z, C X X'Z) comes out as it was
+    const size_t wide = (size_t)KP * c->p_pad * sizeof(double), tall = (size_t)c->n_pad * KP * sizeof(double);
+    const size_t GS = (size_t)KP * KP;
+    AA_CHECK(c->slotSaveP.alloc(wide));
+    AA_CHECK(c->slotSaveGr.alloc(tall + GS * sizeof(double)));
+    AA_CHECK_HIP(hipMemcpy(c->slotSaveP.p, c->P.p, wide, hipMemcpyDeviceToDevice));
+    AA_CHECK_HIP(hipMemcpy(c->slotSaveGr.p, c->Gr.p, tall, hipMemcpyDeviceToDevice));
+    double *saveCKCt = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(c->slotSaveGr.p) + tall);
+    AA_CHECK_HIP(hipMemcpy(saveCKCt, dev_CKCt(c), GS * sizeof(double), hipMemcpyDeviceToDevice));
+    c->products_valid = false;
+    c->grams_valid = false;
+    AA_CHECK(prepare(c, nullptr));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    const unsigned loaded = c->slots_cold | (1u << r);
+    for (int q = 0; q < c->slots_R; ++q) {
+        if ((loaded >> q) & 1u) continue;                 // freshly loaded slots keep what prepare computed
+        const int oq = q * k;
+        AA_CHECK_HIP(hipMemcpy(c->P.as<double>() + (size_t)oq * c->p_pad, c->slotSaveP.as<double>() + (size_t)oq * c->p_pad,
+                               (size_t)k * c->p_pad * sizeof(double), hipMemcpyDeviceToDevice));
+        AA_CHECK_HIP(hipMemcpy2D(c->Gr.as<double>() + oq, (size_t)KP * sizeof(double),
+                                 c->slotSaveGr.as<double>() + oq, (size_t)KP * sizeof(double),
+                                 (size_t)k * sizeof(double), (size_t)c->n_pad, hipMemcpyDeviceToDevice));
+        AA_CHECK_HIP(hipMemcpy2D(dev_CKCt(c) + (size_t)oq * KP + oq, (size_t)KP * sizeof(double),
+                                 saveCKCt + (size_t)oq * KP + oq, (size_t)KP * sizeof(double),
+                                 (size_t)k * sizeof(double), (size_t)k, hipMemcpyDeviceToDevice));
+    }
+    if (c->dtype == AA_F32) AA_CHECK(launch_wide_to_T(c, c->P.as<double>(), operandT(c, c->P, c->Pw)));
+    c->slots_cold = loaded;
+    c->slots_cold_cols = 0u;
+    for (int q = 0; q < c->slots_R; ++q)
+        if ((loaded >> q) & 1u)
+            for (int i = 0; i < k; ++i) c->slots_cold_cols |= 1u << (q * k + i);
+    // initial cost of the new slot only (launch_aa_cost_slots takes all slots: the others' cost0 is
+    // rewritten with the same bits -- their Gram blocks are what they were)
+    std::vector<double> c0(32);
+    AA_CHECK_HIP(hipMemcpy(c0.data(), c->slotCost0.p, 32 * sizeof(double), hipMemcpyDeviceToHost));
+    AA_CHECK(launch_aa_cost_slots(c, 0, nullptr));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    for (int q = 0; q < c->slots_R; ++q)
+        if (q != r)
+            AA_CHECK_HIP(hipMemcpy(c->slotCost0.as<double>() + q, &c0[q], sizeof(double), hipMemcpyHostToDevice));
+    return AA_OK;
+}
+
 // n_iters outer iterations of every slot; status[R] out.  The first call after the loads prepares the
 // stacked state the way aa_set_state + aa_prepare prepare a single fit (all slots of a group start
 // together: the first dictionary update of a fit projects the caller's factors and recomputes the
@@ -1544,12 +1659,20 @@ int aa_slots_run(aa_ctx *h, int n_iters, aa_slot_status *status)
         AA_CHECK(prepare(c, nullptr));
         AA_CHECK(launch_aa_cost_slots(c, 0, nullptr));
         c->slots_started = true;
+        c->slots_cold = slots_all_mask(c);
+        c->slots_cold_cols = 0xffffffffu;
     }
     bool recorded = false;
     for (int it = 0; it < n_iters; ++it) {
+        if (c->slots_cold) {                      // (aa_slots_reload) the cold update of the freshly loaded slots
+            c->x_feasible = false;
+            c->products_valid = false;
+        }
         AA_CHECK(dictionary_update(c, &c->slots_sp, nullptr, true, c->slotCosts.as<double>(),
                                    c->slotCounters.as<int>(), &recorded));
         AA_REQUIRE(recorded, AA_ERR_STATE, "AA slots: the fused line search did not record the cost");
+        c->slots_cold = 0;
+        c->slots_cold_cols = 0xffffffffu;
         AA_CHECK(weights_update(c, &c->slots_qp, nullptr));
         AA_CHECK(launch_aa_cost_slots(c, 2, &c->slots_ip));
         AA_CHECK(launch_aa_snap_slots(c));
@@ -1618,7 +1741,14 @@ int aa_slots_fetch(aa_ctx *h, int r, double *C, long ldc, double *Z, double *CX,
                            (size_t)2 * (st.stop_iter + 1) * sizeof(double), hipMemcpyDeviceToHost));
     AA_CHECK_HIP(hipMemcpy(cost0, c->slotCost0.as<double>() + r, sizeof(double), hipMemcpyDeviceToHost));
     AA_REQUIRE(ldx >= c->p, AA_ERR_ARG, "ldx < p");
-    const double *src = (carried ? c->slotSnapP.as<double>() : c->P.as<double>()) + (size_t)o * c->p_pad;
+    if (!carried) {
+        // C X recomputed from the stopping iteration's dictionary: the pass aa_prepare runs (on the
+        // scratch arrays of the dictionary update, free between iterations)
+        AA_CHECK_HIP(hipMemcpy(c->Dt.p, c->snapC.p, (size_t)c->n_pad * c->KP * sizeof(double), hipMemcpyDeviceToDevice));
+        AA_CHECK(launch_reduce_rows(c, c->Dt.as<double>(), c->Q.as<double>(), nullptr));
+        AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    }
+    const double *src = (carried ? c->slotSnapP.as<double>() : c->Q.as<double>()) + (size_t)o * c->p_pad;
     AA_CHECK_HIP(hipMemcpy2D(CX, (size_t)ldx * sizeof(double), src, (size_t)c->p_pad * sizeof(double),
                              (size_t)c->p * sizeof(double), (size_t)k, hipMemcpyDeviceToHost));
     return AA_OK;
