@@ -8,12 +8,15 @@ launches of a few microseconds each -- so ``fit_restarts`` draws the starting fa
 restarts first, in the drivers' order (so every restart starts exactly where it would in the
 sequential loop), and then
 
-* GPNH models: lays the restarts SIDE BY SIDE in the component slots of one set of device arrays,
-  where they share every launch of an outer iteration (``_fit_gpnh_slots``, aa_gpnh_slots_*):
-  about three times the sequential loop's speed on the JRA-55-shaped problem;
-* AA models: runs the fits on worker threads, each on its own device context; the contexts of a
-  device share one resident copy of the data (useful with ``devices=[...]``: whole restarts dealt
-  over GPUs; on ONE GPU several fits at a time are not faster).
+* GPNH models, and AA models with the drivers' settings (one SPG iteration per dictionary update,
+  delta = 0, at most 4096 samples, k <= 16): lays the restarts SIDE BY SIDE in the component slots of
+  one set of device arrays, where they share every launch of an outer iteration; a restart that stops
+  hands its slot to the next one (``_fit_gpnh_slots`` / aa_gpnh_slots_*, ``_fit_aa_slots`` /
+  aa_slots_*): 3.5-5x the sequential loop's speed on the JRA-55- and HadISST-shaped problems with
+  ``n_init = 100``;
+* other AA settings: runs the fits on worker threads, each on its own device context; the contexts
+  of a device share one resident copy of the data (useful with ``devices=[...]``: whole restarts
+  dealt over GPUs; on ONE GPU several fits at a time are not faster).
 
 Every model ends with the attributes the sequential loop gives it; results are identical, restart
 by restart.

@@ -644,12 +644,14 @@ def test_gpnh_restarts_side_by_side(cdr, orc, case):
 @pytest.mark.parametrize("case", ["stopping_rule", "iteration_cap", "float32", "furthest_sum"])
 def test_aa_restarts_side_by_side(cdr, orc, case):
     """fit_restarts on ArchetypalAnalysis models with the drivers' settings (bin/run_hadisst_aa.py:149-174:
-    one SPG iteration per dictionary update, delta = 0): groups of 32 // k restarts sit side by side in
-    the component slots of ONE set of device arrays (aa_slots_*) -- the passes over X, the Gram kernels,
+    one SPG iteration per dictionary update, delta = 0): 32 // k restarts sit side by side in the
+    component slots of ONE set of device arrays (aa_slots_*) -- the passes over X, the Gram kernels,
     the gradient kernel (block-diagonal M) and the column projections are the single fit's launches,
-    the SPG scalars, the line search, the QP Hessian, the cost and the judge exist once per slot.
-    Restart by restart -- cost, n_iter, cost deltas, weights, dictionary, archetypes -- the result is
-    the sequential loop's, bit for bit (14 restarts of k = 5: three groups, the last one partial)."""
+    the SPG scalars, the line search, the QP Hessian, the cost and the judge exist once per slot -- and
+    a restart that stops hands its slot to the next one, whose cold first update runs beside the
+    carried state of the others (aa_slots_reload).  Restart by restart -- cost, n_iter, cost deltas,
+    weights, dictionary, archetypes -- the result is the sequential loop's, bit for bit (14 restarts
+    of k = 5 through six slots)."""
     import warnings
     from convex_dim_red import restarts
     rng = np.random.RandomState(31)

@@ -44,12 +44,12 @@ for name, (X, k), make in (
         t = time.perf_counter() - t0
         print("   fit_restarts n_jobs=%d: %.2f s (%.0f it/s), identical costs: %s, best restart %d"
               % (jobs, t, it / t, [m.cost for m in models] == c_res, best), flush=True)
-    if name.startswith("C2"):                            # AA: groups of restarts side by side in one set of arrays
+    if name.startswith("C2"):                            # AA: restarts side by side in one set of arrays
         shared = np.random.RandomState(0)
         t0 = time.perf_counter()
         models, best = cdr.fit_restarts(lambda: make(shared), X, n_init)
         t = time.perf_counter() - t0
-        print("   fit_restarts side by side, groups of %d: %.3f s (%.0f it/s) = %.2fx the sequential loop, identical costs: %s, best restart %d"
+        print("   fit_restarts side by side, %d at a time: %.3f s (%.0f it/s) = %.2fx the sequential loop, identical costs: %s, best restart %d"
               % (32 // k, t, it / t, t_res / t, [m.cost for m in models] == c_res, best), flush=True)
     if name.startswith("C3"):                            # GPNH: restarts side by side in one set of arrays
         for slots in (3, 6):
