@@ -717,6 +717,41 @@ def test_restarts_side_by_side_over_devices(cdr, orc, family):
         assert np.array_equal(a.weights, b.weights) and np.array_equal(a.dictionary, b.dictionary)
 
 
+def test_restart_slots_only_where_the_single_fit_runs_the_same_kernels(cdr, orc):
+    """Settings outside the ones the slots reproduce bit for bit -- a GPNH weights QP of more than four
+    passes (a single fit then uses the four-lane and wave kernels), AA with several SPG iterations per
+    dictionary update or delta != 0 -- go through the worker-thread path, with the same results as the
+    sequential loop."""
+    import warnings
+    from convex_dim_red import restarts
+    rng = np.random.RandomState(9)
+    n, p, k, n_init = 500, 40, 4, 3
+    X = orc.right_stochastic_matrix((n, k), rng).dot(rng.standard_normal((k, p))) + 0.1 * rng.standard_normal((n, p))
+    makers = [
+        lambda rs: cdr.GPNHConvexCoding(k, lambda_W=0.2, init="random", tolerance=1e-5, max_iterations=60, random_state=rs,
+                                        stopping_criterion="rel_delta_f", weights_solver_kwargs=dict(max_iterations=50)),
+        lambda rs: cdr.ArchetypalAnalysis(k, init="random", tolerance=1e-5, max_iterations=40, random_state=rs,
+                                          dictionary_solver_kwargs=dict(max_iterations=3)),
+        lambda rs: cdr.ArchetypalAnalysis(k, delta=0.1, init="random", tolerance=1e-5, max_iterations=40, random_state=rs,
+                                          dictionary_solver_kwargs=dict(max_iterations=1)),
+    ]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for make in makers:
+            shared = np.random.RandomState(1)
+            seq = []
+            for _ in range(n_init):
+                m = make(shared)
+                m.fit_transform(X)
+                seq.append(m)
+            restarts.slots_profile.clear()
+            shared = np.random.RandomState(1)
+            models, best = cdr.fit_restarts(lambda: make(shared), X, n_init)
+            assert not restarts.slots_profile                      # the slots path did not run
+            for a, b in zip(seq, models):
+                assert a.cost == b.cost and a.n_iter == b.n_iter and np.array_equal(a.weights, b.weights)
+
+
 def test_gpnh_slot_with_singular_normal_equations_goes_to_the_sequential_path(cdr, orc):
     """A start whose weights have an all-zero column (lambda_W = 0: no Cholesky factor) is reported
     by its slot and left to the sequential path, which solves with lstsq like the reference
