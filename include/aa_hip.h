@@ -389,7 +389,7 @@ int aa_gpnh_slots_fetch(aa_ctx *ctx, int r, double *Wt, long ld, double *Z, doub
 
 /* The same for archetypal analysis (bin/run_hadisst_aa.py:149-174; archetypal_analysis.py:534-670 per
  * restart): R fits of k components in the component slots of one set of arrays (R k <= 32), production
- * settings only (data form, one SPG iteration per dictionary update, delta = 0, at most 4096 samples,
+ * settings only (data form, one SPG iteration per dictionary update, delta = 0, fewer than 65 536 samples,
  * k <= 16, single rank).  aa_slots_begin + aa_slots_load x R start the first restarts together;
  * aa_slots_run iterates every slot and reports its status (a stopped slot's factors of that iteration
  * are kept while the others go on); aa_slots_fetch returns a stopped slot's factors, cost record and

@@ -9,7 +9,7 @@ restarts first, in the drivers' order (so every restart starts exactly where it 
 sequential loop), and then
 
 * GPNH models, and AA models with the drivers' settings (one SPG iteration per dictionary update,
-  delta = 0, at most 4096 samples, k <= 16): lays the restarts SIDE BY SIDE in the component slots of
+  delta = 0, fewer than 65 536 samples, k <= 16): lays the restarts SIDE BY SIDE in the component slots of
   one set of device arrays, where they share every launch of an outer iteration; a restart that stops
   hands its slot to the next one (``_fit_gpnh_slots`` / aa_gpnh_slots_*, ``_fit_aa_slots`` /
   aa_slots_*): 3.5-5x the sequential loop's speed on the JRA-55- and HadISST-shaped problems with
@@ -138,7 +138,7 @@ def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
 
 def _aa_slots_eligible(models, data):
     """AA restarts that can share one set of device arrays (aa_slots_*): production settings -- one SPG
-    iteration per dictionary update, delta = 0 -- same hyper-parameters, at most 4096 samples, k <= 16."""
+    iteration per dictionary update, delta = 0 -- same hyper-parameters, fewer than 65 536 samples, k <= 16."""
     m0 = models[0]
     if not all(type(m) is ArchetypalAnalysis for m in models) or len(models) < 2:
         return False
@@ -149,7 +149,7 @@ def _aa_slots_eligible(models, data):
         return False
     k = m0.n_components
     dkw = dict(m0.dictionary_solver_kwargs)
-    return (isinstance(k, int) and 1 <= k <= 16 and m0.delta == 0 and not m0.verbose and data.shape[0] <= 4096
+    return (isinstance(k, int) and 1 <= k <= 16 and m0.delta == 0 and not m0.verbose and data.shape[0] < 65536
             and dkw.get("max_iterations", 1000) == 1 and dkw.get("memory", 1) <= 16
             and m0.weights_solver_kwargs.get("memory", 1) <= 1
             and m0.weights_solver_kwargs.get("max_iterations", 1000) >= 1
@@ -249,7 +249,7 @@ def fit_restarts(make_model, data, n_init, n_jobs=None, devices=None, side_by_si
     matrix is uploaded ONCE per device and the workers of a device share that copy
     (``aa_share_data``), each with its own factors, streams and scratch.
     ``side_by_side`` (models with the same hyper-parameters; GPNH with k <= 16, AA with the drivers'
-    settings -- one SPG iteration per dictionary update, delta = 0, at most 4096 samples, k <= 16):
+    settings -- one SPG iteration per dictionary update, delta = 0, fewer than 65 536 samples, k <= 16):
     the restarts run ``n_slots`` at a time (default: 64 // k for GPNH, 32 // k for AA) in ONE set of
     device arrays per device and share every launch of an outer iteration (``_fit_gpnh_slots``,
     ``_fit_aa_slots``); with several ``devices`` restart i runs on device i mod G; ``n_jobs`` is not

@@ -2342,7 +2342,7 @@ int launch_qp_slots_aa(Ctx *c, const aa_qp_params *p)
     AA_REQUIRE(k <= 16 && p->memory <= 1 && p->max_iterations >= 1, AA_ERR_ARG,
                "AA slots: k <= 16, QP memory 1");
     const long n = c->n;
-    AA_REQUIRE(n <= 4096, AA_ERR_ARG, "AA slots: at most 4096 samples (no sample ordering)");
+    AA_REQUIRE(n < 65536, AA_ERR_ARG, "AA slots: fewer than 65 536 samples");
     const long n_al = round_up(n, 16);
     const size_t off_A = 64 * (size_t)R;
     const size_t off_bs = off_A + (size_t)R * 32 * 32 * sizeof(double);
@@ -2361,8 +2361,12 @@ int launch_qp_slots_aa(Ctx *c, const aa_qp_params *p)
                        (const double *)c->alphaDev.as<double>(), k, c->KP);
     int cap = g_qp_quad_cap > 0 ? g_qp_quad_cap : 24;
     if (p->max_iterations <= cap) cap = p->max_iterations;
-    const long waves = (n + 15) / 16;
-    const long max_trips = 16 * ((long)cap + 2) + 16;
+    // (a single fit orders its samples by their previous pass counts from 4097 samples on: which wave
+    // takes a sample does not enter its arithmetic, so the slots go without)
+    long waves = (n + 15) / 16;
+    if (waves > g_qp_quad_waves) waves = g_qp_quad_waves;
+    const long rounds = (n + 16 * waves - 1) / (16 * waves);
+    const long max_trips = 16 * rounds * ((long)cap + 2) + 16;
     const int refill = g_qp_quad_refill < 1 ? 1 : (g_qp_quad_refill > 16 ? 16 : g_qp_quad_refill);
     const double *Bt = c->Gr.as<double>();
     double *Zt = c->Zt.as<double>();

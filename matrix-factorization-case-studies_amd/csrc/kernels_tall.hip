@@ -207,12 +207,12 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_first(const double *__restrict
                                                     long n, long rows_pb, int k, int warm_slot,
                                                     const ProjState *__restrict__ ps,
                                                     double *__restrict__ wout,
-                                                    double *__restrict__ partial)
+                                                    double *__restrict__ partial, int kslot = 0)
 {
     __shared__ double sm[3 * PROJ_NT];
     constexpr int RS = PROJ_NT / KP;
     const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
-    const double a = load_a(a_const, scal, a_slot);
+    const double a = load_a(a_const, scal, a_slot, comp, kslot);
     const long rb = (long)blockIdx.x * rows_pb;
     long re = rb + rows_pb;
     if (re > n) re = n;
@@ -2003,7 +2003,7 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
         const int RS = 256 / c->KP;
         const long nseg = (long)c->tallBlocks * RS, segcap = rpb / RS;
         TALL_DISPATCH_NT(PROJ_NT, k_proj_first, x, g, a_const, (const double *)scal, a_slot, c->n, rpb, c->k,
-                      c->projWarm[mode] ? mode : 0, (const ProjState *)ps, wbuf, part);
+                      c->projWarm[mode] ? mode : 0, (const ProjState *)ps, wbuf, part, c->slots_aa ? c->slots_k : 0);
         AA_CHECK(finalize_and_post(c, 3, 1u, POST_FIRST, 0, 0, false));
         TALL_DISPATCH(k_proj_collect, wsrc, c->n, rpb, c->k, (const ProjState *)ps,
                       c->projList.as<double>(), c->projSegCnt.as<int>());

@@ -1463,7 +1463,7 @@ int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp,
 // makes the launchers pick those forms; dictionary_update / weights_update themselves are the
 // single fit's).  Every slot gets the bits it gets from aa_iterate on its own.  Production
 // settings only: data form, one SPG iteration per dictionary update, delta = 0, single rank,
-// at most 4096 samples (one-kernel threshold search, no sample ordering), k <= 16.
+// fewer than 65 536 samples, k <= 16.
 int aa_slots_begin(aa_ctx *h, int R, int k, const aa_iter_params *ip, const aa_spg_params *spg,
                    const aa_qp_params *qp)
 {
@@ -1476,11 +1476,11 @@ int aa_slots_begin(aa_ctx *h, int R, int k, const aa_iter_params *ip, const aa_s
     // must run the kernels a single fit of k <= 16 components runs (KP = 32) to get its bits
     AA_REQUIRE(R >= 1 && k >= 1 && k <= 16 && R * k <= 32, AA_ERR_ARG,
                "slots: R = %d restarts of k = %d components do not fit 32 component slots", R, k);
-    AA_REQUIRE(c->n <= 256L * 32 && c->n <= 4096, AA_ERR_ARG, "AA slots: at most 4096 samples");
+    AA_REQUIRE(c->n < 65536, AA_ERR_ARG, "AA slots: fewer than 65 536 samples");
     AA_REQUIRE(ip->max_outer >= 1 && ip->update_dictionary && ip->update_weights && ip->delta == 0.0, AA_ERR_ARG,
                "slots: both updates, delta = 0");
     AA_REQUIRE(spg->max_iterations == 1 && spg->memory <= 16, AA_ERR_ARG, "slots: one SPG iteration per dictionary update");
-    AA_REQUIRE(g_fuse_finalize && g_proj_mode == 0 && g_proj_small, AA_ERR_STATE, "slots: default projection options");
+    AA_REQUIRE(g_fuse_finalize && g_proj_mode == 0, AA_ERR_STATE, "slots: default projection options");
     c->slots_aa = false;
     c->k = 0;                                         // fresh, zeroed factor arrays
     AA_CHECK(ensure_problem(c, R * k));

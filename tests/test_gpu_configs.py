@@ -641,7 +641,7 @@ def test_gpnh_restarts_side_by_side(cdr, orc, case):
     assert best == int(np.argmin([m.cost for m in seq]))
 
 
-@pytest.mark.parametrize("case", ["stopping_rule", "iteration_cap", "float32", "furthest_sum"])
+@pytest.mark.parametrize("case", ["stopping_rule", "iteration_cap", "float32", "furthest_sum", "list_projection"])
 def test_aa_restarts_side_by_side(cdr, orc, case):
     """fit_restarts on ArchetypalAnalysis models with the drivers' settings (bin/run_hadisst_aa.py:149-174:
     one SPG iteration per dictionary update, delta = 0): 32 // k restarts sit side by side in the
@@ -656,6 +656,8 @@ def test_aa_restarts_side_by_side(cdr, orc, case):
     from convex_dim_red import restarts
     rng = np.random.RandomState(31)
     n, p, k, n_init = 900, 260, 5, 14
+    if case == "list_projection":             # > 8192 rows: candidate-list projection, ordered QP samples in the single fit
+        n, p, n_init = 9100, 48, 8
     B = rng.standard_normal((k, p))
     Zt = orc.right_stochastic_matrix((n, k), rng) ** 4
     Zt /= Zt.sum(axis=1, keepdims=True)
@@ -667,6 +669,8 @@ def test_aa_restarts_side_by_side(cdr, orc, case):
               dtype=dtype, dictionary_solver_kwargs=dict(max_iterations=1))
     if case == "iteration_cap":
         kw.update(tolerance=0, max_iterations=11, require_monotonic_cost_decrease=False)
+    if case == "list_projection":
+        kw.update(max_iterations=60)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         shared = np.random.RandomState(6)
