@@ -37,13 +37,30 @@ from .preprocessing import DeviceData
 slots_profile = {}        # seconds spent loading / iterating / fetching in the last side-by-side run
 
 
+def _print_tables(models, tables, title, rule):
+    """verbose: the per-iteration tables of the sequential loops (archetypal_analysis.py:566-584,655-661;
+    gpnh_convex_coding.py:336-340,391-397), one restart after the other in restart order -- printed
+    when all restarts are done, since they ran side by side."""
+    for m, tab in zip(models, tables):
+        if tab is None:
+            continue
+        finals, begins, per_iter, converged = tab
+        print(title.format(m.n_components))
+        print('{:<12s} | {:<13s} | {:<13s} | {:<12s}'.format('Iteration', 'Cost', 'Cost delta', 'Time'))
+        print(rule * '-')
+        for j in range(len(finals)):
+            print('{:12d} | {: 12.6e} | {: 12.6e} | {: 12.6e}'.format(j + 1, finals[j], finals[j] - begins[j], per_iter))
+        if converged:
+            print('*** Converged at iteration {:d} ***'.format(len(finals)))
+
+
 def _slots_eligible(models):
     """GPNH restarts that can share one set of device arrays: same hyper-parameters, at least four
     restarts of k components in the 64 component slots of the tall arrays."""
     m0 = models[0]
     if not all(isinstance(m, GPNHConvexCoding) for m in models) or len(models) < 2:
         return False
-    keys = ("n_components", "lambda_W", "tolerance", "max_iterations", "stopping_criterion",
+    keys = ("n_components", "lambda_W", "tolerance", "max_iterations", "stopping_criterion", "verbose",
             "require_monotonic_cost_decrease", "dtype", "weights_solver_kwargs", "dictionary_solver_kwargs")
     if any(getattr(m, a) != getattr(m0, a) for m in models[1:] for a in keys):
         return False
@@ -51,7 +68,7 @@ def _slots_eligible(models):
     # (weights QP of at most four SPG passes -- the drivers' setting is one: the slots run the
     # lane-per-sample kernel to completion, which is what a single fit uses for such QPs and only for
     # them, so only then does every restart get the bits it gets alone)
-    return (isinstance(k, int) and 1 <= k <= 16 and not m0.dictionary_solver_kwargs and not m0.verbose
+    return (isinstance(k, int) and 1 <= k <= 16 and not m0.dictionary_solver_kwargs
             and m0.weights_solver_kwargs.get("memory", 1) <= 8
             and 1 <= m0.weights_solver_kwargs.get("max_iterations", 1000) <= 4
             and _backend.distributed_env() is None)
@@ -82,6 +99,7 @@ def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
         pending = list(range(len(models)))
         owner = [None] * n_slots
         loaded_at = [0.0] * n_slots
+        tables = [None] * len(models)
 
         prof = slots_profile
         prof.update(load=0.0, run=0.0, fetch=0.0, polls=0, slots=n_slots)
@@ -122,6 +140,7 @@ def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
                         m.cost, m.n_iter = float(finals[-1]), int(st.stop_iter)
                         m.cost_deltas = [float(d) for d in finals - begins]
                         m.avg_time_per_iter = (time.perf_counter() - loaded_at[r]) / max(st.iterations_run, 1)
+                        tables[i] = (finals, begins, m.avg_time_per_iter, bool(st.converged))
                         if m.n_iter == m.max_iterations and m.tolerance > 0:
                             warnings.warn('Maximum number of iterations %d reached.' % m.max_iterations, UserWarning)
                 else:
@@ -131,6 +150,8 @@ def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
                     load(r)
     finally:
         ctx.close()
+    if m0.verbose:
+        _print_tables(models, tables, "*** GPNH convex coding: n_components = {:d} ***", 100)
     if errors:
         raise errors[min(errors)]
     return fallback
@@ -142,14 +163,14 @@ def _aa_slots_eligible(models, data):
     m0 = models[0]
     if not all(type(m) is ArchetypalAnalysis for m in models) or len(models) < 2:
         return False
-    keys = ("n_components", "delta", "tolerance", "max_iterations", "stopping_criterion",
+    keys = ("n_components", "delta", "tolerance", "max_iterations", "stopping_criterion", "verbose",
             "require_monotonic_cost_decrease", "dtype", "weights_solver_kwargs", "dictionary_solver_kwargs",
             "scale_factors_solver_kwargs")
     if any(getattr(m, a) != getattr(m0, a) for m in models[1:] for a in keys):
         return False
     k = m0.n_components
     dkw = dict(m0.dictionary_solver_kwargs)
-    return (isinstance(k, int) and 1 <= k <= 16 and m0.delta == 0 and not m0.verbose and data.shape[0] < 65536
+    return (isinstance(k, int) and 1 <= k <= 16 and m0.delta == 0 and data.shape[0] < 65536
             and dkw.get("max_iterations", 1000) == 1 and dkw.get("memory", 1) <= 16
             and m0.weights_solver_kwargs.get("memory", 1) <= 1
             and m0.weights_solver_kwargs.get("max_iterations", 1000) >= 1
@@ -185,6 +206,7 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
         pending = list(range(len(models)))
         owner = [None] * n_slots
         loaded_at = [0.0] * n_slots
+        tables = [None] * len(models)
         t0 = time.perf_counter()
         ctx.aa_slots_begin(n_slots, k, m0.max_iterations, m0.tolerance, m0.stopping_criterion,
                            m0.require_monotonic_cost_decrease, m0.dictionary_solver_kwargs,
@@ -220,6 +242,7 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
                     m.cost, m.n_iter = float(finals[-1]), int(st.stop_iter)
                     m.cost_deltas = [d for d in finals - begins]
                     m.avg_time_per_iter = (time.perf_counter() - loaded_at[r]) / max(st.iterations_run, 1)
+                    tables[i] = (finals, begins, m.avg_time_per_iter, bool(st.converged))
                     m.archetypes = CX
                     if m.n_iter == m.max_iterations and m.tolerance > 0:
                         warnings.warn('Maximum number of iterations %d reached.' % m.max_iterations, UserWarning)
@@ -235,6 +258,8 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
         ctx.aa_slots_end()
     finally:
         ctx.close()
+    if m0.verbose:
+        _print_tables(models, tables, "*** AA: n_components = {:d} ***", 80)
     if errors:
         raise errors[min(errors)]
     return []

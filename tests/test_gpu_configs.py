@@ -721,6 +721,44 @@ def test_restarts_side_by_side_over_devices(cdr, orc, family):
         assert np.array_equal(a.weights, b.weights) and np.array_equal(a.dictionary, b.dictionary)
 
 
+@pytest.mark.parametrize("family", ["aa", "gpnh"])
+def test_restart_slots_print_the_verbose_tables(cdr, orc, family, capsys):
+    """verbose (the drivers' wrappers switch it on, bin/run_hadisst_aa_wrapper.sh:52): the per-iteration
+    tables of every restart -- iteration, cost, cost delta -- as the sequential loop prints them, restart
+    after restart (printed when all are done; the time column is the slots' own)."""
+    import warnings
+    rng = np.random.RandomState(19)
+    n, p, k, n_init = 400, 30, 3, 4
+    X = orc.right_stochastic_matrix((n, k), rng).dot(rng.standard_normal((k, p))) + 0.1 * rng.standard_normal((n, p))
+    if family == "aa":
+        def make(rs):
+            return cdr.ArchetypalAnalysis(k, init="random", tolerance=1e-4, max_iterations=200, random_state=rs, verbose=1,
+                                          dictionary_solver_kwargs=dict(max_iterations=1))
+    else:
+        def make(rs):
+            return cdr.GPNHConvexCoding(k, lambda_W=0.3, init="random", tolerance=1e-4, max_iterations=200,
+                                        random_state=rs, verbose=1, stopping_criterion="rel_delta_f",
+                                        weights_solver_kwargs=dict(max_iterations=1))
+
+    def columns(text):
+        rows = []
+        for line in text.splitlines():
+            parts = [q.strip() for q in line.split("|")]
+            rows.append(tuple(parts[:3]) if len(parts) == 4 else (line.strip(),))
+        return rows
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        shared = np.random.RandomState(1)
+        for _ in range(n_init):
+            make(shared).fit_transform(X)
+        want = columns(capsys.readouterr().out)
+        shared = np.random.RandomState(1)
+        cdr.fit_restarts(lambda: make(shared), X, n_init)
+        got = columns(capsys.readouterr().out)
+    assert len(want) > 4 * n_init and got == want
+
+
 def test_restart_slots_only_where_the_single_fit_runs_the_same_kernels(cdr, orc):
     """Settings outside the ones the slots reproduce bit for bit -- a GPNH weights QP of more than four
     passes (a single fit then uses the four-lane and wave kernels), AA with several SPG iterations per
