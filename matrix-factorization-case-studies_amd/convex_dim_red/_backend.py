@@ -748,6 +748,19 @@ class Context(object):
         return ms.value
 
 
+class borrowed(object):
+    """``with borrowed(ctx) as ctx``: a context somebody else owns (not closed on exit)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        return self.ctx
+
+    def __exit__(self, *exc):
+        return False
+
+
 # ---------------------------------------------------------------- data kept resident across fits
 # The drivers fit the same matrix n_init = 100 times (bin/run_hadisst_aa.py:158-172,
 # bin/run_jra55_pca_gpnh.py:123-136), each time through a fresh estimator.  Estimator instances

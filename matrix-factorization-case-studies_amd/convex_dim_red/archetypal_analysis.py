@@ -82,9 +82,10 @@ def _initialize_kernel_aa_dictionary_furthest_sum(kernel, n_components, start_in
     return _one_hot_rows(selected, n_samples, kernel.dtype)
 
 
-def _furthest_sum_on_device(ctx, n_samples, n_components, start_index, n_extra_steps, exclude):
-    """FurthestSum with distance columns computed from the resident data matrix."""
-    cache = {}
+def _furthest_sum_on_device(ctx, n_samples, n_components, start_index, n_extra_steps, exclude, cache=None):
+    """FurthestSum with distance columns computed from the resident data matrix (``cache``: columns
+    already fetched for the same matrix -- restarts.fit_restarts shares one over its restarts)."""
+    cache = {} if cache is None else cache
 
     def column_of(j, sense):
         j = int(j)
@@ -424,7 +425,9 @@ def _fit_on_data_matrix(self, data, linear_kernel, label, dictionary=None, weigh
     # one process per GPU (torch.distributed.run) with CONVEX_DIM_RED_DISTRIBUTED=1: this rank keeps
     # its row block of the data, RCCL all-reduces the Gram products, every rank gets the full factors
     distributed = _backend.distributed_env() is not None and not on_device
-    with (data.borrow() if on_device else
+    draw_ctx = kwargs.get('_draw_ctx') if kwargs.get('_draw_only', False) else None
+    with (_backend.borrowed(draw_ctx) if draw_ctx is not None else      # fit_restarts: one context for all draws
+          data.borrow() if on_device else
           _backend.sharded_context(data, form=_backend.FORM_DATA, dtype=self.dtype) if distributed else
           _backend.resident_context(data, form=_backend.FORM_DATA, dtype=self.dtype)) as ctx:
 
@@ -438,9 +441,10 @@ def _fit_on_data_matrix(self, data, linear_kernel, label, dictionary=None, weigh
                 exclude = kwargs.get('exclude', None)
                 if exclude is None:
                     exclude = np.array([], dtype='i8')
+                columns = kwargs['_cache'].setdefault('distance_columns', {}) if '_cache' in kwargs else None
                 selected = _furthest_sum_on_device(
                     ctx, n_samples, self.n_components, start_index,
-                    kwargs.get('n_extra_steps', 10), exclude)
+                    kwargs.get('n_extra_steps', 10), exclude, cache=columns)
                 return _one_hot_rows(selected, n_samples, np.float64)
             return _initialize_kernel_aa_dictionary(shape_only, self.n_components, init=init,
                                                     random_state=self.random_state)

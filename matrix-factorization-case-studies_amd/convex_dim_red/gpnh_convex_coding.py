@@ -322,7 +322,7 @@ class GPNHConvexCoding(object):
             exclude = kwargs.get('exclude', None)
             if exclude is None:
                 exclude = np.array([], dtype='i8')
-            cache = {}
+            cache = kwargs['_cache'].setdefault('distance_columns', {}) if '_cache' in kwargs else {}
 
             def column_of(j, sense):
                 j = int(j)
@@ -371,7 +371,9 @@ class GPNHConvexCoding(object):
             return self._initial_dictionary(None, data, kwargs), self._initial_weights(n_samples)
         # data resident across the drivers' n_init restarts (bin/run_jra55_pca_gpnh.py:123-136)
         distributed = _backend.distributed_env() is not None and not on_device   # see _backend.distributed_env
-        with (data.borrow() if on_device else
+        draw_ctx = kwargs.get('_draw_ctx') if kwargs.get('_draw_only', False) else None
+        with (_backend.borrowed(draw_ctx) if draw_ctx is not None else  # fit_restarts: one context for all draws
+              data.borrow() if on_device else
               _backend.sharded_context(data, dtype=self.dtype) if distributed else
               _backend.resident_context(data, dtype=self.dtype)) as ctx:
             ctx.set_linear_kernel(False)             # a reused context may come from KernelAA(features=True)

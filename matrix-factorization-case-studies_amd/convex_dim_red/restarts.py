@@ -283,18 +283,30 @@ def fit_restarts(make_model, data, n_init, n_jobs=None, devices=None, side_by_si
     with the lowest cost (the model the drivers' ``if cost < best_cost`` loop keeps)."""
     data = np.asarray(data)
     models, starts = [], []
-    cache = {}                                    # data-dependent constants of the initialisers
-    for _ in range(n_init):                       # RNG draws in the sequential loop's order
-        m = make_model()
-        if isinstance(m, ArchetypalAnalysis):
-            C0, Z0, a0 = m._aa(data, _draw_only=True)
-            starts.append(dict(dictionary=C0, weights=Z0, alpha=a0))
-        elif isinstance(m, GPNHConvexCoding):
-            W0, Z0 = m._gpnh_convex_coding(data, _draw_only=True, _cache=cache)
-            starts.append(dict(dictionary=W0, weights=Z0))
-        else:
-            raise TypeError("fit_restarts handles ArchetypalAnalysis and GPNHConvexCoding models")
-        models.append(m)
+    cache = {}                                    # data-dependent constants of the initialisers: |X| mean,
+                                                  # FurthestSum's distance columns (the same matrix every time)
+    draw_ctx = None                               # FurthestSum starts: ONE context for all draws
+    try:
+        for _ in range(n_init):                   # RNG draws in the sequential loop's order
+            m = make_model()
+            if not isinstance(m, (ArchetypalAnalysis, GPNHConvexCoding)):
+                raise TypeError("fit_restarts handles ArchetypalAnalysis and GPNHConvexCoding models")
+            needs_device = (m.init == 'furthest_sum' or (m.init is None and isinstance(m, ArchetypalAnalysis)))
+            if needs_device and draw_ctx is None and _backend.distributed_env() is None:
+                _backend.release_device_cache()
+                draw_ctx = _backend.Context(dtype=m.dtype)
+                draw_ctx.set_data(data)
+            extra = dict(_draw_ctx=draw_ctx) if (needs_device and draw_ctx is not None) else {}
+            if isinstance(m, ArchetypalAnalysis):
+                C0, Z0, a0 = m._aa(data, _draw_only=True, _cache=cache, **extra)
+                starts.append(dict(dictionary=C0, weights=Z0, alpha=a0))
+            else:
+                W0, Z0 = m._gpnh_convex_coding(data, _draw_only=True, _cache=cache, **extra)
+                starts.append(dict(dictionary=W0, weights=Z0))
+            models.append(m)
+    finally:
+        if draw_ctx is not None:
+            draw_ctx.close()
     _backend.release_device_cache()               # the workers bring their own contexts
     devices = [_backend.device_index()] if devices is None else [int(d) for d in devices]
     todo = list(range(n_init))
