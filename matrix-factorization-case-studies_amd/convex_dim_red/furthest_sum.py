@@ -30,7 +30,74 @@ def _validate(n_samples, n_components, start_index, exclude):
 
 
 class _Pool(object):
-    """Candidate pool as two aligned arrays in the reference's list order."""
+    """The reference's candidate list without its sorts.  The reference stably sorts the list by running
+    sum before every pick and pops the last element, so (a) the pick is the candidate with the
+    largest sum and (b) among equal sums the one positioned last wins, where "position" is the order
+    the PREVIOUS stable sort left -- i.e. the order by the sums at the previous pick, ties by the pick
+    before, ..., finally by the initial order; a candidate pushed back in between sits at the end of
+    the list (it compares as +inf at the sort before its push).  So the pick is a maximum search
+    (O(n)) and the history of sum vectors is consulted only to break a tie -- instead of a stable
+    sort of all candidates per pick (1.5 ms at 22 280 candidates, 19 picks per initialisation).
+    ``_SortedPool`` below is the literal form; tests/test_cpu_host.py checks the two against each
+    other on tie-heavy inputs."""
+
+    def __init__(self, members, sums):
+        members = np.asarray(members, dtype=np.int64)
+        self.n = int(members.max()) + 1 if members.size else 0
+        self.alive = np.zeros(self.n, dtype=bool)
+        self.alive[members] = True
+        self.sums = np.full(self.n, -np.inf)
+        self.sums[members] = np.asarray(sums, dtype=np.float64)
+        self.initial = np.full(self.n, -1, dtype=np.int64)       # position in the initial list
+        self.initial[members] = np.arange(members.size)
+        self.history = []                                         # sum vectors at the earlier sorts, latest last
+
+    def _grow(self, n):
+        if n <= self.n:
+            return
+        pad = n - self.n
+        self.alive = np.concatenate((self.alive, np.zeros(pad, dtype=bool)))
+        self.sums = np.concatenate((self.sums, np.full(pad, -np.inf)))
+        self.initial = np.concatenate((self.initial, np.full(pad, -1, dtype=np.int64)))
+        self.history = [np.concatenate((h, np.full(pad, -np.inf))) for h in self.history]
+        self.n = n
+
+    def take_furthest(self):
+        cur = np.where(self.alive, self.sums, -np.inf)
+        tied = np.flatnonzero(cur == cur.max())
+        depth = len(self.history)
+        while tied.size > 1 and depth > 0:                        # order the previous sorts left
+            depth -= 1
+            h = self.history[depth][tied]
+            tied = tied[h == h.max()]
+        if tied.size > 1:                                         # never told apart: the initial order
+            tied = tied[[int(np.argmax(self.initial[tied]))]]
+        chosen = int(tied[0])
+        self.history.append(cur)                                  # the sort that has just "happened"
+        self.alive[chosen] = False
+        return chosen
+
+    def shift(self, column, sign):
+        column = np.asarray(column)
+        self._grow(column.shape[0])
+        self.sums[self.alive] += sign * column[:self.n][self.alive]
+
+    def push(self, member, value):
+        member = int(member)
+        self._grow(member + 1)
+        self.alive[member] = True
+        self.sums[member] = value
+        # appended at the end of the list: after every candidate in the order the latest sort left
+        if self.history:
+            self.history[-1] = self.history[-1].copy()
+            self.history[-1][member] = np.inf
+        else:
+            self.initial[member] = self.initial.max() + 1
+
+
+class _SortedPool(object):
+    """Candidate pool as two aligned arrays in the reference's list order (the literal form:
+    furthest_sum.py:17-20 of the reference)."""
 
     def __init__(self, members, sums):
         self.members = np.asarray(members, dtype=np.int64)

@@ -118,6 +118,51 @@ def test_furthest_sum_golden():
         assert np.array_equal(cdr.furthest_sum(g["in_D_grid"], k, s, None, e), g[key]), key
 
 
+def test_furthest_sum_pool_without_sorts_matches_the_literal_pool():
+    """The candidate pool picks by a maximum search and consults the history of sum vectors only to
+    break ties (furthest_sum._Pool); the literal form -- a stable sort of the list before every pick,
+    pop the last (reference furthest_sum.py:17-20) -- is kept as _SortedPool.  Same selections on
+    random, tie-heavy (small integers, duplicate points) and asymmetric matrices, with exclusions and
+    up to eleven refinement rounds."""
+    import importlib
+    fs = importlib.import_module("convex_dim_red.furthest_sum")
+    rng = np.random.RandomState(0)
+    compared = 0
+    for trial in range(300):
+        n = rng.randint(3, 40)
+        kind = trial % 4
+        if kind == 0:
+            D = rng.uniform(size=(n, n))
+            D = D + D.T
+        elif kind == 1:
+            D = rng.randint(0, 3, size=(n, n)).astype(float)
+            D = D + D.T
+        elif kind == 2:
+            P = rng.randint(0, 2, size=(n, 2)).astype(float)
+            D = np.sqrt(((P[:, None] - P[None]) ** 2).sum(-1))
+        else:
+            D = rng.randint(0, 4, size=(n, n)).astype(float)
+        np.fill_diagonal(D, 0)
+        k = rng.randint(1, min(n, 8) + 1)
+        start = rng.randint(n)
+        nex = rng.randint(0, max(1, n - k))
+        exclude = [int(i) for i in rng.permutation(n)[:nex] if i != start][:max(0, n - k - 1)]
+        extra = rng.randint(0, 12)
+        try:
+            got = fs.furthest_sum(D, k, start, exclude=exclude, extra_steps=extra)
+        except ValueError:
+            continue
+        lazy = fs._Pool
+        fs._Pool = fs._SortedPool
+        try:
+            want = fs.furthest_sum(D, k, start, exclude=exclude, extra_steps=extra)
+        finally:
+            fs._Pool = lazy
+        assert list(got) == list(want), (trial, kind, n, k, start, exclude, extra)
+        compared += 1
+    assert compared > 200
+
+
 def test_furthest_sum_errors_and_edges():
     D = np.zeros((4, 4))
     with pytest.raises(ValueError):
