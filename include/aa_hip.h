@@ -389,7 +389,7 @@ int aa_gpnh_slots_fetch(aa_ctx *ctx, int r, double *Wt, long ld, double *Z, doub
 
 /* The same for archetypal analysis (bin/run_hadisst_aa.py:149-174; archetypal_analysis.py:534-670 per
  * restart): R fits of k components in the component slots of one set of arrays (R k <= 32), production
- * settings only (data form, one SPG iteration per dictionary update, delta = 0, fewer than 65 536 samples,
+ * settings only (data form, one SPG iteration per dictionary update, fewer than 65 536 samples,
  * k <= 16, single rank).  aa_slots_begin + aa_slots_load x R start the first restarts together;
  * aa_slots_run iterates every slot and reports its status (a stopped slot's factors of that iteration
  * are kept while the others go on); aa_slots_fetch returns a stopped slot's factors, cost record and
@@ -401,15 +401,15 @@ int aa_gpnh_slots_fetch(aa_ctx *ctx, int r, double *Wt, long ld, double *Z, doub
  * aa_slots_end returns the context to single fits.  status[r].not_spd carries the slot's SPG warning
  * flags (AA_SPG_FLAG_*).  Every restart gets the bits aa_iterate gives it on its own. */
 int aa_slots_begin(aa_ctx *ctx, int R, int k, const aa_iter_params *loop, const aa_spg_params *spg,
-                   const aa_qp_params *qp);
-int aa_slots_load(aa_ctx *ctx, int r, const double *C, long ldc, const double *Z);
+                   const aa_qp_params *qp, const aa_spg_params *scale_spg /* loop->delta != 0 */);
+int aa_slots_load(aa_ctx *ctx, int r, const double *C, long ldc, const double *Z, const double *alpha /* k, or NULL: ones */);
 int aa_slots_run(aa_ctx *ctx, int n_iters, aa_slot_status *status);
 /* a new restart into slot r of a RUNNING group (its previous occupant has stopped and been fetched): the
  * other slots keep the products they carry; the slot's next dictionary update is the cold one of a fit */
-int aa_slots_reload(aa_ctx *ctx, int r, const double *C, long ldc, const double *Z);
+int aa_slots_reload(aa_ctx *ctx, int r, const double *C, long ldc, const double *Z, const double *alpha);
 int aa_slots_finish(aa_ctx *ctx);     /* all slots stopped: stopping-iteration factors restored, products rebuilt */
 int aa_slots_fetch(aa_ctx *ctx, int r, double *C, long ldc, double *Z, double *CX, long ldx, int carried,
-                   double *costs, double *cost0);
+                   double *costs, double *cost0, double *alpha /* k scale factors out, nullable */);
 int aa_slots_end(aa_ctx *ctx);
 
 /* ------------------------------------------------------------------ GPNH */

@@ -145,13 +145,13 @@ _SIGNATURES = {
     "aa_gpnh_slots_run": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(SlotStatus)]),
     "aa_gpnh_slots_fetch": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp, _dp, _dp]),
     "aa_slots_begin": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IterParams),
-                                      ctypes.POINTER(SPGParams), ctypes.POINTER(QPParams)]),
-    "aa_slots_load": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp]),
+                                      ctypes.POINTER(SPGParams), ctypes.POINTER(QPParams), ctypes.POINTER(SPGParams)]),
+    "aa_slots_load": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp, _dp]),
     "aa_slots_run": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(SlotStatus)]),
-    "aa_slots_reload": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp]),
+    "aa_slots_reload": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp, _dp]),
     "aa_slots_finish": (ctypes.c_int, [_vp]),
     "aa_slots_fetch": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_int,
-                                      _dp, _dp]),
+                                      _dp, _dp, _dp]),
     "aa_slots_end": (ctypes.c_int, [_vp]),
     "aa_get_spg_scalars": (ctypes.c_int, [_vp, _dp]),
     "aa_pass_reduce_rows": (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, ctypes.c_long]),
@@ -651,25 +651,28 @@ class Context(object):
 
     # ---- AA restarts side by side (aa_slots_*)
     def aa_slots_begin(self, n_slots, k, max_outer, tolerance, stopping_criterion, require_monotonic, spg_kw, qp_kw,
-                       mono_tolerance=None):
+                       mono_tolerance=None, delta=0.0, scale_kw=None):
         crit = {"abs_delta_f": 0, "rel_delta_f": 1}.get(stopping_criterion)
         if crit is None:
             raise ValueError("unsupported stopping criterion '%s'" % stopping_criterion)
         ip = IterParams(int(max_outer), float(tolerance), crit, int(bool(require_monotonic)),
-                        float(tolerance if mono_tolerance is None else mono_tolerance), 1, 1, 8, 0.0)
+                        float(tolerance if mono_tolerance is None else mono_tolerance), 1, 1, 8, float(delta))
         sp, qp = spg_params(**spg_kw), qp_params(**qp_kw)
+        scale = spg_params(**(scale_kw or {})) if delta != 0 else None
         _check(self.lib.aa_slots_begin(self.h, int(n_slots), int(k), ctypes.byref(ip), ctypes.byref(sp),
-                                       ctypes.byref(qp)))
+                                       ctypes.byref(qp), ctypes.byref(scale) if scale is not None else None))
         self.k = int(n_slots) * int(k)
         self._slots = (int(n_slots), int(k), int(max_outer))
 
-    def aa_slots_load(self, r, C, Z):
+    def aa_slots_load(self, r, C, Z, alpha=None):
         C, Z = _c64(C), _c64(Z)
-        _check(self.lib.aa_slots_load(self.h, int(r), _ptr(C), C.shape[1], _ptr(Z)))
+        a = None if alpha is None else _c64(alpha)
+        _check(self.lib.aa_slots_load(self.h, int(r), _ptr(C), C.shape[1], _ptr(Z), None if a is None else _ptr(a)))
 
-    def aa_slots_reload(self, r, C, Z):
+    def aa_slots_reload(self, r, C, Z, alpha=None):
         C, Z = _c64(C), _c64(Z)
-        _check(self.lib.aa_slots_reload(self.h, int(r), _ptr(C), C.shape[1], _ptr(Z)))
+        a = None if alpha is None else _c64(alpha)
+        _check(self.lib.aa_slots_reload(self.h, int(r), _ptr(C), C.shape[1], _ptr(Z), None if a is None else _ptr(a)))
 
     def aa_slots_run(self, n_iters):
         st = (SlotStatus * self._slots[0])()
@@ -680,16 +683,17 @@ class Context(object):
         _check(self.lib.aa_slots_finish(self.h))
 
     def aa_slots_fetch(self, r, stop_iter, carried):
-        """(weights n x k, dictionary k x n, C X k x p, cost0, costs[2 (stop_iter + 1)]) of a stopped slot."""
+        """(weights n x k, dictionary k x n, C X k x p, cost0, costs[2 (stop_iter + 1)], alpha[k]) of a stopped slot."""
         _, k, _ = self._slots
         C = np.empty((k, self.n))
         Z = np.empty((self.n, k))
         CX = np.empty((k, self.p))
+        alpha = np.ones(k)
         costs = np.zeros(2 * (int(stop_iter) + 1))
         c0 = ctypes.c_double(0)
         _check(self.lib.aa_slots_fetch(self.h, int(r), _ptr(C), self.n, _ptr(Z), _ptr(CX), self.p, int(bool(carried)),
-                                       _ptr(costs), ctypes.byref(c0)))
-        return Z, C, CX, c0.value, costs
+                                       _ptr(costs), ctypes.byref(c0), _ptr(alpha)))
+        return Z, C, CX, c0.value, costs, alpha
 
     def aa_slots_end(self):
         _check(self.lib.aa_slots_end(self.h))

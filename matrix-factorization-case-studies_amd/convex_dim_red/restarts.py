@@ -9,7 +9,7 @@ restarts first, in the drivers' order (so every restart starts exactly where it 
 sequential loop), and then
 
 * GPNH models, and AA models with the drivers' settings (one SPG iteration per dictionary update,
-  delta = 0, fewer than 65 536 samples, k <= 16): lays the restarts SIDE BY SIDE in the component slots of
+  any delta, fewer than 65 536 samples, k <= 16): lays the restarts SIDE BY SIDE in the component slots of
   one set of device arrays, where they share every launch of an outer iteration; a restart that stops
   hands its slot to the next one (``_fit_gpnh_slots`` / aa_gpnh_slots_*, ``_fit_aa_slots`` /
   aa_slots_*): 3.5-5x the sequential loop's speed on the JRA-55- and HadISST-shaped problems with
@@ -158,8 +158,8 @@ def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
 
 
 def _aa_slots_eligible(models, data):
-    """AA restarts that can share one set of device arrays (aa_slots_*): production settings -- one SPG
-    iteration per dictionary update, delta = 0 -- same hyper-parameters, fewer than 65 536 samples, k <= 16."""
+    """AA restarts that can share one set of device arrays (aa_slots_*): the drivers' setting -- one SPG
+    iteration per dictionary update -- same hyper-parameters, fewer than 65 536 samples, k <= 16."""
     m0 = models[0]
     if not all(type(m) is ArchetypalAnalysis for m in models) or len(models) < 2:
         return False
@@ -170,7 +170,8 @@ def _aa_slots_eligible(models, data):
         return False
     k = m0.n_components
     dkw = dict(m0.dictionary_solver_kwargs)
-    return (isinstance(k, int) and 1 <= k <= 16 and m0.delta == 0 and data.shape[0] < 65536
+    return (isinstance(k, int) and 1 <= k <= 16 and data.shape[0] < 65536
+            and m0.scale_factors_solver_kwargs.get("memory", 10) <= 16
             and dkw.get("max_iterations", 1000) == 1 and dkw.get("memory", 1) <= 16
             and m0.weights_solver_kwargs.get("memory", 1) <= 1
             and m0.weights_solver_kwargs.get("max_iterations", 1000) >= 1
@@ -210,10 +211,11 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
         t0 = time.perf_counter()
         ctx.aa_slots_begin(n_slots, k, m0.max_iterations, m0.tolerance, m0.stopping_criterion,
                            m0.require_monotonic_cost_decrease, m0.dictionary_solver_kwargs,
-                           m0.weights_solver_kwargs, mono_tolerance=mono_tol)
+                           m0.weights_solver_kwargs, mono_tolerance=mono_tol, delta=m0.delta,
+                           scale_kw=m0.scale_factors_solver_kwargs)
         for r in range(n_slots):                  # the first group starts together
             i = pending.pop(0)
-            ctx.aa_slots_load(r, starts[i]["dictionary"], starts[i]["weights"])
+            ctx.aa_slots_load(r, starts[i]["dictionary"], starts[i]["weights"], starts[i]["alpha"])
             owner[r] = i
             loaded_at[r] = time.perf_counter()
         prof["load"] += time.perf_counter() - t0
@@ -235,10 +237,13 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
                 else:
                     # aa_iterate rebuilds the products only when it ran past the stopping iteration
                     carried = (st.stop_iter + 1) % _DEVICE_LOOP_BATCH == 0 or st.stop_iter + 1 == m.max_iterations
-                    Z, C, CX, cost0, costs = ctx.aa_slots_fetch(r, st.stop_iter, carried)
+                    Z, C, CX, cost0, costs, alpha = ctx.aa_slots_fetch(r, st.stop_iter, carried)
                     finals = costs[1::2]
                     begins = np.concatenate(([cost0], finals[:-1]))
-                    m.weights, m.dictionary, m.alpha = Z, C, np.ones(k)
+                    if m.delta != 0:                  # ArchetypalAnalysis.fit_transform (reference :1140-1144)
+                        C = np.dot(np.diag(alpha), C)
+                        CX = alpha[:, np.newaxis] * CX
+                    m.weights, m.dictionary, m.alpha = Z, C, alpha
                     m.cost, m.n_iter = float(finals[-1]), int(st.stop_iter)
                     m.cost_deltas = [d for d in finals - begins]
                     m.avg_time_per_iter = (time.perf_counter() - loaded_at[r]) / max(st.iterations_run, 1)
@@ -251,7 +256,7 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
                 if pending:
                     t0 = time.perf_counter()
                     i = pending.pop(0)
-                    ctx.aa_slots_reload(r, starts[i]["dictionary"], starts[i]["weights"])
+                    ctx.aa_slots_reload(r, starts[i]["dictionary"], starts[i]["weights"], starts[i]["alpha"])
                     owner[r] = i
                     loaded_at[r] = time.perf_counter()
                     prof["load"] += loaded_at[r] - t0
@@ -274,7 +279,7 @@ def fit_restarts(make_model, data, n_init, n_jobs=None, devices=None, side_by_si
     matrix is uploaded ONCE per device and the workers of a device share that copy
     (``aa_share_data``), each with its own factors, streams and scratch.
     ``side_by_side`` (models with the same hyper-parameters; GPNH with k <= 16, AA with the drivers'
-    settings -- one SPG iteration per dictionary update, delta = 0, fewer than 65 536 samples, k <= 16):
+    settings -- one SPG iteration per dictionary update, fewer than 65 536 samples, k <= 16):
     the restarts run ``n_slots`` at a time (default: 64 // k for GPNH, 32 // k for AA) in ONE set of
     device arrays per device and share every launch of an outer iteration (``_fit_gpnh_slots``,
     ``_fit_aa_slots``); with several ``devices`` restart i runs on device i mod G; ``n_jobs`` is not

@@ -159,7 +159,7 @@ struct Ctx {
     DevBuf slotSaveP, slotSaveGr;              // C X and (C X X')' of the running slots across a reload
     DevBuf slotScal, slotSnapP;
     aa_iter_params slots_ip;
-    aa_spg_params slots_sp;
+    aa_spg_params slots_sp, slots_scale_sp;
     aa_gpnh_params slots_gp;
     aa_qp_params slots_qp;
     DevBuf qpLive;                             // ready[cap] | done[cap] flags of the live hand-over (QpLive)

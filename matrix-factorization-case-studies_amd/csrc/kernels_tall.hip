@@ -2393,9 +2393,22 @@ __global__ __launch_bounds__(64) void k_scale_factors_spg(const double *__restri
                                                           const double *__restrict__ costs,
                                                           const int *__restrict__ slot,
                                                           IterState *__restrict__ st, double mono_tol,
-                                                          int require)
+                                                          int require, const double *slot_costs = nullptr,
+                                                          int slot_stride = 0, const double *slot_cost0 = nullptr)
 {
     extern __shared__ double lds[];               // B1 [k][k+1] | B2 [k][k+1] | xs [64]
+    if (slot_costs) {
+        // restarts side by side (aa_slots_*): block = slot -- its diagonal blocks of the Gram state, its
+        // k scale factors, its cost record, counter and status; the iteration index is the record's
+        const int r = blockIdx.x;
+        state += (size_t)(r * k) * KP + r * k;
+        alpha += r * k;
+        costs = slot_costs + (size_t)r * slot_stride;
+        slot += r;
+        st += r;
+        cost0 = slot_cost0[r];
+        it = *slot / 2;
+    }
     const int i = threadIdx.x, ldb = k + 1;
     double *B1 = lds, *B2 = lds + (size_t)k * ldb, *xs = lds + (size_t)2 * k * ldb;
     const int GS = KP * KP;
@@ -2492,7 +2505,7 @@ __global__ __launch_bounds__(64) void k_scale_factors_spg(const double *__restri
         }
     }
     if (!converged && !(flags & AA_SPG_FLAG_MAX_FEVAL)) flags |= AA_SPG_FLAG_MAX_ITER;   // :278-281
-    if (i < KP) alpha[i] = live ? x : 0.0;
+    if (slot_costs ? live : i < KP) alpha[i] = live ? x : 0.0;
     // cost with the new scale factors (archetypal_analysis.py:601-609); padding lanes carry 0
     const double m2 = matvec(B2, x);
     const double cost = 0.5 * (trace - 2.0 * sf_wsum(live ? x * ci : 0.0) + sf_wsum(live ? x * m2 : 0.0)) / n_global;
@@ -2513,6 +2526,18 @@ __global__ __launch_bounds__(64) void k_scale_factors_spg(const double *__restri
 int launch_scale_factors(Ctx *c, const aa_spg_params *sp, double delta_box, int it, double cost0,
                          const double *costs, const int *slot, IterState *st, double mono_tol, int require)
 {
+    if (c->slots_aa) {
+        const int k = c->slots_k;
+        const size_t lds_s = ((size_t)2 * k * (k + 1) + 64) * sizeof(double);
+        hipLaunchKernelGGL(k_scale_factors_spg, dim3((unsigned)c->slots_R), dim3(64), lds_s, c->stream,
+                           (const double *)c->gramState.as<double>(), c->alphaDev.as<double>(), k, c->KP,
+                           c->trace, (double)c->n_global, delta_box, *sp, 0, 0.0, (const double *)nullptr,
+                           (const int *)c->slotCounters.as<int>(), c->slotStates.as<IterState>(), mono_tol, require,
+                           (const double *)c->slotCosts.as<double>(), c->slots_stride,
+                           (const double *)c->slotCost0.as<double>());
+        AA_CHECK_HIP(hipGetLastError());
+        return AA_OK;
+    }
     const size_t lds = ((size_t)2 * c->k * (c->k + 1) + 64) * sizeof(double);
     hipLaunchKernelGGL(k_scale_factors_spg, dim3(1), dim3(64), lds, c->stream,
                        (const double *)c->gramState.as<double>(), c->alphaDev.as<double>(), c->k, c->KP,
@@ -3145,7 +3170,9 @@ __global__ __launch_bounds__(256) void k_aa_cost_slots(const double *__restrict_
 __global__ __launch_bounds__(256) void k_aa_snap_slots(const double *__restrict__ Ct, double *__restrict__ snapC,
                                                        const double *__restrict__ Zt, double *__restrict__ snapZ,
                                                        long n_pad, int KP, const double *__restrict__ P,
-                                                       double *__restrict__ snapP, int ld, GpnhSlots sl)
+                                                       double *__restrict__ snapP, int ld, GpnhSlots sl,
+                                                       const double *__restrict__ alpha,
+                                                       double *__restrict__ snapAlpha)
 {
     for (int r = 0; r < sl.R; ++r) {
         const IterState st = sl.st[r];
@@ -3158,6 +3185,7 @@ __global__ __launch_bounds__(256) void k_aa_snap_slots(const double *__restrict_
             snapC[row * KP + i] = Ct[row * KP + i];
             snapZ[row * KP + i] = Zt[row * KP + i];
         }
+        if (blockIdx.x == 0 && (int)threadIdx.x < k) snapAlpha[o + threadIdx.x] = alpha[o + threadIdx.x];
         // C X as the loop carries it (P + lambda Q, update after update): what aa_get_archetypes returns
         // when the loop stops on the last iteration of a batch (no restore, no recomputation)
         for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)k * ld; e += (long)gridDim.x * 256)
@@ -3195,7 +3223,8 @@ int launch_aa_snap_slots(Ctx *c)
 {
     hipLaunchKernelGGL(k_aa_snap_slots, dim3(256), dim3(256), 0, c->stream, (const double *)c->Ct.as<double>(),
                        c->snapC.as<double>(), (const double *)c->Zt.as<double>(), c->snapZ.as<double>(), c->n_pad,
-                       c->KP, (const double *)c->P.as<double>(), c->slotSnapP.as<double>(), (int)c->p_pad, slots_of(c));
+                       c->KP, (const double *)c->P.as<double>(), c->slotSnapP.as<double>(), (int)c->p_pad, slots_of(c),
+                       (const double *)c->alphaDev.as<double>(), c->snapAlpha.as<double>());
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }

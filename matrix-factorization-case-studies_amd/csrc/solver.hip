@@ -1465,9 +1465,11 @@ int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp,
 // settings only: data form, one SPG iteration per dictionary update, delta = 0, single rank,
 // fewer than 65 536 samples, k <= 16.
 int aa_slots_begin(aa_ctx *h, int R, int k, const aa_iter_params *ip, const aa_spg_params *spg,
-                   const aa_qp_params *qp)
+                   const aa_qp_params *qp, const aa_spg_params *scale_spg)
 {
     AA_REQUIRE(h && ip && spg && qp, AA_ERR_ARG, "null argument");
+    AA_REQUIRE(ip->delta == 0.0 || (scale_spg && scale_spg->memory <= 16), AA_ERR_ARG,
+               "slots: delta != 0 needs the scale-factor SPG parameters (memory <= 16)");
     Ctx *c = &h->c;
     AA_CHECK_HIP(hipSetDevice(c->device));
     AA_REQUIRE(c->have_data && c->form == AA_FORM_DATA && !c->linear_kernel, AA_ERR_STATE, "AA slots need a data matrix");
@@ -1477,8 +1479,7 @@ int aa_slots_begin(aa_ctx *h, int R, int k, const aa_iter_params *ip, const aa_s
     AA_REQUIRE(R >= 1 && k >= 1 && k <= 16 && R * k <= 32, AA_ERR_ARG,
                "slots: R = %d restarts of k = %d components do not fit 32 component slots", R, k);
     AA_REQUIRE(c->n < 65536, AA_ERR_ARG, "AA slots: fewer than 65 536 samples");
-    AA_REQUIRE(ip->max_outer >= 1 && ip->update_dictionary && ip->update_weights && ip->delta == 0.0, AA_ERR_ARG,
-               "slots: both updates, delta = 0");
+    AA_REQUIRE(ip->max_outer >= 1 && ip->update_dictionary && ip->update_weights, AA_ERR_ARG, "slots: both updates");
     AA_REQUIRE(spg->max_iterations == 1 && spg->memory <= 16, AA_ERR_ARG, "slots: one SPG iteration per dictionary update");
     AA_REQUIRE(g_fuse_finalize && g_proj_mode == 0, AA_ERR_STATE, "slots: default projection options");
     c->slots_aa = false;
@@ -1494,10 +1495,12 @@ int aa_slots_begin(aa_ctx *h, int R, int k, const aa_iter_params *ip, const aa_s
     c->slots_ip = *ip;
     c->slots_sp = *spg;
     c->slots_qp = *qp;
+    if (scale_spg) c->slots_scale_sp = *scale_spg;
     AA_CHECK(c->slotCosts.alloc((size_t)R * c->slots_stride * sizeof(double)));
     AA_CHECK(c->slotCounters.alloc(64 * sizeof(int)));
     AA_CHECK(c->slotStates.alloc(32 * sizeof(IterState)));
     AA_CHECK(c->slotCost0.alloc(32 * sizeof(double)));
+    AA_CHECK(c->snapAlpha.alloc(64 * sizeof(double)));
     c->scalars.release();
     AA_CHECK(c->scalars.alloc((size_t)(R + 1) * AA_SC_STRIDE * sizeof(double)));      // one block per slot
     const size_t tall_bytes = (size_t)c->n_pad * c->KP * sizeof(double);
@@ -1534,7 +1537,19 @@ int aa_slots_begin(aa_ctx *h, int R, int k, const aa_iter_params *ip, const aa_s
 
 // start factors of a restart into slot r (C: k x n, leading dimension ldc; Z: n x k), the products of
 // the stacked state rebuilt (aa_prepare's passes), the slot's initial cost
-int aa_slots_load(aa_ctx *h, int r, const double *C, long ldc, const double *Z)
+static int slots_set_alpha(Ctx *c, int r, const double *alpha, bool running)
+{
+    // the host copy follows the device's (the scale-factor kernel moves the running slots' factors)
+    if (running) {
+        std::vector<double> a(c->KP, 1.0);
+        AA_CHECK_HIP(hipMemcpy(a.data(), c->alphaDev.p, (size_t)c->KP * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < c->k; ++i) c->alpha[i] = a[i];
+    }
+    for (int i = 0; i < c->slots_k; ++i) c->alpha[r * c->slots_k + i] = alpha ? alpha[i] : 1.0;
+    return upload_alpha(c);
+}
+
+int aa_slots_load(aa_ctx *h, int r, const double *C, long ldc, const double *Z, const double *alpha)
 {
     AA_REQUIRE(h && C && Z, AA_ERR_ARG, "null argument");
     Ctx *c = &h->c;
@@ -1555,6 +1570,7 @@ int aa_slots_load(aa_ctx *h, int r, const double *C, long ldc, const double *Z)
     memset(&zero, 0, sizeof(zero));
     AA_CHECK_HIP(hipMemcpy(c->slotStates.as<IterState>() + r, &zero, sizeof(zero), hipMemcpyHostToDevice));
     AA_CHECK_HIP(hipMemset(c->slotCounters.as<int>() + r, 0, sizeof(int)));
+    AA_CHECK(slots_set_alpha(c, r, alpha, false));
     c->products_valid = false;
     c->grams_valid = false;
     c->slots_started = false;
@@ -1564,7 +1580,7 @@ int aa_slots_load(aa_ctx *h, int r, const double *C, long ldc, const double *Z)
 // a new restart into slot r of a RUNNING group (its previous occupant has stopped and been fetched):
 // the factors, the products aa_prepare computes -- for this slot; the other slots keep the products
 // they carry -- its initial cost; its next dictionary update is the cold one of a fit.
-int aa_slots_reload(aa_ctx *h, int r, const double *C, long ldc, const double *Z)
+int aa_slots_reload(aa_ctx *h, int r, const double *C, long ldc, const double *Z, const double *alpha)
 {
     AA_REQUIRE(h && C && Z, AA_ERR_ARG, "null argument");
     Ctx *c = &h->c;
@@ -1585,6 +1601,7 @@ int aa_slots_reload(aa_ctx *h, int r, const double *C, long ldc, const double *Z
     memset(&zero, 0, sizeof(zero));
     AA_CHECK_HIP(hipMemcpy(c->slotStates.as<IterState>() + r, &zero, sizeof(zero), hipMemcpyHostToDevice));
     AA_CHECK_HIP(hipMemset(c->slotCounters.as<int>() + r, 0, sizeof(int)));
+    AA_CHECK(slots_set_alpha(c, r, alpha, true));
     // a fit starts its projections cold (aa_set_state): a warm threshold of +inf selects nothing, which
     // is the cold start of k_proj_small -- for this slot's columns, in both projection states
     {
@@ -1664,6 +1681,11 @@ int aa_slots_run(aa_ctx *h, int n_iters, aa_slot_status *status)
     }
     bool recorded = false;
     for (int it = 0; it < n_iters; ++it) {
+        if (c->slots_ip.delta != 0.0) {           // archetypal_analysis.py:590-609, once per slot
+            AA_CHECK(ensure_ckz(c));
+            AA_CHECK(launch_scale_factors(c, &c->slots_scale_sp, c->slots_ip.delta, 0, 0.0, nullptr, nullptr, nullptr,
+                                          c->slots_ip.mono_tolerance, c->slots_ip.require_monotonic));
+        }
         if (c->slots_cold) {                      // (aa_slots_reload) the cold update of the freshly loaded slots
             c->x_feasible = false;
             c->products_valid = false;
@@ -1717,7 +1739,7 @@ int aa_slots_finish(aa_ctx *h)
 // from the fetched C after aa_slots_finish, or -- carried != 0 -- as the loop carried it at the stopping
 // iteration), cost record and initial cost of a stopped slot
 int aa_slots_fetch(aa_ctx *h, int r, double *C, long ldc, double *Z, double *CX, long ldx, int carried,
-                   double *costs, double *cost0)
+                   double *costs, double *cost0, double *alpha)
 {
     AA_REQUIRE(h && C && Z && costs && cost0 && CX, AA_ERR_ARG, "null argument");
     Ctx *c = &h->c;
@@ -1740,6 +1762,8 @@ int aa_slots_fetch(aa_ctx *h, int r, double *C, long ldc, double *Z, double *CX,
     AA_CHECK_HIP(hipMemcpy(costs, c->slotCosts.as<double>() + (size_t)r * c->slots_stride,
                            (size_t)2 * (st.stop_iter + 1) * sizeof(double), hipMemcpyDeviceToHost));
     AA_CHECK_HIP(hipMemcpy(cost0, c->slotCost0.as<double>() + r, sizeof(double), hipMemcpyDeviceToHost));
+    if (alpha)                                                // the scale factors of the stopping iteration
+        AA_CHECK_HIP(hipMemcpy(alpha, c->snapAlpha.as<double>() + o, (size_t)k * sizeof(double), hipMemcpyDeviceToHost));
     AA_REQUIRE(ldx >= c->p, AA_ERR_ARG, "ldx < p");
     if (!carried) {
         // C X recomputed from the stopping iteration's dictionary: the pass aa_prepare runs (on the

@@ -641,7 +641,8 @@ def test_gpnh_restarts_side_by_side(cdr, orc, case):
     assert best == int(np.argmin([m.cost for m in seq]))
 
 
-@pytest.mark.parametrize("case", ["stopping_rule", "iteration_cap", "float32", "furthest_sum", "list_projection"])
+@pytest.mark.parametrize("case", ["stopping_rule", "iteration_cap", "float32", "furthest_sum", "list_projection",
+                                  "delta", "delta_float32"])
 def test_aa_restarts_side_by_side(cdr, orc, case):
     """fit_restarts on ArchetypalAnalysis models with the drivers' settings (bin/run_hadisst_aa.py:149-174:
     one SPG iteration per dictionary update, delta = 0): 32 // k restarts sit side by side in the
@@ -662,11 +663,13 @@ def test_aa_restarts_side_by_side(cdr, orc, case):
     Zt = orc.right_stochastic_matrix((n, k), rng) ** 4
     Zt /= Zt.sum(axis=1, keepdims=True)
     X = Zt.dot(B) + 0.05 * rng.standard_normal((n, p))
-    dtype = "float32" if case == "float32" else "float64"
+    dtype = "float32" if case in ("float32", "delta_float32") else "float64"
     if dtype == "float32":
         X = X.astype(np.float32)
     kw = dict(init="furthest_sum" if case == "furthest_sum" else "random", tolerance=1e-5, max_iterations=500,
               dtype=dtype, dictionary_solver_kwargs=dict(max_iterations=1))
+    if case.startswith("delta"):              # scale factors in [1 - delta, 1 + delta]: the k-vector SPG once per slot
+        kw.update(delta=0.15)
     if case == "iteration_cap":
         kw.update(tolerance=0, max_iterations=11, require_monotonic_cost_decrease=False)
     if case == "list_projection":
@@ -762,8 +765,8 @@ def test_restart_slots_print_the_verbose_tables(cdr, orc, family, capsys):
 def test_restart_slots_only_where_the_single_fit_runs_the_same_kernels(cdr, orc):
     """Settings outside the ones the slots reproduce bit for bit -- a GPNH weights QP of more than four
     passes (a single fit then uses the four-lane and wave kernels), AA with several SPG iterations per
-    dictionary update or delta != 0 -- go through the worker-thread path, with the same results as the
-    sequential loop."""
+    dictionary update -- go through the worker-thread path, with the same results as the sequential
+    loop."""
     import warnings
     from convex_dim_red import restarts
     rng = np.random.RandomState(9)
@@ -774,8 +777,6 @@ def test_restart_slots_only_where_the_single_fit_runs_the_same_kernels(cdr, orc)
                                         stopping_criterion="rel_delta_f", weights_solver_kwargs=dict(max_iterations=50)),
         lambda rs: cdr.ArchetypalAnalysis(k, init="random", tolerance=1e-5, max_iterations=40, random_state=rs,
                                           dictionary_solver_kwargs=dict(max_iterations=3)),
-        lambda rs: cdr.ArchetypalAnalysis(k, delta=0.1, init="random", tolerance=1e-5, max_iterations=40, random_state=rs,
-                                          dictionary_solver_kwargs=dict(max_iterations=1)),
     ]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
