@@ -65,12 +65,13 @@ def _slots_eligible(models):
     if any(getattr(m, a) != getattr(m0, a) for m in models[1:] for a in keys):
         return False
     k = m0.n_components
-    # (weights QP of at most four SPG passes -- the drivers' setting is one: the slots run the
-    # lane-per-sample kernel to completion, which is what a single fit uses for such QPs and only for
-    # them, so only then does every restart get the bits it gets alone)
-    return (isinstance(k, int) and 1 <= k <= 16 and not m0.dictionary_solver_kwargs
-            and m0.weights_solver_kwargs.get("memory", 1) <= 8
-            and 1 <= m0.weights_solver_kwargs.get("max_iterations", 1000) <= 4
+    # (weights QPs of at most four SPG passes -- the drivers' setting is one -- run in the
+    # lane-per-sample kernel, longer ones in the four-lane and wave-per-sample kernels: per slot what a
+    # single fit runs, so every restart gets the bits it gets alone)
+    passes = m0.weights_solver_kwargs.get("max_iterations", 1000)
+    memory = m0.weights_solver_kwargs.get("memory", 1)
+    return (isinstance(k, int) and 1 <= k <= 16 and not m0.dictionary_solver_kwargs and passes >= 1
+            and (memory <= 8 if passes <= 4 else memory <= 1)
             and _backend.distributed_env() is None)
 
 

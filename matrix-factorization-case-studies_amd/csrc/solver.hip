@@ -1814,6 +1814,8 @@ int aa_gpnh_slots_begin(aa_ctx *h, int R, int k, const aa_gpnh_params *gp, const
                "slots: both updates, max_outer >= 1");
     AA_REQUIRE(ip->criterion == 0 || ip->criterion == 1, AA_ERR_ARG, "bad stopping criterion");
     AA_REQUIRE(qp->max_iterations >= 1 && qp->memory <= 8, AA_ERR_ARG, "slots: QP max_iterations >= 1, memory <= 8");
+    AA_REQUIRE(qp->max_iterations <= 4 || (qp->memory <= 1 && k <= 16 && c->n < 65536), AA_ERR_ARG,
+               "slots: QPs of more than four passes need memory 1, k <= 16, fewer than 65 536 samples");
     c->k = 0;                                         // force fresh, zeroed factor arrays
     AA_CHECK(ensure_problem(c, R * k));
     AA_CHECK(ensure_trace(c));
@@ -1898,7 +1900,10 @@ int aa_gpnh_slots_run(aa_ctx *h, int n_iters, aa_slot_status *status)
         AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));       // X W
         if (!gram_in_cost) AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), dev_CKCt(c)));
         AA_CHECK(launch_gpnh_cost_slots(c, lambda, all, 1, ip, gram_in_cost));
-        AA_CHECK(launch_qp_slots(c, R, k, dev_CKCt(c), &c->slots_qp));
+        // at most four SPG passes per QP: the lane-per-sample kernel, as in a single fit; more: the
+        // four-lane and wave-per-sample kernels of the AA slots (the Hessian blocks are W'W's)
+        if (c->slots_qp.max_iterations <= 4) AA_CHECK(launch_qp_slots(c, R, k, dev_CKCt(c), &c->slots_qp));
+        else AA_CHECK(launch_qp_slots_aa(c, &c->slots_qp));
         AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
         AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), nullptr));
         AA_CHECK(launch_gpnh_cost_slots(c, lambda, all, 2, ip, false));

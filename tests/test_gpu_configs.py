@@ -597,7 +597,7 @@ def test_two_ranks_match_one_rank(cdr):
     assert "MULTI_RANK_ESTIMATORS_OK world=2" in out.stdout, out.stdout[-3000:]
 
 
-@pytest.mark.parametrize("case", ["stopping_rule", "iteration_cap", "float32", "three_slots"])
+@pytest.mark.parametrize("case", ["stopping_rule", "iteration_cap", "float32", "three_slots", "long_qp"])
 def test_gpnh_restarts_side_by_side(cdr, orc, case):
     """fit_restarts on GPNH models (bin/run_jra55_pca_gpnh.py:112-138): the restarts sit
     side by side in the component slots of ONE set of device arrays and share every launch of an
@@ -620,6 +620,8 @@ def test_gpnh_restarts_side_by_side(cdr, orc, case):
               dtype=dtype, weights_solver_kwargs=dict(max_iterations=1))
     if case == "iteration_cap":
         kw.update(tolerance=0, max_iterations=13, require_monotonic_cost_decrease=False)
+    if case == "long_qp":                      # the reference's default weights solver: QPs run to convergence
+        kw.update(weights_solver_kwargs={}, max_iterations=60)
     n_init = 9
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -764,9 +766,8 @@ def test_restart_slots_print_the_verbose_tables(cdr, orc, family, capsys):
 
 def test_restart_slots_only_where_the_single_fit_runs_the_same_kernels(cdr, orc):
     """Settings outside the ones the slots reproduce bit for bit -- a GPNH weights QP of more than four
-    passes (a single fit then uses the four-lane and wave kernels), AA with several SPG iterations per
-    dictionary update -- go through the worker-thread path, with the same results as the sequential
-    loop."""
+    passes with a non-monotone memory, AA with several SPG iterations per dictionary update -- go
+    through the worker-thread path, with the same results as the sequential loop."""
     import warnings
     from convex_dim_red import restarts
     rng = np.random.RandomState(9)
@@ -774,7 +775,8 @@ def test_restart_slots_only_where_the_single_fit_runs_the_same_kernels(cdr, orc)
     X = orc.right_stochastic_matrix((n, k), rng).dot(rng.standard_normal((k, p))) + 0.1 * rng.standard_normal((n, p))
     makers = [
         lambda rs: cdr.GPNHConvexCoding(k, lambda_W=0.2, init="random", tolerance=1e-5, max_iterations=60, random_state=rs,
-                                        stopping_criterion="rel_delta_f", weights_solver_kwargs=dict(max_iterations=50)),
+                                        stopping_criterion="rel_delta_f",
+                                        weights_solver_kwargs=dict(max_iterations=50, memory=3)),
         lambda rs: cdr.ArchetypalAnalysis(k, init="random", tolerance=1e-5, max_iterations=40, random_state=rs,
                                           dictionary_solver_kwargs=dict(max_iterations=3)),
     ]
