@@ -2379,8 +2379,13 @@ int launch_qp_slots_aa(Ctx *c, const aa_qp_params *p)
     else if (g_qp_quad_occ == 3) QQS(k_qp_quad_w3);
     else QQS(k_qp_quad);
 #undef QQS
+    // (a wave per parked sample: no more blocks per slot than a quarter of its samples -- which block
+    // continues a sample does not enter its arithmetic, and R x 1024 mostly idle blocks cost 49 us)
+    long wblocks = (n + 3) / 4;
+    if (wblocks < 64) wblocks = 64;
+    if (wblocks > g_qp_wave_blocks) wblocks = g_qp_wave_blocks;
     if (cap < p->max_iterations)
-        hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)g_qp_wave_blocks, (unsigned)R), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)wblocks, (unsigned)R), dim3(256), 0, c->stream,
                            (const double *)A2d, Bt, (long)1, (long)c->KP, (const double *)bsd, Zt, c->KP, (long)-1, k,
                            *p, (int *)nullptr, hdr, (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr,
                            (const int *)nullptr, (const unsigned int *)nullptr, 1 << 30, (unsigned int *)nullptr,
