@@ -3,10 +3,12 @@
 Mirrors the public classes and the test-visible private functions of reference
 src/convex_dim_red/archetypal_analysis.py (same names, argument meaning, return
 tuples, exceptions and warnings); every numeric step runs on the GPU through
-``_backend.Context`` (csrc/solver.hip).  What stays on the host is what the reference
-keeps in Python around its numba kernels: argument validation, RNG-ordered
-initialisation, the k-vector scale-factor update (``delta != 0``), monotonicity and
-stopping checks, timing and verbose tables.
+``_backend.Context`` (csrc/solver.hip) -- the alternating loop included: the monotonicity
+check, the stopping rule and the k-vector scale-factor update (``delta != 0``) run on the
+device (aa_iterate), the host reads one status record per batch of iterations.  What stays
+on the host is argument validation, RNG-ordered initialisation (FurthestSum's candidate
+list), warnings, timing and verbose tables; the host-driven one-update-at-a-time loop is
+kept as a cross-check (``_DEVICE_LOOP = False``).
 
 Unlike the reference, ``ArchetypalAnalysis`` never forms the n x n kernel
 ``data.dot(data.T)`` (reference :1032), the n x n dissimilarity matrix (:95-100) or

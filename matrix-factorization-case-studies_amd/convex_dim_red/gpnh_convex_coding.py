@@ -4,11 +4,13 @@ Mirrors reference src/convex_dim_red/gpnh_convex_coding.py (class ``GPNHConvexCo
 and the test-visible ``_gpnh_cost``, ``_iterate_gpnh_convex_coding``,
 ``_update_gpnh_dictionary``, ``_update_gpnh_weights``).
 
-Device work per outer iteration (csrc/solver.hip: aa_gpnh_*): Z'X (reduce-over-rows
-GEMM), X W (row-local GEMM), the n per-sample simplex QPs, Z'Z and tr(W'X'Z).  The
-k x k regularised least-squares solve for the dictionary (reference :213-226) stays on
-the host (``numpy.linalg.lstsq`` on a k x k system with a k x p right-hand side), as do
-the GPNH penalty and W'W, which only touch the small p x k dictionary.
+The whole alternating loop runs on the device (csrc/solver.hip: aa_gpnh_iterate): Z'X
+(reduce-over-rows GEMM), the k x k regularised normal equations for the dictionary
+(reference :213-226; Cholesky in LDS), X W (row-local GEMM), W'W, the GPNH penalty, the
+cost, the n per-sample simplex QPs, the monotonicity check and the stopping rule; the host
+reads one status record per batch of iterations.  When the normal equations are not
+positive definite (an unused component) the host loop with ``numpy.linalg.lstsq`` -- the
+reference's solver -- takes over.
 """
 from __future__ import absolute_import, division, print_function
 
