@@ -376,7 +376,10 @@ int aa_distance_column(aa_ctx *ctx, long j, double *d);
  *                         own stopping rule / monotonicity check / iteration cap; its factors of that
  *                         iteration are kept while the others go on
  *   aa_gpnh_slots_fetch   factors, cost record (2 (stop_iter + 1) values) and initial cost of a
- *                         stopped slot; the slot can then be loaded again */
+ *                         stopped slot; the slot can then be loaded again
+ *   aa_slots_end          (shared with the AA slots below) leaves the slot mode: the context must be
+ *                         ended -- or destroyed -- before it is used for single fits again; a begin
+ *                         call of either slot mode resets whatever an earlier, un-ended one left */
 typedef struct {
     int stop, converged, error_stage, stop_iter;
     int not_spd;            /* the slot's normal equations were not positive definite */
@@ -398,7 +401,8 @@ int aa_gpnh_slots_fetch(aa_ctx *ctx, int r, double *Wt, long ld, double *Z, doub
  * iteration of a batch; aa_slots_reload puts the next restart into the freed slot (its first dictionary
  * update is the cold one of a fit, the running slots keep the products they carry); aa_slots_finish
  * (optional, all slots stopped) restores the stopping-iteration factors and rebuilds the products;
- * aa_slots_end returns the context to single fits.  status[r].not_spd carries the slot's SPG warning
+ * aa_slots_end returns the context to single fits (from either slot mode: it also ends a run begun with
+ * aa_gpnh_slots_begin).  status[r].not_spd carries the slot's SPG warning
  * flags (AA_SPG_FLAG_*).  Every restart gets the bits aa_iterate gives it on its own. */
 int aa_slots_begin(aa_ctx *ctx, int R, int k, const aa_iter_params *loop, const aa_spg_params *spg,
                    const aa_qp_params *qp, const aa_spg_params *scale_spg /* loop->delta != 0 */);
@@ -465,6 +469,13 @@ int aa_time_kernel(aa_ctx *ctx, int which, int reps, double *ms_avg);
  * launches recorded since the previous call, clears them, and sets the mode to `enable`. */
 int aa_gemm_timing(aa_ctx *ctx, int enable, double *ms_reduce_rows, int *n_reduce_rows,
                    double *ms_row_local, int *n_row_local);
+/* Names of the kernels the context's most recent reduce-over-rows and row-local passes were
+ * launched with, as "reduce;row_local" (e.g. "k_reduce_rows_f32<1,4>;k_row_local_f32_dma<8>"):
+ * the kernels are picked by shard size and dtype (csrc/kernels_gemm.hip: launch_reduce_rows,
+ * launch_row_local), and a parity test has to know that it exercised the ones a benchmark times
+ * (tests/test_gpu_headline.py).  The reference has no counterpart (NumPy picks its BLAS kernels
+ * silently).  Empty names before the first pass.  Returns AA_ERR_ARG if `len` is too small. */
+int aa_pass_kernels(aa_ctx *ctx, char *buf, int len);
 
 #ifdef __cplusplus
 }

@@ -159,6 +159,7 @@ _SIGNATURES = {
     "aa_time_kernel": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp]),
     "aa_gemm_timing": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_int), _dp,
                                       ctypes.POINTER(ctypes.c_int)]),
+    "aa_pass_kernels": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
@@ -745,6 +746,13 @@ class Context(object):
         _check(self.lib.aa_gemm_timing(self.h, int(bool(enable)), ctypes.byref(a), ctypes.byref(na),
                                        ctypes.byref(b), ctypes.byref(nb)))
         return a.value, na.value, b.value, nb.value
+
+    def pass_kernels(self):
+        """(reduce-over-rows kernel, row-local kernel) of the most recent passes of this context:
+        which kernels the shard size and dtype selected."""
+        buf = ctypes.create_string_buffer(128)
+        _check(self.lib.aa_pass_kernels(self.h, buf, 128))
+        return tuple(buf.value.decode().split(";"))
 
     def time_kernel(self, which, reps):
         ms = ctypes.c_double(0)

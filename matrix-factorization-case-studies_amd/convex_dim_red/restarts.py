@@ -54,9 +54,11 @@ def _print_tables(models, tables, title, rule):
             print('*** Converged at iteration {:d} ***'.format(len(finals)))
 
 
-def _slots_eligible(models):
+def _slots_eligible(models, data):
     """GPNH restarts that can share one set of device arrays: same hyper-parameters, at least four
-    restarts of k components in the 64 component slots of the tall arrays."""
+    restarts of k components in the 64 component slots of the tall arrays.  Mirrors the
+    preconditions of aa_gpnh_slots_begin (csrc/solver.hip): QPs of more than four passes take the
+    AA slots' four-lane / wave-per-sample launch, which exists for fewer than 65 536 samples."""
     m0 = models[0]
     if not all(isinstance(m, GPNHConvexCoding) for m in models) or len(models) < 2:
         return False
@@ -71,8 +73,23 @@ def _slots_eligible(models):
     passes = m0.weights_solver_kwargs.get("max_iterations", 1000)
     memory = m0.weights_solver_kwargs.get("memory", 1)
     return (isinstance(k, int) and 1 <= k <= 16 and not m0.dictionary_solver_kwargs and passes >= 1
-            and (memory <= 8 if passes <= 4 else memory <= 1)
+            and (memory <= 8 if passes <= 4 else (memory <= 1 and data.shape[0] < 65536))
             and _backend.distributed_env() is None)
+
+
+def _gpnh_slot_count(m0, n_samples, n_slots):
+    """Restarts side by side: 64 // k in the 64 component slots -- except for float32 data from
+    32 768 samples on, where a single fit (32 component slots) runs the row-local pass that sums
+    32-column fp32 pieces in float64 (k_row_local_f32_dma) and 64 slots would take the
+    register-staged kernel with plain fp32 chains (csrc/kernels_gemm.hip: row_local_variant): the
+    restarts stay within 32 slots there so that every restart keeps the bits -- and the accumulation
+    accuracy -- it has alone."""
+    k = m0.n_components
+    room = 64
+    if _backend.dtype_code(m0.dtype) == _backend.AA_F32 and n_samples > 32768 - 128:
+        room = 32
+    cap = max(1, room // k)
+    return cap if n_slots is None else max(1, min(int(n_slots), cap))
 
 
 def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
@@ -86,8 +103,8 @@ def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
     import warnings
     m0 = models[0]
     k = m0.n_components
-    n_slots = min((64 // k) if n_slots is None else int(n_slots), 64 // k, len(models))
     n_samples = data.shape[0]
+    n_slots = min(_gpnh_slot_count(m0, n_samples, n_slots), len(models))
     fallback, errors = [], {}
     ctx = _backend.Context(dtype=m0.dtype, device=device)
     try:
@@ -149,6 +166,7 @@ def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
                 owner[r] = None
                 if pending:
                     load(r)
+        ctx.aa_slots_end()
     finally:
         ctx.close()
     if m0.verbose:
@@ -319,7 +337,7 @@ def fit_restarts(make_model, data, n_init, n_jobs=None, devices=None, side_by_si
     slot_fit = None
     if side_by_side and _aa_slots_eligible(models, data):
         slot_fit = _fit_aa_slots          # AA: groups of restarts share every launch (aa_slots_*)
-    elif side_by_side and _slots_eligible(models):
+    elif side_by_side and _slots_eligible(models, data):
         slot_fit = _fit_gpnh_slots        # GPNH: slots refilled as restarts stop (aa_gpnh_slots_*)
     if slot_fit is not None:
         # the restarts are dealt over the devices (restart i on device i mod G), every device runs its

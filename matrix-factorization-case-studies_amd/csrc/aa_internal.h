@@ -165,6 +165,7 @@ struct Ctx {
     DevBuf qpLive;                             // ready[cap] | done[cap] flags of the live hand-over (QpLive)
     long qp_live_cap = 0;
     int qp_live_epoch = 0;
+    char pass_names[2][48] = {{0}, {0}};       // last reduce-over-rows / row-local kernel launched (aa_pass_kernels)
     bool qp_tail_pending = false;              // stragglers run on stream2, results in tmpTall by slot
     // the residual projection of the dictionary SPG (spg.py:250-276: convergence flags only) runs on
     // the side stream beside the weights QP, on its own scratch set (launch_proj_side / join_side)

@@ -1184,6 +1184,8 @@ int launch_stream_probe(Ctx *c, int variant)
 // ---------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------
+#define PASS_NAME(WHICH, ...) snprintf(c->pass_names[WHICH], sizeof(c->pass_names[WHICH]), __VA_ARGS__)
+
 static void gemm_event(Ctx *c, int which)
 {
     if (!c->time_gemm) return;
@@ -1210,10 +1212,13 @@ int launch_reduce_rows(Ctx *c, const double *A_tall, double *out_wide, void *out
         } else {
             RRL(2, 4);
         }
+        PASS_NAME(0, "k_reduce_rows_f32<%d,%d>", c->KP / 32, (c->KP == 32 && g_reduce_rows_unroll == 8) ? 8 : 4);
 #undef RRL
     } else {
         dim3 grid((unsigned)((c->p_pad + 255) / 256), (unsigned)c->nslab);
         double *part = c->partial.as<double>();
+        if (g_f64_mfma) PASS_NAME(0, "k_reduce_rows_f64_mfma<%d>", c->KP == 32 ? 2 : 4);
+        else PASS_NAME(0, "k_reduce_rows_f64<%d>", c->KP);
         if (g_f64_mfma) {
             if (c->KP == 32)
                 hipLaunchKernelGGL(k_reduce_rows_f64_mfma<2>, grid, block, 0, c->stream, c->X.as<double>(),
@@ -1332,6 +1337,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
                            c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W);                     \
     } while (0)
 #define RLD2(RV) do { if (g_row_local_nt) RLD(RV, true); else RLD(RV, false); } while (0)
+        PASS_NAME(1, "k_row_local_f32_dma<%d>", R);
         switch (R) {
             case 8: RLD2(8); break;
             case 9: RLD2(9); break;
@@ -1366,6 +1372,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
 #define RLW(NCTV, A64V)                                                                              \
     hipLaunchKernelGGL((k_row_local_f32_ws<NCTV, A64V>), grid, blk, lds, c->stream, c->X.as<float>(), \
                        c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, g_row_local_stagger)
+        PASS_NAME(1, "k_row_local_f32_ws<%d,%d>", nct, (int)a64);
         if (nct == 1) { if (a64) RLW(1, true); else RLW(1, false); }
         else          { if (a64) RLW(2, true); else RLW(2, false); }
 #undef RLW
@@ -1406,6 +1413,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
                                c->X.as<float>(), c->p_pad, B, (int)c->p_pad, dst, c->n_pad, chunk);    \
     } while (0)
         const int v = row_local_variant(c);
+        PASS_NAME(1, "k_row_local_f32_blk[v%d,acc64=%d,split=%d]", v, g_row_local_acc64 != 0, nsplit);
         if (c->KP == 32) {
             switch (v) {
                 case 3: RLB(1, 64, true); break;
@@ -1430,6 +1438,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
     } else if (c->dtype == AA_F32 && row_local_variant(c) == 1) {
         const float *B = reinterpret_cast<const float *>(B_wideT);
         dim3 grid((unsigned)(c->n_pad / 128));
+        PASS_NAME(1, "k_row_local_f32_lds<%d>", c->KP / 32);
         if (c->KP == 32)
             hipLaunchKernelGGL(k_row_local_f32_lds<1>, grid, block, 0, c->stream, c->X.as<float>(),
                                c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
@@ -1438,6 +1447,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
                                c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
     } else if (c->dtype == AA_F32) {
         const float *B = reinterpret_cast<const float *>(B_wideT);
+        PASS_NAME(1, "k_row_local_f32<%d>", c->KP / 32);
         if (c->KP == 32) {
             constexpr int RT = 2;
             dim3 grid((unsigned)((c->n_pad + 128 * RT - 1) / (128 * RT)));
@@ -1470,6 +1480,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
                 attr_set64[c->device & 63] = true;
             }
             dim3 gw((unsigned)((tiles + W - 1) / W)), bw((unsigned)(64 * W));
+            PASS_NAME(1, "k_row_local_f64_ws<%d>", nt);
             if (nt == 2)
                 hipLaunchKernelGGL(k_row_local_f64_ws<2>, gw, bw, lds, c->stream, c->X.as<double>(), c->p_pad,
                                    B, (int)c->p_pad, out_tall, c->n_pad, W);
@@ -1495,6 +1506,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
                 dst = c->rlPartial.as<double>();
             }
             dim3 g2((unsigned)rblocks, (unsigned)nsplit);
+            PASS_NAME(1, "k_row_local_f64_mfma<%d>[split=%d]", c->KP == 32 ? 2 : 4, nsplit);
             if (c->KP == 32)
                 hipLaunchKernelGGL(k_row_local_f64_mfma<2>, g2, block, 0, c->stream, c->X.as<double>(),
                                    c->p_pad, B, (int)c->p_pad, dst, c->n_pad, chunk);
@@ -1506,7 +1518,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
                 hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
                                    (const double *)dst, elems, nsplit, out_tall);
             }
-        } else if (c->KP == 32)
+        } else if (PASS_NAME(1, "k_row_local_f64<%d>", c->KP), c->KP == 32)
             hipLaunchKernelGGL(k_row_local_f64<32>, grid, block, 0, c->stream, c->X.as<double>(),
                                c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad);
         else

@@ -1788,10 +1788,14 @@ int aa_slots_end(aa_ctx *h)
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
     c->slots_aa = false;
     c->slots_R = 0;
+    c->slots_started = false;
     c->k = 0;                                         // the next aa_set_state sizes the arrays afresh
     c->have_state = false;
+    c->gpnh_valid = false;                            // (the GPNH slot mode ends here too)
     c->grams_valid = false;
+    c->ckz_valid = false;
     c->products_valid = false;
+    c->qp_iters_valid = false;
     return AA_OK;
 }
 
@@ -1817,6 +1821,9 @@ int aa_gpnh_slots_begin(aa_ctx *h, int R, int k, const aa_gpnh_params *gp, const
     AA_REQUIRE(qp->max_iterations <= 4 || (qp->memory <= 1 && k <= 16 && c->n < 65536), AA_ERR_ARG,
                "slots: QPs of more than four passes need memory 1, k <= 16, fewer than 65 536 samples");
     c->k = 0;                                         // force fresh, zeroed factor arrays
+    c->slots_aa = false;                              // (an AA slot run that was never ended)
+    c->slots_started = false;
+    c->products_valid = false;
     AA_CHECK(ensure_problem(c, R * k));
     AA_CHECK(ensure_trace(c));
     for (int i = 0; i < c->k; ++i) c->alpha[i] = 1.0;
@@ -2105,6 +2112,16 @@ int aa_pass_row_local(aa_ctx *h, int k, const double *B, long ldb, double *out)
 }
 
 // ------------------------------------------------------------------ measurement
+int aa_pass_kernels(aa_ctx *h, char *buf, int len)
+{
+    AA_REQUIRE(h && buf, AA_ERR_ARG, "null argument");
+    const Ctx *c = &h->c;
+    const int need = snprintf(nullptr, 0, "%s;%s", c->pass_names[0], c->pass_names[1]) + 1;
+    AA_REQUIRE(len >= need, AA_ERR_ARG, "aa_pass_kernels: buffer of %d bytes, %d needed", len, need);
+    snprintf(buf, (size_t)len, "%s;%s", c->pass_names[0], c->pass_names[1]);
+    return AA_OK;
+}
+
 int aa_gemm_timing(aa_ctx *h, int enable, double *ms_reduce_rows, int *n_reduce_rows,
                    double *ms_row_local, int *n_row_local)
 {

@@ -562,7 +562,7 @@ update_scale_factors_fn = update_scale_factors
 
 def iterate_aa(X, Z, C, alpha, delta=0, update_weights=True, update_dictionary=True,
                update_scale_factors=True, tolerance=1e-6, max_iterations=1000,
-               trace_XXt=None, timings=None, **kwargs):
+               trace_XXt=None, timings=None, cost_log=None, **kwargs):
     """archetypal_analysis.py:534-670: the reference's op sequence -- with
     ``dictionary_solver_kwargs={'max_iterations': 1}`` 11 GEMM passes over X per
     outer iteration (7 inside spg, 2 at :618-619, 2 at :641-642).
@@ -570,7 +570,9 @@ def iterate_aa(X, Z, C, alpha, delta=0, update_weights=True, update_dictionary=T
     ``trace_XXt``: the reference forms np.trace(X.dot(X.T)) (:552, an n x n
     temporary); pass the value (= ||X||_F^2) to avoid that at large n.
     ``timings``: optional dict accumulating seconds per phase
-    ('dictionary', 'gram', 'weights')."""
+    ('dictionary', 'gram', 'weights').
+    ``cost_log``: optional list that receives (stage, cost) after every update
+    (the values the reference's monotonicity checks see, :612,:630,:651)."""
     n, k = Z.shape
     require = kwargs.get("require_monotonic_cost_decrease", True)
     done = _converged(kwargs.get("stopping_criterion", "abs_delta_f"))
@@ -605,6 +607,8 @@ def iterate_aa(X, Z, C, alpha, delta=0, update_weights=True, update_dictionary=T
             alpha = update_scale_factors_fn(alpha, trX, CXXtZ, ZtZ, CXXtCt, delta, **skw)
             da = np.diag(alpha)
             new = cost()
+            if cost_log is not None:
+                cost_log.append(("scale factors", new))
             _cost_increased(old, new, tolerance, "scale factors", require)
         if update_dictionary:
             t1 = time.perf_counter()
@@ -617,6 +621,8 @@ def iterate_aa(X, Z, C, alpha, delta=0, update_weights=True, update_dictionary=T
             CXXtZ = C.dot(XXtZ)
             tick("gram", t1)
             new = cost()
+            if cost_log is not None:
+                cost_log.append(("dictionary", new))
             _cost_increased(old, new, tolerance, "dictionary", require)
         if update_weights:
             t1 = time.perf_counter()
@@ -629,6 +635,8 @@ def iterate_aa(X, Z, C, alpha, delta=0, update_weights=True, update_dictionary=T
             CXXtZ = C.dot(XXtZ)
             tick("gram", t1)
             new = cost()
+            if cost_log is not None:
+                cost_log.append(("weights", new))
             _cost_increased(old, new, tolerance, "weights", require)
         times.append(time.perf_counter() - t0)
         deltas.append(new - old)

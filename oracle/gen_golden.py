@@ -322,8 +322,34 @@ def main():
                                          max_iterations=400, stopping_criterion="rel_delta_f",
                                          random_state=0, weights_solver_kwargs=wkw)
                 m.fit_transform(X)
-                Wn, cn = m.transform(Xn)
                 key = "lam%d_%s" % (int(lam), wtag)
+                # the transform's loop from its own start, stage by stage: the start weights the
+                # estimator's generator gives next (drawn from a copy of its state), the weights
+                # after 1 and 3 weights-only iterations, and the cost changes of the run to the
+                # stopping rule (transform() itself keeps none of these)
+                import copy
+                rs2 = copy.deepcopy(m.random_state)
+                Z0n = gp._initialize_gpnh_convex_coding_weights(Xn, 5, init="random", random_state=rs2)
+                arrays["out_start_" + key] = Z0n
+                for iters in (1, 3):
+                    Zi = gp._iterate_gpnh_convex_coding(
+                        Xn, Z0n.copy(), m.dictionary.copy(), lambda_W=lam, update_dictionary=False,
+                        update_weights=True, tolerance=0, max_iterations=iters,
+                        stopping_criterion="rel_delta_f", weights_solver_kwargs=wkw)[0]
+                    arrays["out_W%d_%s" % (iters, key)] = Zi
+                tr = gp._iterate_gpnh_convex_coding(
+                    Xn, Z0n.copy(), m.dictionary.copy(), lambda_W=lam, update_dictionary=False,
+                    update_weights=True, tolerance=1e-6, max_iterations=400,
+                    stopping_criterion="rel_delta_f", weights_solver_kwargs=wkw)
+                arrays["out_trace_" + key] = np.array([tr[2], tr[3]], dtype=np.float64)   # cost, n_iter
+                arrays["out_deltas_" + key] = np.asarray(tr[5])
+                if tr[3] >= 1:      # the weights one iteration before the stop: how far an iteration still moves them
+                    arrays["out_Wprev_" + key] = gp._iterate_gpnh_convex_coding(
+                        Xn, Z0n.copy(), m.dictionary.copy(), lambda_W=lam, update_dictionary=False,
+                        update_weights=True, tolerance=0, max_iterations=int(tr[3]),
+                        stopping_criterion="rel_delta_f", weights_solver_kwargs=wkw)[0]
+                Wn, cn = m.transform(Xn)
+                assert np.array_equal(Wn, tr[0]) and cn == tr[2]     # the same loop from the same start
                 arrays["out_fit_" + key] = np.array([m.cost, m.n_iter], dtype=np.float64)
                 arrays["out_dictionary_" + key] = np.ascontiguousarray(m.dictionary)   # the transform's input
                 arrays["out_W_" + key] = Wn

@@ -223,25 +223,37 @@ def test_c3_jra55_shape_fixed_iterations(cdr, orc, c3_problem, lam, dtype, rtol)
         # float32 data.  One-pass weight updates amplify a difference ~5-8x per outer iteration on
         # this problem, in ANY arithmetic (the float64 path against the oracle: max|dZ| 6e-13 after
         # one iteration, 6e-10 after eight), and single weights then land on another face of the
-        # simplex.  So the float32 factors after eight iterations are held to the float32 error of
-        # ONE iteration (fp32 rounding of the X W' entries, ~1e-7, seen through one projected step)
-        # times the growth the float64 path itself shows over the same seven iterations, x 20.
-        def run(dt, iters):
-            kk = dict(kw, max_iterations=iters)
-            o = orc.iterate_gpnh(Xd, Zi.copy(), Wi.copy(), **kk)
-            h = gp._iterate_gpnh_convex_coding(Xh if dt == "float32" else Xd, Zi.copy(), Wi.copy(), dtype=dt, **kk)
-            return np.abs(h[0] - o[0]).max(), np.abs(h[1] - o[1]).max()
-        z32_1, w32_1 = run("float32", 1)
-        z64_1, w64_1 = run("float64", 1)
-        z64_8, w64_8 = run("float64", 8)
-        gz, gw = max(z64_8 / z64_1, 1.0), max(w64_8 / w64_1, 1.0)
-        g = max(gz, gw)                                       # the factors feed each other
-        print("C3 float32 lam=%g: one iteration max|dZ| %.2e max|dW| %.2e; float64 growth over 7 more: %.0fx / %.0fx; "
-              "eight iterations max|dZ| %.2e max|dW| %.2e"
-              % (lam, z32_1, w32_1, gz, gw, np.abs(Z - wZ).max(), np.abs(W - wW).max()))
-        assert z32_1 < 1e-3 and w32_1 < 1e-5 * scale          # one iteration: fp32 rounding through one step
-        assert np.abs(Z - wZ).max() <= min(20 * g * z32_1, 1.0)
-        assert np.abs(W - wW).max() <= 20 * g * w32_1
+        # simplex.  The yardstick that CAN fail: the float32 path -- X stored in float32, the two
+        # big contractions on the fp32 matrix cores -- must stay as close to the oracle as the
+        # ORACLE ITSELF stays when its data are perturbed at float32 size (`f32_perturbed`, three
+        # draws), x 20.  After 1 and 3 iterations in the maximum norm of both factors.  After 8 the
+        # maximum norm of the weights says nothing any more -- the oracle's own twins differ by 0.07
+        # there, ONE of 22 280 samples on another face -- so the weights are then held by the
+        # root-mean-square and the 99.9 % quantile of the per-sample differences, the dictionary by
+        # its maximum norm, and the share of samples on another face by the twins' share.
+        def oracle(Xin, iters):
+            return orc.iterate_gpnh(Xin, Zi.copy(), Wi.copy(), **dict(kw, max_iterations=iters))
+
+        def measures(Za, Wa, o):
+            per_sample = np.abs(Za - o[0]).max(axis=1)
+            return dict(zmax=per_sample.max(), zrms=np.sqrt(np.mean((Za - o[0]) ** 2)),
+                        zq999=np.quantile(per_sample, 0.999), wmax=np.abs(Wa - o[1]).max(),
+                        face=float(np.mean(np.any((Za > 1e-15) != (o[0] > 1e-15), axis=1))))
+
+        for iters in (1, 3, 8):
+            o = oracle(X, iters)                              # the exact (float64) data
+            twins = [oracle(f32_perturbed(X, s), iters) for s in (6, 7, 8)]
+            tm = [measures(t[0], t[1], o) for t in twins]
+            yard = {key: max(t[key] for t in tm) for key in tm[0]}
+            h = gp._iterate_gpnh_convex_coding(Xh, Zi.copy(), Wi.copy(), dtype=dtype, **dict(kw, max_iterations=iters))
+            got = measures(h[0], h[1], o)
+            print("C3 float32 lam=%g, %d iteration(s): " % (lam, iters)
+                  + ", ".join("%s %.2e (oracle's float32-sized twins %.2e)" % (key, got[key], yard[key])
+                              for key in sorted(got)))
+            held = ("zmax", "wmax") if iters < 8 else ("zrms", "zq999", "wmax")
+            for key in held:
+                assert got[key] <= 20 * yard[key], (iters, key, got[key], yard[key])
+            assert got["face"] <= 20 * yard["face"] + 2.0 / X.shape[0], (iters, got["face"], yard["face"])
 
 
 @pytest.mark.parametrize("lam", [0.0, 1.0])
