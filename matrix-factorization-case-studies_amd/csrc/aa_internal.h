@@ -316,7 +316,10 @@ int launch_row_broadcast(Ctx *c, long j_local, bool own);
 int launch_proj_side(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode,
                      const aa_spg_params *sp, int stage_after);   // launch_proj on the side stream / scratch set
 int join_side(Ctx *c);             // the main stream waits for a pending side-stream projection
-extern int g_proj_res_side;
+bool side_available(const Ctx *c);  // side stream + second scratch set usable (single rank, fused stages)
+int side_begin(Ctx *c);            // launch_* calls go to the side stream (own scratch set) until side_end
+int side_end(Ctx *c);
+extern int g_proj_res_side, g_grad_side;
 int proj_poll_multirank(Ctx *c);   // multi-rank: read the deferred overflow flag / list lengths (host sync point)   // multi-rank: row j -> wideScratch on every rank
 int launch_residual_cost(Ctx *c, const double *Ztall, const double *Wwide, const double *alpha_dev,
                          double *out_host);
@@ -365,6 +368,7 @@ extern int g_qp_refill_min;       // kernels_qp.hip
 extern int g_qp_waves;            // kernels_qp.hip
 extern int g_qp_sort;             // kernels_qp.hip
 extern int g_qp_profile;          // kernels_qp.hip
+extern int g_qp_wave_mem1;
 extern int g_qp_overlap_tail, g_qp_tail_cap, g_qp_live, g_qp_live_blocks, g_qp_live_occ;     // kernels_qp.hip
 
 // ------------------------------------------------------------------ comm.hip

@@ -930,7 +930,10 @@ __device__ __forceinline__ double qw_matvec_bcast(const double (&Acol)[16], doub
     return pa + pb;
 }
 
-template <int KQ>
+// MEM1: the non-monotone memory is 1 (spg.py:310 default, and always on the continuation path): the
+// f_mem array -- 32 wave-uniform doubles, i.e. 64 SGPRs that hipcc spills to VGPR lanes around every
+// reduction -- does not exist.
+template <int KQ, bool MEM1 = false>
 __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ][KQ]*/,
                                                  const double *__restrict__ B, long stride_j,
                                                  long stride_t, const double *__restrict__ bscale,
@@ -980,7 +983,8 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
         if constexpr (HALF) return qw_matvec_bcast(Arow, v, lane);
         else return qw_matvec<KQ>(Arow, v);
     };
-    const int mem = p.memory < 1 ? 1 : (p.memory > QW_MAXMEM ? QW_MAXMEM : p.memory);
+    constexpr int NMEM = MEM1 ? 1 : QW_MAXMEM;
+    const int mem = MEM1 ? 1 : (p.memory < 1 ? 1 : (p.memory > QW_MAXMEM ? QW_MAXMEM : p.memory));
     // n_fresh >= 0: process rows [0, n_fresh) from scratch; otherwise the overflow list
     // fresh_list: the first hdr->n_long entries of the sorted sample list, from scratch
     const bool fresh = n_fresh >= 0 || fresh_list != nullptr;
@@ -1034,11 +1038,11 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
 
         double x = live ? (shared ? qp_load_agent(&Z[row * ldz + comp]) : Z[row * ldz + comp]) : 0.0;
         const double b = live ? -B[comp * stride_j + row * stride_t] * (bscale ? bscale[comp] : 1.0) : 0.0;
-        double f, alpha = 1.0, fmem[QW_MAXMEM];
+        double f, alpha = 1.0, fmem[NMEM];
         int n_iter, n_feval;
         unsigned long long support = 0ull, support_r = 0ull;   // latest direction / residual supports
 #pragma unroll
-        for (int i = 0; i < QW_MAXMEM; ++i) fmem[i] = NAN;
+        for (int i = 0; i < NMEM; ++i) fmem[i] = NAN;
         if (fresh) {
             const double t0 = qw_threshold<HALF>(live ? x : -INFINITY, comp, support);
             x = live ? fmax(x - t0, 0.0) : 0.0;
@@ -1087,14 +1091,16 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
             const double dAd = qw_sum<HALF>(d * Ad);
 
             double f_max = f;
-            if (mem > 1) {                         // memory == 1 (the default): f_max = f
+            if constexpr (!MEM1) {
+                if (mem > 1) {                     // memory == 1 (the default): f_max = f
 #pragma unroll
-                for (int i = QW_MAXMEM - 1; i > 0; --i)
-                    if (i < mem) fmem[i] = fmem[i - 1];
-                fmem[0] = f;
+                    for (int i = NMEM - 1; i > 0; --i)
+                        if (i < mem) fmem[i] = fmem[i - 1];
+                    fmem[0] = f;
 #pragma unroll
-                for (int i = 1; i < QW_MAXMEM; ++i)
-                    if (i < mem && fmem[i] > f_max) f_max = fmem[i];
+                    for (int i = 1; i < NMEM; ++i)
+                        if (i < mem && fmem[i] > f_max) f_max = fmem[i];
+                }
             }
 
             double lam = 1.0;
@@ -1168,16 +1174,22 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
                 QpLive lv = QpLive{0, 0, 0u, 0u, nullptr, nullptr}, int rst_b = 0, long rst_n = 0
 #define QW_PASS A, B, stride_j, stride_t, bscale, Z, ldz, n_fresh, k, p, iters, hdr, ovf_rows, ovf, zslot,           \
                 fresh_list, count_ptr, park_at, n_parked, park_rows, park, lv, rst_b, rst_n
-template <int KQ>
-__global__ __launch_bounds__(256) void k_qp_wave(QW_ARGS) { qp_wave_body<KQ>(QW_PASS); }
+template <int KQ, bool MEM1 = false>
+__global__ __launch_bounds__(256) void k_qp_wave(QW_ARGS) { qp_wave_body<KQ, MEM1>(QW_PASS); }
 // the live consumers (QpLive mode 1): blocks of 16 waves that are launched with a whole CU's LDS
 // as (unused) dynamic shared memory while k_qp_quad asks for 1/12 of it per wave -- LDS becomes the
 // resource that keeps the two kernels on DIFFERENT CUs: the latency-bound chains of the consumers
 // (four per SIMD) do not share issue slots with the MFMA-heavy waves of k_qp_quad, which stretched
 // a consumer's pass from 0.9 to ~1.8 us when the two kernels were mixed on every SIMD
-__global__ __launch_bounds__(1024) void k_qp_wave_live(QW_ARGS) { qp_wave_body<32>(QW_PASS); }
+__global__ __launch_bounds__(1024) void k_qp_wave_live(QW_ARGS) { qp_wave_body<32, true>(QW_PASS); }
 #undef QW_ARGS
 #undef QW_PASS
+// continuation launches (memory == 1 by construction of the callers)
+#define QW32_LAUNCH(...)                                                              \
+    do {                                                                              \
+        if (g_qp_wave_mem1) hipLaunchKernelGGL((k_qp_wave<32, true>), __VA_ARGS__);   \
+        else hipLaunchKernelGGL((k_qp_wave<32, false>), __VA_ARGS__);                 \
+    } while (0)
 
 // max_iterations <= 0: the reference's loop body never runs and x = P(x0) is returned.
 template <int KQ>
@@ -2120,6 +2132,7 @@ int g_qp_live_occ = 3;         // register budget of k_qp_quad beside the consum
 int g_qp_live_blocks = 48;     // CUs given to the consumers (one block of 16 waves each)
 #define QP_LIVE_LDS 163840     // a CU's LDS
 int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)
+int g_qp_wave_mem1 = 1;        // continuation launches of the wave-per-sample kernel: 1 = the memory-1 instantiation (no f_mem array: 311 fewer SGPR spills), 0 = the generic one (A/B)
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
 int g_qp_tail_cap = 96;        // with qp_overlap_tail: only samples beyond this many passes go to the side stream (0: all parked ones)
 int g_qp_profile = 0;          // cycle accounting of k_qp (printed when stats are requested)
@@ -2385,7 +2398,7 @@ int launch_qp_slots_aa(Ctx *c, const aa_qp_params *p)
     if (wblocks < 64) wblocks = 64;
     if (wblocks > g_qp_wave_blocks) wblocks = g_qp_wave_blocks;
     if (cap < p->max_iterations)
-        hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)wblocks, (unsigned)R), dim3(256), 0, c->stream,
+        QW32_LAUNCH(dim3((unsigned)wblocks, (unsigned)R), dim3(256), 0, c->stream,
                            (const double *)A2d, Bt, (long)1, (long)c->KP, (const double *)bsd, Zt, c->KP, (long)-1, k,
                            *p, (int *)nullptr, hdr, (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr,
                            (const int *)nullptr, (const unsigned int *)nullptr, 1 << 30, (unsigned int *)nullptr,
@@ -2498,7 +2511,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         if (hybrid) {
             AA_CHECK_HIP(hipEventRecord(c->evFork, c->stream));
             AA_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->evFork, 0));
-            hipLaunchKernelGGL(k_qp_wave<32>, dim3(512), dim3(256), 0, c->stream2, A2d, Btall, stride_j,
+            QW32_LAUNCH(dim3(512), dim3(256), 0, c->stream2, A2d, Btall, stride_j,
                                stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr, perm);
             AA_CHECK_HIP(hipEventRecord(c->evJoin, c->stream2));
@@ -2515,7 +2528,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                                g_qp_row_hot, g_qp_profile, g_qp_row_chunk, cap, ovf_rows, ovf);
         if (hybrid) AA_CHECK_HIP(hipStreamWaitEvent(c->stream, c->evJoin, 0));
         if (cap < p->max_iterations)
-            hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, c->stream, A2d, Btall, stride_j,
+            QW32_LAUNCH(dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, c->stream, A2d, Btall, stride_j,
                                stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr);
     } else if (quad_mode) {
@@ -2594,7 +2607,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
             // clean-up: whatever the consumers did not take (they give up after a bounded wait)
             AA_CHECK_HIP(hipStreamWaitEvent(c->stream, c->evJoin, 0));
             lv.mode = 2;
-            hipLaunchKernelGGL(k_qp_wave<32>, dim3(64), dim3(256), 0, c->stream, A2d, Btall,
+            QW32_LAUNCH(dim3(64), dim3(256), 0, c->stream, A2d, Btall,
                                stride_j, stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr,
                                (const int *)nullptr, (const unsigned int *)nullptr, 1 << 30,
@@ -2611,13 +2624,13 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
             if (defer && tail_cap > cap && tail_cap < p->max_iterations) {
                 // two stages: everything up to tail_cap passes here, at full speed on the whole chip;
                 // the few samples beyond it on the side stream beside the caller's Z'X pass
-                hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, c->stream, A2d, Btall,
+                QW32_LAUNCH(dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, c->stream, A2d, Btall,
                                    stride_j, stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                    (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr,
                                    (const int *)nullptr, (const unsigned int *)nullptr, tail_cap, &hdr->pad, ovf2_rows, ovf2);
                 AA_CHECK_HIP(hipEventRecord(c->evFork, c->stream));
                 AA_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->evFork, 0));
-                hipLaunchKernelGGL(k_qp_wave<32>, dim3(64), dim3(256), 0, c->stream2, A2d, Btall,
+                QW32_LAUNCH(dim3(64), dim3(256), 0, c->stream2, A2d, Btall,
                                    stride_j, stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                    (const int *)ovf2_rows, (const QpCarry *)ovf2, c->tmpTall.as<double>(),
                                    (const int *)nullptr, (const unsigned int *)&hdr->pad);
@@ -2634,7 +2647,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                     s2 = c->stream2;
                     zslot = c->tmpTall.as<double>();
                 }
-                hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, s2, A2d, Btall, stride_j,
+                QW32_LAUNCH(dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, s2, A2d, Btall, stride_j,
                                    stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                    (const int *)ovf_rows, (const QpCarry *)ovf, zslot);
                 if (defer) {
@@ -2648,14 +2661,13 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     } else if (wave_only) {
         long blocks = (n + 3) / 4;
         if (blocks > 2048) blocks = 2048;
-        if (KW == 64)
-            hipLaunchKernelGGL(k_qp_wave<64>, dim3((unsigned)blocks), dim3(256), 0, c->stream, A2d, Btall,
-                               stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr,
-                               (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr);
-        else
-            hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)blocks), dim3(256), 0, c->stream, A2d, Btall,
-                               stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr,
-                               (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr);
+#define QWF(KWV, M1V)                                                                            \
+    hipLaunchKernelGGL((k_qp_wave<KWV, M1V>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A2d, Btall, \
+                       stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, iters_dev, hdr,               \
+                       (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr)
+        if (KW == 64) { if (p->memory <= 1) QWF(64, true); else QWF(64, false); }
+        else          { if (p->memory <= 1) QWF(32, true); else QWF(32, false); }
+#undef QWF
     } else {
         // phase 1: every sample gets up to pass_cap passes in a lane
         int cap = qp_pass_cap();
@@ -2704,7 +2716,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                 s2 = c->stream2;
                 zslot = c->tmpTall.as<double>();
             }
-            hipLaunchKernelGGL(k_qp_wave<32>, dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, s2, A2d, Btall, stride_j,
+            QW32_LAUNCH(dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, s2, A2d, Btall, stride_j,
                                stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                (const int *)ovf_rows, (const QpCarry *)ovf, zslot);
             if (defer) {

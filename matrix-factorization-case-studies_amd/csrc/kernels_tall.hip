@@ -1930,6 +1930,7 @@ int g_proj_check_always = 1; // multi-rank: 1 (default) = every list projection 
                              // ends the fit with an error instead of being handled
 int g_pq_blocks = 128;          // most blocks of k_gram_wide_pq (their partial Grams are summed by ONE block; 64 -> 128:
                                 // C2, p = 25 000, 0.553 -> 0.537 ms per iteration; 256: 0.548)
+int g_grad_side = 1;            // one SPG iteration per dictionary update: g_new, x += lambda d and the BB stage on the side stream too
 int g_proj_res_side = 1;        // the SPG's residual projection (flags only) on the side stream, beside the weights QP
 int g_proj_small = 1;           // short columns: threshold search of a projection in one kernel (k_proj_small)
 int g_fuse_finalize = 1;    // 1: second reduction stages run in the last block of their producer (single rank)
@@ -2086,35 +2087,56 @@ int join_side(Ctx *c)
     return AA_OK;
 }
 
-int launch_proj_side(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode,
-                     const aa_spg_params *sp, int stage_after)
+// The side stream with its own scratch set (projection state, partials, reduction outputs, candidate
+// lists, the w buffer): between side_begin and side_end every launch_* call of this file goes to
+// stream2.  side_begin forks from the main stream (everything enqueued so far is visible), side_end
+// records the event join_side waits for.
+static void side_swap(Ctx *c)
 {
-    const bool ok = g_proj_res_side && c->stream2 && c->proj2.p && c->evFork2 && c->world <= 1 && !c->force_comm &&
-                    g_proj_mode == 0 && g_fuse_finalize;
-    if (!ok) return launch_proj(c, x, g, a_const, a_slot, mode, sp, stage_after);
+    std::swap(c->stream, c->stream2);
+    std::swap(c->tmpTall, c->tmpTall2);
+    std::swap(c->redPartial, c->redPartial2);
+    std::swap(c->redOut, c->redOut2);
+    std::swap(c->proj, c->proj2);
+    std::swap(c->projList, c->projList2);
+    std::swap(c->projSegCnt, c->projSegCnt2);
+    for (int m = 0; m < 4; ++m) {
+        std::swap(c->projWarm[m], c->projWarm2[m]);
+        std::swap(c->projPassHint[m], c->projPassHint2[m]);
+    }
+}
+
+bool side_available(const Ctx *c)
+{
+    return g_proj_res_side && c->stream2 && c->proj2.p && c->evFork2 && c->world <= 1 && !c->force_comm &&
+           g_proj_mode == 0 && g_fuse_finalize;
+}
+
+int side_begin(Ctx *c)
+{
     AA_CHECK(join_side(c));
     AA_CHECK_HIP(hipEventRecord(c->evFork2, c->stream));
     AA_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->evFork2, 0));
-    auto swap_all = [&]() {
-        std::swap(c->stream, c->stream2);
-        std::swap(c->tmpTall, c->tmpTall2);
-        std::swap(c->redPartial, c->redPartial2);
-        std::swap(c->redOut, c->redOut2);
-        std::swap(c->proj, c->proj2);
-        std::swap(c->projList, c->projList2);
-        std::swap(c->projSegCnt, c->projSegCnt2);
-        for (int m = 0; m < 4; ++m) {
-            std::swap(c->projWarm[m], c->projWarm2[m]);
-            std::swap(c->projPassHint[m], c->projPassHint2[m]);
-        }
-    };
-    swap_all();
-    const int rc = launch_proj(c, x, g, a_const, a_slot, mode, sp, stage_after);
-    swap_all();
-    AA_CHECK(rc);
+    side_swap(c);
+    return AA_OK;
+}
+
+int side_end(Ctx *c)
+{
+    side_swap(c);
     AA_CHECK_HIP(hipEventRecord(c->evJoin2, c->stream2));
     c->side_pending = true;
     return AA_OK;
+}
+
+int launch_proj_side(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode,
+                     const aa_spg_params *sp, int stage_after)
+{
+    if (!side_available(c)) return launch_proj(c, x, g, a_const, a_slot, mode, sp, stage_after);
+    AA_CHECK(side_begin(c));
+    const int rc = launch_proj(c, x, g, a_const, a_slot, mode, sp, stage_after);
+    AA_CHECK(side_end(c));
+    return rc;
 }
 
 // xupd (nullable, needs d_for_dot): x += lambda d in the same pass.  stage_after >= 0 (with

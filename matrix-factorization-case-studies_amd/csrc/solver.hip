@@ -234,6 +234,7 @@ static int refresh_after_weights(Ctx *c)
         AA_CHECK(launch_reduce_rows_finish(c, c->ZtX.as<double>(), operandT(c, c->ZtX, c->Qw),
                                            tail ? QP_FIX_SLABS : 0));
         AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
+        AA_CHECK(join_side(c));                  // the side stream's gradient kernel reads the old H and updates C
         AA_CHECK(launch_row_local(c, operandT(c, c->ZtX, c->Qw), c->H.as<double>()));
     } else {
         if (c->qp_tail_pending) AA_CHECK(launch_qp_tail_fixup(c, c->Zt.as<double>()));   // not used
@@ -362,6 +363,7 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
 
     std::vector<double> sc(SC_COUNT, 0.0);
     int n_iter = -1, flags = 0;
+    bool grad_on_side = false;
     for (int it = 0; it < sp->max_iterations; ++it) {
         n_iter = it;
         if (it == 0 && sp->alpha0 < 0.0) {                                      // spg.py:178-189
@@ -394,6 +396,15 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
             // the BB stage (spg.py:232-244) in the last block of that kernel
             AA_CHECK(launch_wide_axpy_lambda(c, c->P.as<double>(), c->Q.as<double>(), operandT(c, c->P, c->Pw)));
             AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gn.as<double>()));
+            // With one SPG iteration per update nobody on the main stream waits for g_new, the step
+            // x += lambda d, the BB stage or the residual projection before the update of the
+            // weights has run (the QP reads C XX' and the Gram of the accepted point only): the whole
+            // tail of the SPG iteration goes to the side stream and runs beside the QP (round 4:
+            // 36 + 14 us of gradient kernel and finalize step off the critical path).  Joined in
+            // refresh_after_weights before H = X (X'Z)' is overwritten (the gradient reads the old
+            // H) and before C K Z is formed from the updated C.
+            grad_on_side = g_grad_side && sp->max_iterations == 1 && !st && side_available(c);
+            if (grad_on_side) AA_CHECK(side_begin(c));
             AA_CHECK(launch_grad(c, c->Gn.as<double>(), c->H.as<double>(), c->gn.as<double>(), gscale,
                                  c->Dt.as<double>(), SC_DGN, x, sp, ST_BB));
         } else {
@@ -403,7 +414,11 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
                                  c->Dt.as<double>(), SC_DGN, nullptr, sp, ST_BB));
         }
         // spg.py:250-276; with one SPG iteration per update nobody waits for the flags: side stream
-        if (sp->max_iterations == 1 && !st && data)
+        if (grad_on_side) {
+            const int rc = launch_proj(c, x, c->gn.as<double>(), 1.0, -1, PROJ_RES, sp, ST_CONV);
+            AA_CHECK(side_end(c));
+            AA_CHECK(rc);
+        } else if (sp->max_iterations == 1 && !st && data)
             AA_CHECK(launch_proj_side(c, x, c->gn.as<double>(), 1.0, -1, PROJ_RES, sp, ST_CONV));
         else
             AA_CHECK(launch_proj(c, x, c->gn.as<double>(), 1.0, -1, PROJ_RES, sp, ST_CONV));
@@ -520,6 +535,10 @@ int aa_set_option(const char *name, int value)
         g_proj_check_always = value != 0;
     } else if (!strcmp(name, "fuse_finalize")) {
         g_fuse_finalize = value != 0;
+    } else if (!strcmp(name, "grad_side")) {
+        g_grad_side = value != 0;
+    } else if (!strcmp(name, "qp_wave_mem1")) {
+        g_qp_wave_mem1 = value != 0;
     } else if (!strcmp(name, "qp_overlap_tail")) {
         g_qp_overlap_tail = value != 0;
     } else if (!strcmp(name, "qp_tail_cap")) {
@@ -1154,6 +1173,7 @@ int aa_iterate(aa_ctx *h, const aa_iter_params *ip, const aa_spg_params *spg, co
                 AA_CHECK(launch_aa_cost(c, cd, slot, &jd));
                 AA_CHECK(launch_iter_judge(c, done + b, cost0, cd, st, ip, true));
             } else {
+                AA_CHECK(join_side(c));                // the snapshot reads the dictionary the side stream steps
                 AA_CHECK(launch_cost_carry(c, cd, slot, cost0));
                 AA_CHECK(launch_iter_judge(c, done + b, cost0, cd, st, ip));
             }

@@ -7,9 +7,7 @@ never does, and fails loudly when its HIP library is missing.
 
 Parity status: PINNED -- ``tests/test_oracle_golden.py`` checks every function
 here against outputs of the reference itself (``tests/golden/*.npz``, generated
-by ``oracle/gen_golden.py`` from ``/root/reference/src/convex_dim_red``) and,
-when ``/root/reference`` is present, ``tests/test_oracle_vs_reference.py`` checks
-it live against the imported reference.
+by ``oracle/gen_golden.py`` from ``/root/reference/src/convex_dim_red``).
 
 A float64 NumPy restatement of the reference's exact operation sequence
 (citations relative to ``/root/reference/src/convex_dim_red``).  The two serial
@@ -55,6 +53,64 @@ class _CParams(ctypes.Structure):
                 ("alpha_min", ctypes.c_double), ("alpha_max", ctypes.c_double),
                 ("epsilon_one", ctypes.c_double), ("epsilon_two", ctypes.c_double),
                 ("max_iterations", ctypes.c_int), ("max_feval", ctypes.c_int)]
+
+
+# --------------------------------------------------------------------------
+# yardstick mode for the float32 legs of the GPU tests: what rounding the non-data operand
+# of every big contraction against X to float32, and accumulating the reduce-over-rows pass in
+# float32 (_rr), does to an otherwise exact (float64) run.
+# The HIP path's float32 mode feeds its four passes over X with float32 operands (the dictionary /
+# weights / search direction as MFMA A-operands of the reduce-over-rows pass, C X and X'Z as
+# operands of the row-local pass); an archetype row C X is an average over thousands of samples, so
+# rounding IT moves it far more than float32-sized noise on the samples does.  Off (None) the
+# functions below are the reference's op sequence, bit for bit.
+# --------------------------------------------------------------------------
+_OPERAND_DTYPE = None
+
+
+class operand_rounding(object):
+    """``with operand_rounding(np.float32): ...`` -- see above.  Test yardstick only."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _OPERAND_DTYPE
+        self.saved, _OPERAND_DTYPE = _OPERAND_DTYPE, self.dtype
+        _rr.calls = 0                              # the noise of a run is reproducible
+        return self
+
+    def __exit__(self, *exc):
+        global _OPERAND_DTYPE
+        _OPERAND_DTYPE = self.saved
+        return False
+
+
+def _op(a):
+    if _OPERAND_DTYPE is None:
+        return a
+    return np.asarray(a).astype(_OPERAND_DTYPE).astype(np.float64)
+
+
+def _rr(A, X):
+    """A . X for a k x n matrix A against the data (the reduce-over-rows pass).  Yardstick mode: A is
+    rounded to the operand dtype and the result carries the error of a float32 accumulation chain,
+    modelled as Gaussian noise of 1e-7 |A| . |X| per entry -- the middle of the 5e-8 ... 1.9e-7 the
+    float32 pass kernel measures against float64 NumPy (tests/test_gpu_longrun.py::
+    test_pass_kernels_against_numpy pins it below 2e-7).  With c >= 0 and data of mixed signs
+    |A| . |X| is several times |A . X|, so this is the largest float32 effect on C X."""
+    if _OPERAND_DTYPE is None:
+        return A.dot(X)
+    Ar = _op(A)
+    out = Ar.dot(X)
+    if np.dtype(_OPERAND_DTYPE) == np.float32:
+        _rr.calls += 1
+        noise = np.random.RandomState(_rr.calls).standard_normal(out.shape)
+        out = out + 1e-7 * np.abs(Ar).dot(np.abs(X)) * noise
+    return out
+
+
+_rr.calls = 0
 
 
 _clib = None
@@ -443,13 +499,13 @@ def update_aa_dictionary(X, C, alpha, trace_XXt, XXtZ, ZtZ, project=None, **kw):
     DZtZD = da.dot(ZtZ.dot(da))
 
     def f(x):
-        CX = x.dot(X)
+        CX = _rr(x, X)
         return 0.5 * (trace_XXt - 2 * np.trace(x.dot(XXtZD))
                       + np.trace(DZtZD.dot(CX.dot(CX.T)))) / x.shape[0]
 
     def df(x):
-        CX = x.dot(X)
-        return (DZtZD.dot(CX.dot(X.T)) - XXtZD.T) / x.shape[1]
+        CX = _rr(x, X)
+        return (DZtZD.dot(_op(CX).dot(X.T)) - XXtZD.T) / x.shape[1]
 
     return spg(f, df, C, project=project or simplex_project_rows, **kw)
 
@@ -586,11 +642,11 @@ def iterate_aa(X, Z, C, alpha, delta=0, update_weights=True, update_dictionary=T
 
     da = np.diag(alpha)
     ZtZ = Z.T.dot(Z)
-    CX = C.dot(X)
-    CXXt = CX.dot(X.T)
+    CX = _rr(C, X)
+    CXXt = _op(CX).dot(X.T)
     CXXtCt = CX.dot(CX.T)
-    XtZ = X.T.dot(Z)
-    XXtZ = X.dot(XtZ)
+    XtZ = X.T.dot(Z) if _OPERAND_DTYPE is None else _rr(Z.T, X).T
+    XXtZ = X.dot(_op(XtZ))
     CXXtZ = C.dot(XXtZ)
     trX = np.trace(X.dot(X.T)) if trace_XXt is None else trace_XXt
 
@@ -615,8 +671,8 @@ def iterate_aa(X, Z, C, alpha, delta=0, update_weights=True, update_dictionary=T
             C = update_aa_dictionary(X, C, alpha, trX, XXtZ, ZtZ, **dkw)[0]
             tick("dictionary", t1)
             t1 = time.perf_counter()
-            CX = C.dot(X)
-            CXXt = CX.dot(X.T)
+            CX = _rr(C, X)
+            CXXt = _op(CX).dot(X.T)
             CXXtCt = CX.dot(CX.T)
             CXXtZ = C.dot(XXtZ)
             tick("gram", t1)
@@ -630,8 +686,8 @@ def iterate_aa(X, Z, C, alpha, delta=0, update_weights=True, update_dictionary=T
             tick("weights", t1)
             t1 = time.perf_counter()
             ZtZ = Z.T.dot(Z)
-            XtZ = X.T.dot(Z)
-            XXtZ = X.dot(XtZ)
+            XtZ = X.T.dot(Z) if _OPERAND_DTYPE is None else _rr(Z.T, X).T
+            XXtZ = X.dot(_op(XtZ))
             CXXtZ = C.dot(XXtZ)
             tick("gram", t1)
             new = cost()
@@ -769,13 +825,13 @@ def update_gpnh_dictionary(X, Z, ZtZ, GW, lambda_W=0):
     """gpnh_convex_coding.py:213-226."""
     n = X.shape[0]
     lhs = ZtZ / n + lambda_W * GW
-    rhs = Z.T.dot(X) / n
+    rhs = _rr(Z.T, X) / n
     return np.linalg.lstsq(lhs, rhs, rcond=None)[0].T
 
 
 def update_gpnh_weights(X, Z, W, return_iters=False, **kw):
     """gpnh_convex_coding.py:254-279."""
-    return qp_batch(W.T.dot(W), X.dot(W), Z, "nk", return_iters=return_iters, **kw)
+    return qp_batch(W.T.dot(W), X.dot(_op(W)), Z, "nk", return_iters=return_iters, **kw)
 
 
 def iterate_gpnh(X, Z, W, lambda_W=0, update_weights=True, update_dictionary=True,

@@ -20,6 +20,8 @@ import warnings
 import numpy as np
 import pytest
 
+from conftest import f32_perturbed, oracle_twins, ulp_perturbed
+
 pytestmark = pytest.mark.gpu
 
 
@@ -40,30 +42,6 @@ def orc():
 def _assert_simplex(M, atol=1e-12):
     assert np.all(M >= 0)
     assert np.allclose(M.sum(axis=1), 1, rtol=0, atol=atol)
-
-
-def ulp_perturbed(X, seed=5):
-    """X with every entry moved by about one unit in the last place.
-
-    The alternating solvers are not contractions: the BB step lengths of the SPG solvers, the
-    max-norm first step (spg.py:178-189, :326-336), QPs that end at the function-evaluation
-    cap and the support changes of the projections amplify rounding differences from one outer
-    iteration to the next (measured on the C3 stand-in: a 1-ulp perturbation of X moves the
-    ORACLE's own cost by 6e-7 relative and its dictionary by 1e-3 after 50 outer iterations;
-    on the C2 stand-in by 4e-6 after 5).  Wherever a run is long enough for that to matter, the
-    tolerance of the HIP-vs-oracle comparison is therefore tied to the oracle's own sensitivity:
-    ``tol = max(floor, 20 x |oracle(X) - oracle(ulp_perturbed(X))|)`` -- the HIP path has to
-    agree with the oracle as well as the oracle agrees with itself when its input moves by one
-    ulp; short runs keep the plain rounding-level tolerances."""
-    return X * (1.0 + 2e-16 * np.random.RandomState(seed).standard_normal(X.shape))
-
-
-def f32_perturbed(X, seed=6):
-    """X with every entry moved by about one float32 rounding (6e-8 relative): what storing the
-    data in float32 and running the two big contractions on the fp32 matrix cores does to the
-    inputs of an otherwise exact run.  The float32 legs are held to 20 x the oracle's own
-    response to this perturbation -- the same rule as `ulp_perturbed` for the float64 legs."""
-    return X * (1.0 + 6e-8 * np.random.RandomState(seed).standard_normal(X.shape))
 
 
 # ------------------------------------------------------------------ C2: HadISST-shaped AA
@@ -225,8 +203,9 @@ def test_c3_jra55_shape_fixed_iterations(cdr, orc, c3_problem, lam, dtype, rtol)
         # one iteration, 6e-10 after eight), and single weights then land on another face of the
         # simplex.  The yardstick that CAN fail: the float32 path -- X stored in float32, the two
         # big contractions on the fp32 matrix cores -- must stay as close to the oracle as the
-        # ORACLE ITSELF stays when its data are perturbed at float32 size (`f32_perturbed`, three
-        # draws), x 20.  After 1 and 3 iterations in the maximum norm of both factors.  After 8 the
+        # ORACLE ITSELF stays under float32-sized perturbations (`conftest.oracle_twins`: the data
+        # moved by 6e-8 relative, three draws, and the operands of the contractions rounded to
+        # float32 as the matrix cores get them), x 20.  After 1 and 3 iterations in the maximum norm of both factors.  After 8 the
         # maximum norm of the weights says nothing any more -- the oracle's own twins differ by 0.07
         # there, ONE of 22 280 samples on another face -- so the weights are then held by the
         # root-mean-square and the 99.9 % quantile of the per-sample differences, the dictionary by
@@ -240,20 +219,32 @@ def test_c3_jra55_shape_fixed_iterations(cdr, orc, c3_problem, lam, dtype, rtol)
                         zq999=np.quantile(per_sample, 0.999), wmax=np.abs(Wa - o[1]).max(),
                         face=float(np.mean(np.any((Za > 1e-15) != (o[0] > 1e-15), axis=1))))
 
+        # The dictionary has one more source of error that no perturbation of the inputs models: the
+        # fp32 accumulation chains of the reduce-over-rows pass (Z'X), pinned at <= 2e-7 of
+        # sum |z||x| by test_gpu_longrun.py::test_pass_kernels_against_numpy.  Pushed through the k x k
+        # solve of the first update (gpnh_convex_coding.py:213-226) that is a rigorous bound for one
+        # iteration; later iterations get it amplified as the oracle's own twins are amplified.
+        from oracle.aa_oracle import gpnh_gw
+        n, p = X.shape
+        lhs_inv = np.abs(np.linalg.inv(Zi.T.dot(Zi) / n + lam * gpnh_gw(p, k)))
+        w_chain = float((lhs_inv.dot(2e-7 * np.abs(Zi).T.dot(np.abs(X)) / n)).max())
+        first = None
         for iters in (1, 3, 8):
             o = oracle(X, iters)                              # the exact (float64) data
-            twins = [oracle(f32_perturbed(X, s), iters) for s in (6, 7, 8)]
+            twins = oracle_twins(orc, lambda Xin: oracle(Xin, iters), X, dtype)
             tm = [measures(t[0], t[1], o) for t in twins]
             yard = {key: max(t[key] for t in tm) for key in tm[0]}
+            first = first or yard
             h = gp._iterate_gpnh_convex_coding(Xh, Zi.copy(), Wi.copy(), dtype=dtype, **dict(kw, max_iterations=iters))
             got = measures(h[0], h[1], o)
+            bound = {key: 20 * yard[key] for key in yard}
+            bound["wmax"] = max(bound["wmax"], w_chain * yard["wmax"] / first["wmax"])
             print("C3 float32 lam=%g, %d iteration(s): " % (lam, iters)
-                  + ", ".join("%s %.2e (oracle's float32-sized twins %.2e)" % (key, got[key], yard[key])
-                              for key in sorted(got)))
+                  + ", ".join("%s %.2e (bound %.2e)" % (key, got[key], bound[key]) for key in sorted(got)))
             held = ("zmax", "wmax") if iters < 8 else ("zrms", "zq999", "wmax")
             for key in held:
-                assert got[key] <= 20 * yard[key], (iters, key, got[key], yard[key])
-            assert got["face"] <= 20 * yard["face"] + 2.0 / X.shape[0], (iters, got["face"], yard["face"])
+                assert got[key] <= bound[key], (iters, key, got[key], bound[key])
+            assert got["face"] <= bound["face"] + 2.0 / X.shape[0], (iters, got["face"], bound["face"])
 
 
 @pytest.mark.parametrize("lam", [0.0, 1.0])
