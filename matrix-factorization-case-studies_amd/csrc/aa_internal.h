@@ -170,6 +170,9 @@ struct Ctx {
     // the residual projection of the dictionary SPG (spg.py:250-276: convergence flags only) runs on
     // the side stream beside the weights QP, on its own scratch set (launch_proj_side / join_side)
     hipEvent_t evFork2 = nullptr, evJoin2 = nullptr;
+    hipEvent_t evOrderFork = nullptr, evOrder = nullptr;   // sample order of the NEXT weights QP, formed on the side stream
+    bool qp_perm_ready = false;                // qpPerm holds (or will hold, after evOrder) the order by the pass counts in qpIters
+    long qp_perm_n = 0;
     bool side_pending = false;
     DevBuf tmpTall2, redPartial2, redOut2, proj2, projList2, projSegCnt2;
     int projPassHint2[4] = {0, 0, 0, 0};
@@ -368,7 +371,7 @@ extern int g_qp_refill_min;       // kernels_qp.hip
 extern int g_qp_waves;            // kernels_qp.hip
 extern int g_qp_sort;             // kernels_qp.hip
 extern int g_qp_profile;          // kernels_qp.hip
-extern int g_qp_wave_mem1;
+extern int g_qp_wave_mem1, g_qp_prefetch_order;
 extern int g_qp_overlap_tail, g_qp_tail_cap, g_qp_live, g_qp_live_blocks, g_qp_live_occ;     // kernels_qp.hip
 
 // ------------------------------------------------------------------ comm.hip

@@ -698,6 +698,23 @@ __global__ __launch_bounds__(64) void k_qp(const double *__restrict__ A /*[KQ][K
 // 64-sample wave hostage.  memory == 1 only on the continuation path (the host keeps
 // samples in phase 1 otherwise); fresh samples support any memory.
 // ---------------------------------------------------------------------------
+// sqrt(v) < e (spg.py:388-390: ||P(x - g) - x||_2 < epsilon_two) without the square root in the loop:
+// the correctly rounded square root is monotone, so with  lim = the smallest double whose square root
+// is >= e  the test is exactly  v < lim  (same decision for every v, NaN included).  lim sits within an
+// ulp or two of e * e and is found once per wave with the device's own sqrt; *ok = false (e * e
+// denormal or not finite: never in practice) keeps the sqrt form.  ~20 instructions off every pass of the
+// latency-bound wave-per-sample kernel.
+__device__ __forceinline__ double qp_sq_limit(double e, bool *ok)
+{
+    double y = e * e;
+    *ok = (e > 0.0) && (y > 1e-290) && (y < 1e290);
+    if (!*ok) return 0.0;
+    for (int i = 0; i < 4 && sqrt(y) >= e; ++i) y = __longlong_as_double(__double_as_longlong(y) - 1);
+    for (int i = 0; i < 8 && sqrt(y) < e; ++i) y = __longlong_as_double(__double_as_longlong(y) + 1);
+    *ok = sqrt(y) >= e && sqrt(__longlong_as_double(__double_as_longlong(y) - 1)) < e;
+    return y;
+}
+
 // lane exchange across rows of 16 / halves of 32 (gfx950 v_permlane16_swap / v_permlane32_swap)
 typedef unsigned int qq_u2 __attribute__((ext_vector_type(2)));
 
@@ -984,6 +1001,8 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
         else return qw_matvec<KQ>(Arow, v);
     };
     constexpr int NMEM = MEM1 ? 1 : QW_MAXMEM;
+    bool sq_ok;
+    const double sq_lim = qp_sq_limit(p.epsilon_two, &sq_ok);
     const int mem = MEM1 ? 1 : (p.memory < 1 ? 1 : (p.memory > QW_MAXMEM ? QW_MAXMEM : p.memory));
     // n_fresh >= 0: process rows [0, n_fresh) from scratch; otherwise the overflow list
     // fresh_list: the first hdr->n_long entries of the sorted sample list, from scratch
@@ -1129,7 +1148,7 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
             // max |r| < epsilon_one  <=>  no lane has |r| >= epsilon_one (no reduction)
             const bool rinf_small = __ballot(!(fabs(r) < p.epsilon_one)) == 0ull;
             n_iter += 1;
-            const bool conv = (sqrt(r2) < p.epsilon_two) || rinf_small;
+            const bool conv = (sq_ok ? r2 < sq_lim : sqrt(r2) < p.epsilon_two) || rinf_small;
             if (conv || n_feval > p.max_feval || n_iter >= p.max_iterations) break;
             if (n_iter >= park_at) {
                 parked = true;
@@ -1815,6 +1834,8 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
     }
     constexpr int J = 4 * MT;
     const int lane = threadIdx.x, sl = lane & 15, q = lane >> 4;
+    bool sq_ok;
+    const double sq_lim = qp_sq_limit(p.epsilon_two, &sq_ok);
     double H[MT][J];                                // A's operand tiles (constant)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -2010,7 +2031,7 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
         qinf = qq_max(qinf);
         if (was_active) {
             n_iter += 1;
-            const bool conv = (sqrt(q2) < p.epsilon_two) || (qinf < p.epsilon_one);
+            const bool conv = (sq_ok ? q2 < sq_lim : sqrt(q2) < p.epsilon_two) || (qinf < p.epsilon_one);
             const bool finished = conv || n_feval > p.max_feval || n_iter >= p.max_iterations;
             if (finished || n_iter >= pass_cap) {
                 if (live_epoch && !finished) {
@@ -2132,6 +2153,7 @@ int g_qp_live_occ = 3;         // register budget of k_qp_quad beside the consum
 int g_qp_live_blocks = 48;     // CUs given to the consumers (one block of 16 waves each)
 #define QP_LIVE_LDS 163840     // a CU's LDS
 int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)
+int g_qp_prefetch_order = 1;   // four-lane QP: the sample order of the NEXT update (by this update's pass counts) is formed on the side stream right after this one, beside the Z'X pass (25 us off the critical path)
 int g_qp_wave_mem1 = 1;        // continuation launches of the wave-per-sample kernel: 1 = the memory-1 instantiation (no f_mem array: 311 fewer SGPR spills), 0 = the generic one (A/B)
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
 int g_qp_tail_cap = 96;        // with qp_overlap_tail: only samples beyond this many passes go to the side stream (0: all parked ones)
@@ -2452,6 +2474,11 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     const bool will_sort = g_qp_sort && p->max_iterations > 2 && n > 4096 && !wave_only && iters_dev &&
                            iters_dev == c->qpIters.as<int>() && c->qp_iters_valid;
     int *sort_hist = nullptr;
+    // the order formed ahead of time on the side stream (end of the previous call, below)
+    const bool prefetched = c->qp_perm_ready;
+    const bool use_prefetched = prefetched && will_sort && quad_mode && c->qp_perm_n == n && !A_host;
+    c->qp_perm_ready = false;
+    if (prefetched) AA_CHECK_HIP(hipStreamWaitEvent(c->stream, c->evOrder, 0));   // used or dropped: qpPerm is ours again
     if (A_host) {
         std::vector<unsigned char> host(off_rows, 0);
         double *Ah = reinterpret_cast<double *>(host.data() + off_A);
@@ -2467,7 +2494,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         AA_CHECK_HIP(hipStreamSynchronize(c->stream));   // host vector goes out of scope
     } else {
         AA_REQUIRE(gram_dev != nullptr, AA_ERR_ARG, "QP: no Hessian");
-        if (will_sort) {                               // its histograms are zeroed by the set-up kernel
+        if (will_sort && !use_prefetched) {            // its histograms are zeroed by the set-up kernel
             AA_CHECK(c->qpPerm.alloc((size_t)n * sizeof(int) + 2 * QP_SORT_BUCKETS * sizeof(int)));
             sort_hist = c->qpPerm.as<int>() + n;
         }
@@ -2583,7 +2610,8 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         }
         // (the ordering kernels run while the cross-stream dependency of the consumers resolves: the
         // consumers are resident on their CUs before k_qp_quad fills the chip)
-        if (will_sort) AA_CHECK(qp_order_rows(c, iters_dev, n, &perm, nullptr, 0, sort_hist != nullptr));
+        if (use_prefetched) perm = c->qpPerm.as<int>();
+        else if (will_sort) AA_CHECK(qp_order_rows(c, iters_dev, n, &perm, nullptr, 0, sort_hist != nullptr));
         const int quad_occ = live ? g_qp_live_occ : g_qp_quad_occ;
         // beside live consumers every wave of k_qp_quad asks for its share of a CU's LDS (see k_qp_wave_live)
         const unsigned quad_lds = live ? (unsigned)((QP_LIVE_LDS / (4 * quad_occ)) & ~511) : 0u;
@@ -2657,6 +2685,25 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                     c->qp_tail_count = &hdr->n_overflow;
                 }
             }
+        }
+        // the order of the NEXT update by the pass counts of this one: on the side stream, behind this
+        // update's kernels, beside the Z'X pass
+        if (g_qp_prefetch_order && g_qp_sort && !A_host && !stats && !live && !defer_tail && c->stream2 && c->world <= 1 &&
+            !c->force_comm && p->max_iterations > 2 && n > 4096 && iters_dev && iters_dev == c->qpIters.as<int>()) {
+            if (!c->evOrder) {
+                AA_CHECK_HIP(hipEventCreateWithFlags(&c->evOrderFork, hipEventDisableTiming));
+                AA_CHECK_HIP(hipEventCreateWithFlags(&c->evOrder, hipEventDisableTiming));
+            }
+            AA_CHECK_HIP(hipEventRecord(c->evOrderFork, c->stream));
+            AA_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->evOrderFork, 0));
+            const int *unused = nullptr;
+            std::swap(c->stream, c->stream2);
+            const int rc = qp_order_rows(c, iters_dev, n, &unused, nullptr, 0, false);
+            std::swap(c->stream, c->stream2);
+            AA_CHECK(rc);
+            AA_CHECK_HIP(hipEventRecord(c->evOrder, c->stream2));
+            c->qp_perm_ready = true;
+            c->qp_perm_n = n;
         }
     } else if (wave_only) {
         long blocks = (n + 3) / 4;

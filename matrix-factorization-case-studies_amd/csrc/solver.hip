@@ -535,6 +535,8 @@ int aa_set_option(const char *name, int value)
         g_proj_check_always = value != 0;
     } else if (!strcmp(name, "fuse_finalize")) {
         g_fuse_finalize = value != 0;
+    } else if (!strcmp(name, "qp_prefetch_order")) {
+        g_qp_prefetch_order = value != 0;
     } else if (!strcmp(name, "grad_side")) {
         g_grad_side = value != 0;
     } else if (!strcmp(name, "qp_wave_mem1")) {
@@ -667,6 +669,8 @@ int aa_ctx_destroy(aa_ctx *h)
     for (DevBuf *b : all) b->release();
     if (c->evFork2) (void)hipEventDestroy(c->evFork2);
     if (c->evJoin2) (void)hipEventDestroy(c->evJoin2);
+    if (c->evOrderFork) (void)hipEventDestroy(c->evOrderFork);
+    if (c->evOrder) (void)hipEventDestroy(c->evOrder);
     for (int w = 0; w < 2; ++w)
         for (hipEvent_t e : c->gemmEvents[w]) (void)hipEventDestroy(e);
     if (c->evFork) (void)hipEventDestroy(c->evFork);

@@ -57,8 +57,9 @@ class _CParams(ctypes.Structure):
 
 # --------------------------------------------------------------------------
 # yardstick mode for the float32 legs of the GPU tests: what rounding the non-data operand
-# of every big contraction against X to float32, and accumulating the reduce-over-rows pass in
-# float32 (_rr), does to an otherwise exact (float64) run.
+# of every big contraction against X to float32, and accumulating the reduce-over-rows pass (_rr)
+# and the 32-column pieces of the row-local pass (_rl) in float32, does to an otherwise exact
+# (float64) run.
 # The HIP path's float32 mode feeds its four passes over X with float32 operands (the dictionary /
 # weights / search direction as MFMA A-operands of the reduce-over-rows pass, C X and X'Z as
 # operands of the row-local pass); an archetype row C X is an average over thousands of samples, so
@@ -111,6 +112,27 @@ def _rr(A, X):
 
 
 _rr.calls = 0
+
+
+def _rl(X, B):
+    """X . B for the data against a p x k matrix B (the row-local pass).  Yardstick mode: B is rounded
+    to the operand dtype and the result carries the error of the float32 accumulation chain inside
+    every 32-column piece (the pieces themselves are summed in float64):
+    independent Gaussian noise of 4e-8 x (sum of |x||b| over the piece) per piece -- at p = 4096
+    (128 pieces) an rms of 3.5e-9 of sum |x||b|, which is what k_row_local_f32_dma measures against
+    float64 NumPy; at p <= 32 the whole of 4e-8 (one chain)."""
+    if _OPERAND_DTYPE is None:
+        return X.dot(B)
+    Br = _op(B)
+    out = X.dot(Br)
+    if np.dtype(_OPERAND_DTYPE) == np.float32:
+        _rr.calls += 1
+        var = np.zeros_like(out)
+        aX, aB = np.abs(X), np.abs(Br)
+        for c0 in range(0, X.shape[1], 32):
+            var += aX[:, c0:c0 + 32].dot(aB[c0:c0 + 32]) ** 2
+        out = out + 4e-8 * np.sqrt(var) * np.random.RandomState(_rr.calls).standard_normal(out.shape)
+    return out
 
 
 _clib = None
@@ -505,7 +527,7 @@ def update_aa_dictionary(X, C, alpha, trace_XXt, XXtZ, ZtZ, project=None, **kw):
 
     def df(x):
         CX = _rr(x, X)
-        return (DZtZD.dot(_op(CX).dot(X.T)) - XXtZD.T) / x.shape[1]
+        return (DZtZD.dot(CX.dot(X.T) if _OPERAND_DTYPE is None else _rl(X, CX.T).T) - XXtZD.T) / x.shape[1]
 
     return spg(f, df, C, project=project or simplex_project_rows, **kw)
 
@@ -643,10 +665,10 @@ def iterate_aa(X, Z, C, alpha, delta=0, update_weights=True, update_dictionary=T
     da = np.diag(alpha)
     ZtZ = Z.T.dot(Z)
     CX = _rr(C, X)
-    CXXt = _op(CX).dot(X.T)
+    CXXt = CX.dot(X.T) if _OPERAND_DTYPE is None else _rl(X, CX.T).T
     CXXtCt = CX.dot(CX.T)
     XtZ = X.T.dot(Z) if _OPERAND_DTYPE is None else _rr(Z.T, X).T
-    XXtZ = X.dot(_op(XtZ))
+    XXtZ = _rl(X, XtZ)
     CXXtZ = C.dot(XXtZ)
     trX = np.trace(X.dot(X.T)) if trace_XXt is None else trace_XXt
 
@@ -672,7 +694,7 @@ def iterate_aa(X, Z, C, alpha, delta=0, update_weights=True, update_dictionary=T
             tick("dictionary", t1)
             t1 = time.perf_counter()
             CX = _rr(C, X)
-            CXXt = _op(CX).dot(X.T)
+            CXXt = CX.dot(X.T) if _OPERAND_DTYPE is None else _rl(X, CX.T).T
             CXXtCt = CX.dot(CX.T)
             CXXtZ = C.dot(XXtZ)
             tick("gram", t1)
@@ -687,7 +709,7 @@ def iterate_aa(X, Z, C, alpha, delta=0, update_weights=True, update_dictionary=T
             t1 = time.perf_counter()
             ZtZ = Z.T.dot(Z)
             XtZ = X.T.dot(Z) if _OPERAND_DTYPE is None else _rr(Z.T, X).T
-            XXtZ = X.dot(_op(XtZ))
+            XXtZ = _rl(X, XtZ)
             CXXtZ = C.dot(XXtZ)
             tick("gram", t1)
             new = cost()
@@ -831,7 +853,7 @@ def update_gpnh_dictionary(X, Z, ZtZ, GW, lambda_W=0):
 
 def update_gpnh_weights(X, Z, W, return_iters=False, **kw):
     """gpnh_convex_coding.py:254-279."""
-    return qp_batch(W.T.dot(W), X.dot(_op(W)), Z, "nk", return_iters=return_iters, **kw)
+    return qp_batch(W.T.dot(W), _rl(X, W), Z, "nk", return_iters=return_iters, **kw)
 
 
 def iterate_gpnh(X, Z, W, lambda_W=0, update_weights=True, update_dictionary=True,

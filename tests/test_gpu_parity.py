@@ -540,7 +540,9 @@ def test_gpnh_transform_golden(cdr, orc, dtype):
             def oracle(Xin, **kw):
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
-                    return orc.iterate_gpnh(Xin, Z0.copy(), W.copy(), **dict(run, **kw))
+                    # (no monotonicity check: a perturbed twin may step back by its own noise)
+                    return orc.iterate_gpnh(Xin, Z0.copy(), W.copy(),
+                                            **dict(run, require_monotonic_cost_decrease=False, **kw))
 
             # ---- fixed iterations
             for iters in (1, 3):
