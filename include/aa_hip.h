@@ -364,6 +364,16 @@ int aa_get_archetypes(aa_ctx *ctx, double *CX, long ld);
  * sqrt(K_ii - 2 K_ij + K_jj) for this rank's rows i, K = XX' never formed
  * (form DATA) or the stored K (form KERNEL).  j is a GLOBAL row index. */
 int aa_distance_column(aa_ctx *ctx, long j, double *d);
+/* The whole FurthestSum selection (furthest_sum.py:23-127) on the device, single rank: running
+ * distance sums and the candidate flags stay in device memory, every pick is one distance-column
+ * kernel and one single-block step, the picked index is passed on in device memory -- no host
+ * round trip per pick.  selected[k] out.  *tie != 0: at some pick the largest running sum was
+ * shared by several candidates; the reference then takes the one its stable sorts left last, a rule
+ * that depends on the history of the list -- the caller repeats the selection through
+ * aa_distance_column and the host's list logic (convex_dim_red/furthest_sum.py).  Distances in the
+ * arithmetic of aa_distance_column, sums updated in the same order: the same picks. */
+int aa_furthest_sum(aa_ctx *ctx, int k, long start_index, const int *exclude, int n_exclude, int extra_steps,
+                    int *selected, int *tie);
 
 /* GPNH restarts side by side (the drivers' n_init loop, bin/run_jra55_pca_gpnh.py:112-138):
  * R independent fits of k components each share one set of device arrays (R k <= 64) and every launch

@@ -131,6 +131,8 @@ _SIGNATURES = {
     "aa_reconstruction_cost": (ctypes.c_int, [_vp, _dp]),
     "aa_get_archetypes": (ctypes.c_int, [_vp, _dp, ctypes.c_long]),
     "aa_distance_column": (ctypes.c_int, [_vp, ctypes.c_long, _dp]),
+    "aa_furthest_sum": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_long, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                       ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "aa_gpnh_set_factors": (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.c_long, _dp]),
     "aa_gpnh_get_weights": (ctypes.c_int, [_vp, _dp]),
     "aa_gpnh_reduce": (ctypes.c_int, [_vp, _dp, ctypes.c_long, _dp, _dp]),
@@ -245,6 +247,19 @@ def dtype_code(dtype):
     if dtype == np.float32:
         return AA_F32
     raise ValueError("unsupported dtype %r (float64 or float32)" % (dtype,))
+
+
+def check_component_count(k, whom, defaulted_from=None):
+    """The device arrays hold 32 or 64 component slots: a model with more
+    components is refused where its hyper-parameters are checked -- before any data moves -- and
+    the message names the reference default that leads there."""
+    if isinstance(k, (int, np.integer)) and k > MAX_K:
+        hint = ""
+        if defaulted_from is not None:
+            hint = (" (n_components=None defaults to %s in the reference, archetypal_analysis.py:785-786 / "
+                    "gpnh_convex_coding.py:508-509: pass n_components <= %d explicitly)" % (defaulted_from, MAX_K))
+        raise ValueError("%s: n_components = %d exceeds the %d component slots of the MI355X build%s"
+                         % (whom, k, MAX_K, hint))
 
 
 def require_gpu():
@@ -564,6 +579,21 @@ class Context(object):
         d = np.empty(self.n)
         _check(self.lib.aa_distance_column(self.h, int(j), _ptr(d)))
         return self._gather_rows(d)
+
+    def furthest_sum(self, n_components, start_index, exclude=None, extra_steps=1):
+        """FurthestSum on the device (aa_furthest_sum); returns the selected indices, or None when a
+        pick met a shared maximum (the caller then uses the host's list logic) or the context is
+        row-sharded."""
+        if self.global_view or n_components < 1 or n_components > MAX_K:
+            return None
+        ex = np.ascontiguousarray([] if exclude is None else exclude, dtype=np.int32)
+        sel = np.zeros(int(n_components), dtype=np.int32)
+        tie = ctypes.c_int(0)
+        _check(self.lib.aa_furthest_sum(self.h, int(n_components), int(start_index),
+                                        ex.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), int(ex.size),
+                                        int(max(extra_steps, 0)),
+                                        sel.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(tie)))
+        return None if tie.value else sel.astype(np.int64)
 
     # -- GPNH
     def gpnh_set_factors(self, k, W=None, Z=None):

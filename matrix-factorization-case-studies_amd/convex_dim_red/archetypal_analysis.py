@@ -84,10 +84,27 @@ def _initialize_kernel_aa_dictionary_furthest_sum(kernel, n_components, start_in
     return _one_hot_rows(selected, n_samples, kernel.dtype)
 
 
+_FURTHEST_SUM_ON_DEVICE = True       # False: always the host-driven selection (one distance column per pick)
+
+
 def _furthest_sum_on_device(ctx, n_samples, n_components, start_index, n_extra_steps, exclude, cache=None):
     """FurthestSum with distance columns computed from the resident data matrix (``cache``: columns
     already fetched for the same matrix -- restarts.fit_restarts shares one over its restarts)."""
+    shared = cache is not None                   # restarts.fit_restarts: one cache for the draws of all restarts
     cache = {} if cache is None else cache
+    # A restart loop on a matrix whose distance columns are expensive (short and wide: the
+    # HadISST shape, 322 MB per column) keeps the host-driven form: its picks end at the same few
+    # extreme points restart after restart, so nearly every column comes out of the shared cache.
+    column_bytes = float(getattr(ctx, 'n', 0)) * float(getattr(ctx, 'p', 0)) * (4 if ctx.dtype_code == _backend.AA_F32 else 8)
+    if _FURTHEST_SUM_ON_DEVICE and not (shared and column_bytes > 64e6):
+        # the whole selection in one chain of device launches (aa_furthest_sum); the host's list logic
+        # below takes over when a pick meets a shared maximum (the reference's tie rule lives there)
+        from .furthest_sum import _validate
+        ex = [] if exclude is None else [int(e) for e in exclude]
+        _validate(n_samples, n_components, start_index, ex)
+        picked = ctx.furthest_sum(n_components, start_index, ex, n_extra_steps) if n_components > 0 else None
+        if picked is not None:
+            return picked
 
     def column_of(j, sense):
         j = int(j)
@@ -409,6 +426,7 @@ def _fit_on_data_matrix(self, data, linear_kernel, label, dictionary=None, weigh
     n_samples = data.shape[0]
     if self.n_components is None:
         self.n_components = data.shape[1]
+        self._n_components_defaulted_from = 'n_features'
     self._check_hyper_parameters()
     shape_only = _ShapeOnly(n_samples)
     if (kwargs.get('_draw_only', False) and self.init == 'random' and not on_device and dictionary is None
@@ -509,6 +527,8 @@ class _BaseAA(object):
         if not isinstance(self.n_components, INTEGER_TYPES) or self.n_components <= 0:
             raise ValueError('Number of components must be a positive integer;'
                              ' got (n_components=%r)' % self.n_components)
+        _backend.check_component_count(self.n_components, self._whom,
+                                       getattr(self, '_n_components_defaulted_from', None))
         if not isinstance(self.max_iterations, INTEGER_TYPES) or self.max_iterations <= 0:
             raise ValueError('Maximum number of iterations must be a positive '
                              'integer; got (max_iterations=%r)' % self.max_iterations)
@@ -580,6 +600,7 @@ class KernelAA(_BaseAA):
             # runs on ||x_i - x_j||^2 = K_ii - 2 K_ij + K_jj computed from X.
             if self.n_components is None:
                 self.n_components = kernel.shape[0]
+                self._n_components_defaulted_from = 'n_samples'
             out = _fit_on_data_matrix(self, kernel, True, "Kernel AA", dictionary, weights, alpha,
                                       update_dictionary, update_weights, update_scale_factors,
                                       **kwargs)
@@ -592,6 +613,7 @@ class KernelAA(_BaseAA):
                              'Got shape %s' % ('kernel_aa', kernel.shape))
         if self.n_components is None:
             self.n_components = n_samples
+            self._n_components_defaulted_from = 'n_samples'
         self._check_hyper_parameters()
 
         dictionary, weights, alpha = self._resolve_factors(

@@ -325,17 +325,9 @@ class GPNHConvexCoding(object):
             if exclude is None:
                 exclude = np.array([], dtype='i8')
             cache = kwargs['_cache'].setdefault('distance_columns', {}) if '_cache' in kwargs else {}
-
-            def column_of(j, sense):
-                j = int(j)
-                if j not in cache:
-                    cache[j] = ctx.distance_column(j)
-                return cache[j]
-
-            selected = furthest_sum_from_columns(
-                column_of, lambda i, j: column_of(j, "into")[int(i)], n_samples,
-                self.n_components, start_index, exclude=exclude,
-                extra_steps=kwargs.get('n_extra_steps', 10))
+            from .archetypal_analysis import _furthest_sum_on_device
+            selected = _furthest_sum_on_device(ctx, n_samples, self.n_components, start_index,
+                                               kwargs.get('n_extra_steps', 10), exclude, cache=cache)
             return np.ascontiguousarray(np.asarray(data, dtype=np.float64)[selected].T)
         raise ValueError('Invalid init parameter: got %r instead of one of %r'
                          % (init, INITIALIZATION_METHODS))
@@ -354,11 +346,14 @@ class GPNHConvexCoding(object):
         if not on_device:
             data = np.asarray(data)
         n_samples, n_features = data.shape
+        defaulted = None
         if self.n_components is None:
             self.n_components = n_features
+            defaulted = 'n_features'
         if not isinstance(self.n_components, INTEGER_TYPES) or self.n_components <= 0:
             raise ValueError('Number of components must be a positive integer;'
                              ' got (n_components=%r)' % self.n_components)
+        _backend.check_component_count(self.n_components, 'GPNHConvexCoding', defaulted)
         if not isinstance(self.max_iterations, INTEGER_TYPES) or self.max_iterations <= 0:
             raise ValueError('Maximum number of iterations must be a positive '
                              'integer; got (max_iterations=%r)' % self.max_iterations)

@@ -225,6 +225,7 @@ struct Ctx {
     DevBuf iterState, snapC, snapZ, snapAlpha; // aa_iterate: status record, factors at the stopping iteration
     DevBuf qpIters;                            // n ints: pass counts of the latest weights update
     DevBuf qpPerm;                             // n ints: sample order of the lane kernel
+    DevBuf fsScratch;                          // FurthestSum on the device: running sums, one distance column, state, alive flags
     bool qp_iters_valid = false;               // qpIters belongs to the current rows / state
     bool linear_kernel = false;                // data form, KernelAA conventions: K = X X' implicit (aa_set_linear_kernel)
     DevBuf qpStats;                            // 2 long long
@@ -315,6 +316,8 @@ int launch_gpnh_judge(Ctx *c, int it, double cost0, const double *costs, IterSta
 enum { ST_INIT_F = 0, ST_ALPHA = 1, ST_LINESEARCH = 2, ST_BB = 3, ST_CONV = 4 };
 int launch_row_sqnorm_sum(Ctx *c, double *trace_out_host);
 int launch_distance_column(Ctx *c, long j_local, int owner_has_row, const double *xj_host, double *d_host);
+int launch_furthest_sum(Ctx *c, int k, int start, const int *exclude_host, int n_ex, int extra_steps,
+                        int *selected_host, int *tie_host);
 int launch_row_broadcast(Ctx *c, long j_local, bool own);
 int launch_proj_side(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode,
                      const aa_spg_params *sp, int stage_after);   // launch_proj on the side stream / scratch set

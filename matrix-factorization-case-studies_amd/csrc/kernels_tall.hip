@@ -321,8 +321,9 @@ __device__ __forceinline__ void proj_solve_lds(const double *u, int total, doubl
 
 // PACK = false: one block per column finishes the projection on this rank's candidate
 // list.  PACK = true (multi-rank): the block only copies the list, in its fixed order, into
-// this rank's slot of the gather buffer ([world][KP][cap + 1], element cap = the count, -1
-// when the list does not fit); k_proj_solve_gathered continues after the all-reduce.
+// this rank's slot of the gather buffer ([world][KP][cap + 2]: candidates, element cap = the true
+// count, element cap + 1 = the largest candidate left out when the list is longer than the slot);
+// k_proj_solve_gathered continues after the all-reduce.
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ list,
                                                     const int *__restrict__ segcnt, long nseg,
@@ -396,7 +397,81 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
         }
     }
     if constexpr (PACK) {
-        if (t == 0) dst[pack_cap] = in_lds ? (double)total : -1.0;
+        // slot layout: [0, cap) candidates, [cap] = this rank's TRUE candidate count, [cap + 1] = the
+        // largest candidate that was NOT sent (-inf: all were sent; +inf: none selected, list too long)
+        if (in_lds) {
+            if (t == 0) {
+                dst[pack_cap] = (double)total;
+                dst[pack_cap + 1] = -INFINITY;
+            }
+            return;
+        }
+        // More candidates than the slot holds (they are the entries above a LOWER BOUND of the
+        // threshold, usually far more than the support): send the pack_cap largest, in their list
+        // order, and the largest one left out as a witness.  If the threshold the ranks then find on
+        // the union of these lists is >= every rank's witness, nothing left out belongs to the
+        // support and the threshold is exact (k_proj_solve_gathered); the device decides, the host
+        // does not have to look.  The (cap + 1)-th largest key by radix selection, bit by bit, on the
+        // order-preserving integer image of the doubles.
+        if (total > 64 * pack_cap) {                     // hopeless (dense start): leave it to the fallback
+            if (t == 0) {
+                dst[pack_cap] = (double)total;
+                dst[pack_cap + 1] = INFINITY;
+            }
+            return;
+        }
+        auto key_of = [](double v) -> unsigned long long {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+            return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+        };
+        auto for_each_mine = [&](auto &&fn) {
+            for (int q = 0; q < spt; ++q)
+                if (s0 + q < nseg) {
+                    const int cq2 = mycnt[s0 + q];
+                    const double *src = mylist + (s0 + q) * segcap;
+                    for (int i = 0; i < cq2; ++i) fn(src[i]);
+                }
+        };
+        unsigned long long kw = 0ull;
+        for (int bit = 63; bit >= 0; --bit) {
+            const unsigned long long trial = kw | (1ull << bit);
+            double dummy = 0.0;
+            int m = 0;
+            for_each_mine([&](double v) { m += key_of(v) >= trial ? 1 : 0; });
+            block_sum_sm(dummy, m, rs, rm);
+            if (m >= pack_cap + 1) kw = trial;               // uniform: every thread holds the block total
+        }
+        // kw = key of the (cap + 1)-th largest candidate: everything strictly above it is sent
+        int sel = 0;
+        for_each_mine([&](double v) { sel += key_of(v) > kw ? 1 : 0; });
+        __syncthreads();
+        scan[t] = sel;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int add = t >= off ? scan[t - off] : 0;
+            __syncthreads();
+            scan[t] += add;
+            __syncthreads();
+        }
+        int pos = scan[t] - sel;
+        double witness = -INFINITY;
+        for_each_mine([&](double v) {
+            if (key_of(v) > kw) dst[pos++] = v;
+            else witness = fmax(witness, v);
+        });
+        double dummy = 0.0;
+        int sent = scan[255];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) witness = fmax(witness, __shfl_xor(witness, o, 64));
+        if ((t & 63) == 0) rs[t >> 6] = witness;
+        __syncthreads();
+        if (t == 0) {
+            // (zero-fill between the candidates sent and the slot's end: the buffer was zeroed)
+            dst[pack_cap] = (double)total;
+            dst[pack_cap + 1] = fmax(fmax(rs[0], rs[1]), fmax(rs[2], rs[3]));
+            (void)sent;
+            (void)dummy;
+        }
         return;
     }
     __syncthreads();
@@ -522,8 +597,10 @@ __global__ __launch_bounds__(256) void k_proj_small(const double *__restrict__ x
 
 // multi-rank: the ranks' candidate lists side by side (gathered [world][KP][cap + 1], summed
 // all-reduce of per-rank slots) -> the same fixed point on every rank, lists concatenated in
-// rank order.  A rank whose list did not fit (count -1) leaves the column unconverged; the
-// host then falls back to the iterative passes from the lower bound.
+// rank order.  A rank with more candidates than its slot holds has sent its largest ones and the
+// largest it left out (k_proj_solve<true>); if that witness lies above the threshold found here the
+// column is left unconverged (sticky flag; the host falls back to the iterative passes from the lower
+// bound when it checks at once, or stops with an error at its next poll).
 __global__ __launch_bounds__(256) void k_proj_solve_gathered(const double *__restrict__ gathered,
                                                              int world, int cap, int KP,
                                                              ProjState *__restrict__ ps, int mode)
@@ -532,35 +609,46 @@ __global__ __launch_bounds__(256) void k_proj_solve_gathered(const double *__res
     __shared__ double rs[4];
     __shared__ int rm[4];
     const int comp = blockIdx.x, t = threadIdx.x;
-    const size_t stride = (size_t)cap + 1;
-    int total = 0;
-    bool overflow = false;
+    const size_t stride = (size_t)cap + 2;
+    // per rank: its true candidate count (the first min(count, cap) slots hold what it sent) and the
+    // largest candidate it left out
+    int total = 0, true_total = 0;
+    double witness = -INFINITY;
     for (int r = 0; r < world; ++r) {                    // uniform: every thread reads the counts
-        const double c = gathered[((size_t)r * KP + comp) * stride + cap];
-        if (c < 0.0) overflow = true;
-        else total += (int)c;
+        const double *src = gathered + ((size_t)r * KP + comp) * stride;
+        const int c = (int)src[cap];
+        true_total += c;
+        total += c < cap ? c : cap;
+        witness = fmax(witness, src[cap + 1]);
     }
-    if (total > PROJ_LDS_CAP) overflow = true;
+    bool overflow = total > PROJ_LDS_CAP || witness == INFINITY;
     double th = ps->t[comp];
     int prev = -1, conv = 0;
     if (!overflow) {
         int pos = 0;
         for (int r = 0; r < world; ++r) {
             const double *src = gathered + ((size_t)r * KP + comp) * stride;
-            const int c = (int)src[cap];
+            const int c0 = (int)src[cap];
+            const int c = c0 < cap ? c0 : cap;
             for (int i = t; i < c; i += 256) u[pos + i] = src[i];
             pos += c;
         }
         __syncthreads();
         if (total == 0) conv = 1;
         else proj_solve_lds(u, total, th, prev, conv, rs, rm);
+        // a candidate that was left out and lies above the threshold belongs to the support: the lists
+        // were too short for THIS column (its support, not just its candidate list, outgrew a slot)
+        if (conv && witness > th) {
+            conv = 0;
+            overflow = true;
+        }
     }
     if (t == 0) {
-        ps->t[comp] = th;
+        ps->t[comp] = overflow ? ps->t[comp] : th;       // an unconverged column keeps its lower bound for the fallback
         ps->cnt[comp] = (double)prev;
         ps->shrunk[comp] = conv;
         if (!conv) atomicOr(&ps->overflow_sticky, 1);
-        atomicMax(&ps->list_max[mode & 3], overflow ? (1 << 30) : total);
+        atomicMax(&ps->list_max[mode & 3], overflow ? (1 << 30) : true_total);
     }
 }
 
@@ -1922,7 +2010,7 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
 static int g_proj_hard_cap = 200;
 
 int g_proj_mode = 0;        // 0: candidate lists, 1: iterative full passes
-int g_proj_check_always = 1; // multi-rank: 1 (default) = every list projection is checked for overflow at once (one host
+int g_proj_check_always = 0; // multi-rank: 1 = every list projection is checked for overflow at once (one host
                              // synchronisation; an overflowing column falls back to the iterative passes in the same
                              // projection), 0 = the check is deferred to the next poll while the lists of that kind of
                              // projection have been short -- faster, but a list that outgrows its slot between two
@@ -2016,10 +2104,11 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
         } else {
             // every rank packs its candidates into its slot of [world][KP][cap + 1]; one sum
             // all-reduce puts all lists on all ranks; each rank solves the union (same bits)
+            // (slot layout [KP][cap + 2]: candidates, true count, largest candidate left out)
             int cap = g_proj_list_cap;
             if (cap * c->world > PROJ_LDS_CAP) cap = PROJ_LDS_CAP / c->world;
             if (cap < 1) cap = 1;
-            const size_t stride = (size_t)cap + 1, slot = (size_t)c->KP * stride;
+            const size_t stride = (size_t)cap + 2, slot = (size_t)c->KP * stride;
             AA_CHECK(c->listGather.alloc((size_t)c->world * slot * sizeof(double)));
             double *gl = c->listGather.as<double>();
             AA_CHECK_HIP(hipMemsetAsync(gl, 0, (size_t)c->world * slot * sizeof(double), c->stream));
@@ -3556,6 +3645,226 @@ int launch_distance_column(Ctx *c, long j_local, int owner_has_row, const double
     AA_CHECK_HIP(hipMemcpyAsync(d_host, dd, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost,
                                 c->stream));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return AA_OK;
+}
+
+// ---------------------------------------------------------------- FurthestSum on the device
+// furthest_sum.py:23-127 of the reference with the candidate list as two device arrays (running sums,
+// alive flags): a pick is the live candidate with the largest running sum (the reference sorts its
+// list by sum, stably, and pops the last element: the same candidate unless the largest sum is
+// shared -- then the winner depends on the history of earlier sorts, the host's _Pool knows that
+// rule, and this chain only raises a flag so that the caller repeats the selection there).  One
+// distance column (k_distance_data / k_distance_kernel arithmetic: i == j gives exactly 0) and one
+// single-block step per pick, the index of the picked row passed on in device memory: no host
+// round trip per pick (the host-driven form pulled n doubles per pick and spent 5 ms per
+// initialisation at 22 280 samples in NumPy: SURVEY 8(f1), the drivers' FurthestSum restarts).
+struct FsState {
+    int cur, tie, next_slot, pad;
+    int selected[AA_MAX_K];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_fs_distance(const T *__restrict__ X, long ldx, long n, int p_pad,
+                                                     int data_form, const FsState *__restrict__ st,
+                                                     double *__restrict__ d)
+{
+    const long j = st->cur;
+    if (data_form) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const long r = (long)blockIdx.x * 4 + wave;
+        if (r >= n) return;
+        const T *xj = X + j * ldx;
+        double sii = 0.0, sij = 0.0, sjj = 0.0;
+        for (int c = lane; c < p_pad; c += 64) {
+            const double a = (double)X[r * ldx + c], b = (double)xj[c];
+            sii = fma(a, a, sii);
+            sij = fma(a, b, sij);
+            sjj = fma(b, b, sjj);
+        }
+        sii = wave_sum(sii);
+        sij = wave_sum(sij);
+        sjj = wave_sum(sjj);
+        if (lane == 0) d[r] = sqrt(fmax(sii - 2.0 * sij + sjj, 0.0));
+    } else {
+        const long r = (long)blockIdx.x * 256 + threadIdx.x;
+        if (r >= n) return;
+        const double kd = (double)X[r * ldx + r], kj = (double)X[r * ldx + j], jj = (double)X[j * ldx + j];
+        d[r] = sqrt(kd - 2.0 * kj + jj);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fs_init(unsigned char *__restrict__ alive, long n, int start,
+                                                 const int *__restrict__ exclude, int n_ex, int k,
+                                                 FsState *__restrict__ st)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        bool ok = i != start;
+        for (int e = 0; e < n_ex; ++e) ok = ok && exclude[e] != i;
+        alive[i] = ok ? 1 : 0;
+    }
+    if (i == 0) {
+        st->cur = start;
+        st->tie = 0;
+        st->next_slot = 1;
+        for (int q = 0; q < AA_MAX_K; ++q) st->selected[q] = start;
+    }
+}
+
+// op 0: sums = col (the list as first built, furthest_sum.py:103-108); op 1: sums += col on the live
+// candidates (:16-20 after a pick); op 2: sums -= col, the candidate `leaving` = selected[slot] comes
+// back with the sum of its distances to the other selected points (:113-123).  pick != 0: afterwards
+// the live candidate with the largest sum goes to selected[pick_slot] and becomes st->cur.
+// set_cur_slot >= 0 (no pick): st->cur = selected[set_cur_slot] (the next replacement's `leaving`).
+template <typename T>
+__global__ __launch_bounds__(1024) void k_fs_step(double *__restrict__ sums, unsigned char *__restrict__ alive,
+                                                  const double *__restrict__ col, long n, int op, int slot,
+                                                  int k, int pick, int pick_slot, int set_cur_slot,
+                                                  FsState *__restrict__ st, const T *__restrict__ X, long ldx,
+                                                  int p_pad, int data_form)
+{
+    __shared__ double sv[1024];
+    __shared__ long si[1024];
+    __shared__ int sc[1024];
+    __shared__ double dback[AA_MAX_K];
+    const int t = threadIdx.x;
+    const int leaving = op == 2 ? st->selected[slot] : -1;
+    for (long i = t; i < n; i += 1024)
+        if (alive[i]) sums[i] = op == 0 ? col[i] : (op == 1 ? sums[i] + col[i] : sums[i] - col[i]);
+    if (op == 2) {
+        // D[leaving, other] in the orientation the host path reads it (row = leaving, column = other: the
+        // dissimilarity is not symmetric to the last bit), one wave per selected point, the arithmetic
+        // of k_fs_distance
+        const int wave = t >> 6, lane = t & 63;
+        for (int q = wave; q < k; q += 16) {
+            const long other = st->selected[q];
+            double dv = 0.0;
+            if (other != leaving) {
+                if (data_form) {
+                    const T *xi = X + (long)leaving * ldx, *xj = X + other * ldx;
+                    double sii = 0.0, sij = 0.0, sjj = 0.0;
+                    for (int c = lane; c < p_pad; c += 64) {
+                        const double a = (double)xi[c], b = (double)xj[c];
+                        sii = fma(a, a, sii);
+                        sij = fma(a, b, sij);
+                        sjj = fma(b, b, sjj);
+                    }
+                    sii = wave_sum(sii);
+                    sij = wave_sum(sij);
+                    sjj = wave_sum(sjj);
+                    dv = sqrt(fmax(sii - 2.0 * sij + sjj, 0.0));
+                } else {
+                    const double kd = (double)X[(long)leaving * ldx + leaving], kj = (double)X[(long)leaving * ldx + other],
+                                 jj = (double)X[other * ldx + other];
+                    dv = sqrt(kd - 2.0 * kj + jj);
+                }
+            }
+            if (lane == 0) dback[q] = dv;
+        }
+    }
+    __syncthreads();
+    if (op == 2 && t == 0) {
+        double back = 0.0;
+        for (int q = 0; q < k; ++q)                       // in the order of `selected`, as the reference sums
+            if (st->selected[q] != leaving) back += dback[q];
+        alive[leaving] = 1;
+        sums[leaving] = back;
+    }
+    __syncthreads();
+    if (pick) {
+        double best = -INFINITY;
+        long arg = -1;
+        int cnt = 0;
+        for (long i = t; i < n; i += 1024)
+            if (alive[i]) {
+                const double v = sums[i];
+                if (v > best) { best = v; arg = i; cnt = 1; }
+                else if (v == best) { cnt += 1; }
+            }
+        sv[t] = best; si[t] = arg; sc[t] = cnt;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if (t < o) {
+                const double a = sv[t], b = sv[t + o];
+                if (b > a) { sv[t] = b; si[t] = si[t + o]; sc[t] = sc[t + o]; }
+                else if (b == a) { sc[t] += sc[t + o]; if (si[t] < 0) si[t] = si[t + o]; }
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            if (sc[0] != 1 || si[0] < 0) st->tie = 1;     // shared maximum (or nothing left): the host decides
+            const long a = si[0] < 0 ? 0 : si[0];
+            st->selected[pick_slot] = (int)a;
+            alive[a] = 0;
+            st->cur = (int)a;
+        }
+    } else if (set_cur_slot >= 0 && t == 0) {
+        st->cur = st->selected[set_cur_slot];
+    }
+}
+
+int launch_furthest_sum(Ctx *c, int k, int start, const int *exclude_host, int n_ex, int extra_steps,
+                        int *selected_host, int *tie_host)
+{
+    const long n = c->n;
+    // scratch: sums[n] | col[n] | FsState | exclude[n_ex] | alive[n]
+    const size_t off_col = round_up((long)n * sizeof(double), 256);
+    const size_t off_st = 2 * off_col;
+    const size_t off_ex = off_st + round_up((long)sizeof(FsState), 256);
+    const size_t off_alive = off_ex + round_up((long)(n_ex > 0 ? n_ex : 1) * sizeof(int), 256);
+    AA_CHECK(c->fsScratch.alloc(off_alive + (size_t)n));
+    unsigned char *base = reinterpret_cast<unsigned char *>(c->fsScratch.p);
+    double *sums = reinterpret_cast<double *>(base), *col = reinterpret_cast<double *>(base + off_col);
+    FsState *st = reinterpret_cast<FsState *>(base + off_st);
+    int *ex = reinterpret_cast<int *>(base + off_ex);
+    unsigned char *alive = base + off_alive;
+    if (n_ex > 0)
+        AA_CHECK_HIP(hipMemcpyAsync(ex, exclude_host, (size_t)n_ex * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_fs_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, alive, n, start,
+                       (const int *)ex, n_ex, k, st);
+    const int data = c->form == AA_FORM_DATA;
+    auto distance = [&]() {
+        const dim3 grid((unsigned)(data ? (n + 3) / 4 : (n + 255) / 256));
+        if (c->dtype == AA_F32)
+            hipLaunchKernelGGL(k_fs_distance<float>, grid, dim3(256), 0, c->stream, c->X.as<float>(), c->p_pad, n,
+                               (int)c->p_pad, data, (const FsState *)st, col);
+        else
+            hipLaunchKernelGGL(k_fs_distance<double>, grid, dim3(256), 0, c->stream, c->X.as<double>(), c->p_pad, n,
+                               (int)c->p_pad, data, (const FsState *)st, col);
+    };
+    auto step = [&](int op, int slot, int pick, int pick_slot, int set_cur_slot) {
+        if (c->dtype == AA_F32)
+            hipLaunchKernelGGL(k_fs_step<float>, dim3(1), dim3(1024), 0, c->stream, sums, alive, (const double *)col, n,
+                               op, slot, k, pick, pick_slot, set_cur_slot, st, (const float *)c->X.as<float>(),
+                               c->p_pad, (int)c->p_pad, data);
+        else
+            hipLaunchKernelGGL(k_fs_step<double>, dim3(1), dim3(1024), 0, c->stream, sums, alive, (const double *)col, n,
+                               op, slot, k, pick, pick_slot, set_cur_slot, st, (const double *)c->X.as<double>(),
+                               c->p_pad, (int)c->p_pad, data);
+    };
+    // the list as first built: distances to the start point; first pick
+    distance();
+    const int first_leaving = extra_steps > 0 ? 0 : -1;
+    if (k > 1) step(0, 0, 1, 1, -1);
+    else step(0, 0, 0, 0, first_leaving);
+    for (int slot = 1; slot < k; ++slot) {
+        distance();                                       // column of selected[slot]
+        if (slot + 1 < k) step(1, 0, 1, slot + 1, -1);
+        else step(1, 0, 0, 0, first_leaving);
+    }
+    for (int s = 0; s < extra_steps; ++s) {
+        const int slot = s % k;
+        distance();                                       // column of the point that leaves (st->cur)
+        step(2, slot, 1, slot, -1);                       // it comes back as a candidate; the furthest takes its place
+        distance();
+        step(1, 0, 0, 0, s + 1 < extra_steps ? (s + 1) % k : -1);
+    }
+    AA_CHECK_HIP(hipGetLastError());
+    FsState hst;
+    AA_CHECK_HIP(hipMemcpyAsync(&hst, st, sizeof(hst), hipMemcpyDeviceToHost, c->stream));
+    AA_CHECK_HIP(hipStreamSynchronize(c->stream));
+    for (int q = 0; q < k; ++q) selected_host[q] = hst.selected[q];
+    *tie_host = hst.tie;
     return AA_OK;
 }
 

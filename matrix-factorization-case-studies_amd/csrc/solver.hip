@@ -664,7 +664,7 @@ int aa_ctx_destroy(aa_ctx *h)
     comm_destroy(c);
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->rlPartial, &c->redPartial,
-                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->iterState, &c->snapC, &c->snapZ, &c->snapAlpha, &c->qpIters, &c->qpPerm,
+                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->iterState, &c->snapC, &c->snapZ, &c->snapAlpha, &c->qpIters, &c->qpPerm, &c->fsScratch,
                      &c->qpStats, &c->qpLive, &c->slotCosts, &c->slotCounters, &c->slotStates, &c->slotCost0, &c->slotSnapP, &c->slotSaveP, &c->slotSaveGr, &c->tmpTall2, &c->redPartial2, &c->redOut2, &c->proj2, &c->projList2, &c->projSegCnt2};
     for (DevBuf *b : all) b->release();
     if (c->evFork2) (void)hipEventDestroy(c->evFork2);
@@ -1270,6 +1270,26 @@ int aa_distance_column(aa_ctx *h, long j, double *d)
         return launch_distance_column(c, jl, own ? 1 : 0, nullptr, d);
     }
     return launch_distance_column(c, j, 1, nullptr, d);
+}
+
+int aa_furthest_sum(aa_ctx *h, int k, long start_index, const int *exclude, int n_exclude, int extra_steps,
+                    int *selected, int *tie)
+{
+    AA_REQUIRE(h && selected && tie, AA_ERR_ARG, "null argument");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->have_data, AA_ERR_STATE, "no data");
+    AA_REQUIRE(c->world <= 1 && !c->force_comm, AA_ERR_STATE,
+               "aa_furthest_sum is single-rank (row-sharded runs pull distance columns: aa_distance_column)");
+    AA_REQUIRE(k >= 1 && k <= AA_MAX_K, AA_ERR_ARG, "k = %d out of range", k);
+    AA_REQUIRE(start_index >= 0 && start_index < c->n, AA_ERR_ARG, "start index %ld out of range", start_index);
+    AA_REQUIRE(n_exclude >= 0 && (n_exclude == 0 || exclude), AA_ERR_ARG, "bad exclude list");
+    for (int e = 0; e < n_exclude; ++e)
+        AA_REQUIRE(exclude[e] >= 0 && exclude[e] < c->n && exclude[e] != start_index, AA_ERR_ARG,
+                   "excluded index %d out of range or equal to the start index", exclude[e]);
+    AA_REQUIRE((long)k <= c->n - n_exclude, AA_ERR_ARG, "too few points for %d components", k);
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    return launch_furthest_sum(c, k, (int)start_index, exclude, n_exclude, extra_steps < 0 ? 0 : extra_steps,
+                               selected, tie);
 }
 
 // ------------------------------------------------------------------ GPNH

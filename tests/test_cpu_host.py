@@ -275,3 +275,18 @@ def test_gap_statistic_matches_its_definition():
     assert abs(w - KMeans(n_clusters=3, n_init=10, random_state=r).fit(sample).inertia_) < 1e-9 * w
     with pytest.raises(ValueError, match="unrecognized reference"):
         cdr.gap_statistic(X, Wk, 3, n_trials=1, reference="nope")
+
+
+def test_more_than_64_components_is_refused_before_any_data_moves():
+    """The device arrays hold at most 64 component slots.  The reference's KernelAA(n_components=None)
+    defaults to n_samples (archetypal_analysis.py:785-786) and GPNHConvexCoding(None) to n_features
+    (gpnh_convex_coding.py:508-509): both are refused where the hyper-parameters are checked, with
+    the default named -- no GPU needed to get there."""
+    import convex_dim_red as cdr
+    K = np.eye(80)
+    with pytest.raises(ValueError, match="n_components = 80 exceeds the 64 component slots.*n_samples"):
+        cdr.KernelAA(None).fit_transform(K)
+    with pytest.raises(ValueError, match="exceeds the 64 component slots"):
+        cdr.ArchetypalAnalysis(65).fit_transform(np.ones((100, 70)))
+    with pytest.raises(ValueError, match="n_components = 70 exceeds.*n_features"):
+        cdr.GPNHConvexCoding(None).fit_transform(np.ones((100, 70)))

@@ -885,6 +885,7 @@ def test_rccl_path_single_rank(cdr, orc):
             _backend.set_option("proj_mode", 0)
             _backend.set_option("proj_list_cap", 2048)
             _backend.set_option("proj_small", 1)
+            _backend.set_option("proj_check", 0)
 
     # bit-for-bit: both paths on the candidate-list projection (the single-rank default for
     # columns this short, the one-kernel threshold search, sums in another order)
@@ -897,9 +898,19 @@ def test_rccl_path_single_rank(cdr, orc):
     small = run(False)                                   # one-kernel threshold search: rounding level
     assert abs(small[0] - a[0]) < 1e-12 * abs(a[0]) and np.abs(small[1] - a[1]).max() < 1e-6 * abs(a[0])
     assert np.abs(small[3] - a[3]).max() < 1e-6 and np.abs(small[4] - a[4]).max() < 1e-5
-    a, c = run(False, proj_small=0), run(True, proj_list_cap=1)
+    a, c = run(False, proj_small=0), run(True, proj_list_cap=1, proj_check=1)
     assert np.abs(np.asarray(a[1]) - np.asarray(c[1])).max() < 1e-9 * abs(a[0])
     assert np.abs(a[3] - c[3]).max() < 1e-12 and np.abs(a[4] - c[4]).max() < 1e-9
+    # A slot shorter than the candidate lists but longer than the supports (round 4): the rank sends its
+    # largest candidates and the largest one it left out; the threshold found on what was sent is
+    # checked against that witness ON THE DEVICE, so the host neither looks (proj_check = 0: an
+    # unconverged column would end the call with an error at the next poll) nor falls back.  Cold
+    # projections collect every entry above max - 1 -- all 900 rows of a column here -- against
+    # supports of a few dozen.  Same thresholds up to the summation order of the compacted lists.
+    for cap in (128, 300):
+        d = run(True, proj_list_cap=cap, proj_check=0)
+        assert np.abs(np.asarray(a[1]) - np.asarray(d[1])).max() < 1e-12 * abs(a[0]), cap
+        assert np.abs(a[3] - d[3]).max() < 1e-13 and np.abs(a[4] - d[4]).max() < 1e-9, cap
 
 
 @pytest.mark.parametrize("n,k,dense", [(900, 6, False), (7000, 5, True), (7000, 40, True),
@@ -1352,3 +1363,57 @@ def _check_scale_factors(aa, orc, X, Z0, C0, a0, form, skw, tol):
     assert np.abs(dev[2] - 1.0).max() > 1e-3                             # the scale factors did move
     assert np.abs(np.asarray(dev[6]) - np.asarray(host[6])).max() < tol * dev[3] * 10
     assert np.abs(dev[1] - want[1]).max() < 1e4 * tol and np.abs(dev[0] - want[0]).max() < 1e-4
+
+
+# ---------------------------------------------------------------- FurthestSum on the device
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_furthest_sum_on_the_device(cdr, orc, dtype):
+    """aa_furthest_sum (the whole selection as one chain of device launches, round 4) against the
+    host-driven selection it replaces (one distance column per pick, the reference's list logic in
+    convex_dim_red/furthest_sum.py) and against the reference's own selections on the golden
+    dissimilarity matrices: same indices in the same order, with exclusions, 0 / 1 / 10 / 37 extra
+    steps, k = 1 and k = 60; data with duplicated rows (shared maxima: the device raises its tie
+    flag and the host's rule decides); the kernel form (explicit K)."""
+    from convex_dim_red import _backend
+    from convex_dim_red import archetypal_analysis as aa
+    rng = np.random.RandomState(12)
+    X = rng.standard_normal((700, 90))
+    Xh = X.astype(np.float32) if dtype == "float32" else X
+
+    def host(ctx, n, k, start, extra, exclude):
+        aa._FURTHEST_SUM_ON_DEVICE = False
+        try:
+            return aa._furthest_sum_on_device(ctx, n, k, start, extra, exclude)
+        finally:
+            aa._FURTHEST_SUM_ON_DEVICE = True
+
+    with _backend.Context(dtype=dtype) as ctx:
+        ctx.set_data(Xh)
+        for k, start, extra, exclude in ((4, 0, 1, []), (7, 59, 10, []), (1, 5, 3, []), (60, 3, 0, []),
+                                         (5, 17, 37, [4, 99, 250, 699]), (3, 698, 10, [0])):
+            want = host(ctx, 700, k, start, extra, np.asarray(exclude, dtype="i8"))
+            got = ctx.furthest_sum(k, start, exclude, extra)
+            if k == 1 and extra > 0:
+                # the single point leaves, every candidate's running sum drops to exactly 0: a shared
+                # maximum by construction, the device says so
+                assert got is None
+            else:
+                assert got is not None and np.array_equal(got, want), (k, start, extra, exclude, got, want)
+            assert np.array_equal(aa._furthest_sum_on_device(ctx, 700, k, start, extra, np.asarray(exclude, dtype="i8")), want)
+    # duplicated rows: equal running sums -> the tie flag, and the dispatcher ends at the host's answer
+    Xd = np.vstack([X[:50], X[:50], X[50:80]])
+    Xdh = Xd.astype(np.float32) if dtype == "float32" else Xd
+    with _backend.Context(dtype=dtype) as ctx:
+        ctx.set_data(Xdh)
+        want = host(ctx, 130, 6, 2, 10, np.array([], dtype="i8"))
+        assert ctx.furthest_sum(6, 2, [], 10) is None
+        assert np.array_equal(aa._furthest_sum_on_device(ctx, 130, 6, 2, 10, np.array([], dtype="i8")), want)
+    # the kernel form: an explicit (n x n) kernel matrix on the device
+    K = X[:300].dot(X[:300].T)
+    Kh = K.astype(np.float32) if dtype == "float32" else K
+    with _backend.Context(dtype=dtype) as ctx:
+        ctx.set_data(Kh, form=_backend.FORM_KERNEL)
+        for k, start, extra, exclude in ((4, 0, 1, []), (9, 299, 10, [7, 8])):
+            want = host(ctx, 300, k, start, extra, np.asarray(exclude, dtype="i8"))
+            got = ctx.furthest_sum(k, start, exclude, extra)
+            assert got is not None and np.array_equal(got, want), (k, start, extra, exclude, got, want)
