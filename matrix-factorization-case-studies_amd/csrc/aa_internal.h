@@ -70,7 +70,10 @@ struct DevBuf {
         if (b == 0) b = 16;
         AA_CHECK_HIP(hipMalloc(&p, b));
         bytes = b;
-        AA_CHECK_HIP(hipMemset(p, 0, b));
+        // zero fill on the null stream, waited for: the contexts' streams are non-blocking (nothing
+        // they run is ordered against the null stream), and allocations are rare
+        AA_CHECK_HIP(hipMemsetAsync(p, 0, b, nullptr));
+        AA_CHECK_HIP(hipStreamSynchronize(nullptr));
         return AA_OK;
     }
     void release()
@@ -322,6 +325,31 @@ int launch_row_broadcast(Ctx *c, long j_local, bool own);
 int launch_proj_side(Ctx *c, const double *x, const double *g, double a_const, int a_slot, int mode,
                      const aa_spg_params *sp, int stage_after);   // launch_proj on the side stream / scratch set
 int join_side(Ctx *c);             // the main stream waits for a pending side-stream projection
+// Copies and fills ORDERED ON THE CONTEXT'S STREAM.  The streams of a context are created
+// hipStreamNonBlocking (round 4): the legacy null stream orders nothing for them any more, and a
+// null-stream hipMemcpy in one context is no longer a barrier across every context of the process
+// (worker threads of fit_restarts, stream capture).  ctx_memcpy: the side stream joined, the copy
+// enqueued on the main stream, the host waits for it (the semantics the synchronous hipMemcpy had
+// for this context).  ctx_memset: enqueued only -- whatever reads the buffer is enqueued behind it.
+inline hipError_t ctx_memcpy(Ctx *c, void *dst, const void *src, size_t nbytes, hipMemcpyKind kind)
+{
+    if (join_side(c) != AA_OK) return hipErrorUnknown;
+    hipError_t e = hipMemcpyAsync(dst, src, nbytes, kind, c->stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(c->stream);
+}
+inline hipError_t ctx_memcpy2d(Ctx *c, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width,
+                               size_t height, hipMemcpyKind kind)
+{
+    if (join_side(c) != AA_OK) return hipErrorUnknown;
+    hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, c->stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(c->stream);
+}
+inline hipError_t ctx_memset(Ctx *c, void *dst, int value, size_t nbytes)
+{
+    return hipMemsetAsync(dst, value, nbytes, c->stream);
+}
 bool side_available(const Ctx *c);  // side stream + second scratch set usable (single rank, fused stages)
 int side_begin(Ctx *c);            // launch_* calls go to the side stream (own scratch set) until side_end
 int side_end(Ctx *c);

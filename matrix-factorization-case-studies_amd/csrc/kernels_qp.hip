@@ -2153,7 +2153,7 @@ int g_qp_live_occ = 3;         // register budget of k_qp_quad beside the consum
 int g_qp_live_blocks = 48;     // CUs given to the consumers (one block of 16 waves each)
 #define QP_LIVE_LDS 163840     // a CU's LDS
 int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)
-int g_qp_prefetch_order = 1;   // four-lane QP: the sample order of the NEXT update (by this update's pass counts) is formed on the side stream right after this one, beside the Z'X pass (25 us off the critical path)
+int g_qp_prefetch_order = 0;   // four-lane QP, opt-in: the sample order of the NEXT update (by this update's pass counts) is formed on the side stream right after this one, beside the Z'X pass -- 25 us of kernels off the critical path, but the fork and the join cost two ~6 us bubbles on the main stream and the ordering kernels run 3 x slower beside the pass: 488-490 it/s with, 489-491 without (profiles/round4_ab.txt)
 int g_qp_wave_mem1 = 1;        // continuation launches of the wave-per-sample kernel: 1 = the memory-1 instantiation (no f_mem array: 311 fewer SGPR spills), 0 = the generic one (A/B)
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
 int g_qp_tail_cap = 96;        // with qp_overlap_tail: only samples beyond this many passes go to the side stream (0: all parked ones)
@@ -2784,7 +2784,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         stats->reserved = (int)h.n_overflow;
         if (g_qp_profile && row_mode && h.dbg_waves) {
             unsigned long long d5[5];
-            AA_CHECK_HIP(hipMemcpy(d5, base + 64, sizeof(d5), hipMemcpyDeviceToHost));
+            AA_CHECK_HIP(ctx_memcpy(c, d5, base + 64, sizeof(d5), hipMemcpyDeviceToHost));
             fprintf(stderr, "[qp_profile] row kernel waves: slowest %.0f kcycles (its trips %llu), mean %.0f kcycles; "
                     "most trips %llu (that wave: %.0f kcycles = %.0f cycles per trip)\n",
                     (double)(d5[1] >> 20) / 1e3, d5[1] & 0xfffffull, (double)d5[3] / h.dbg_waves / 1e3,
@@ -2799,7 +2799,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                     h.n_overflow);
         if (g_qp_profile && !row_mode) {
             QpDebug d;
-            AA_CHECK_HIP(hipMemcpy(&d, base + 64, sizeof(d), hipMemcpyDeviceToHost));
+            AA_CHECK_HIP(ctx_memcpy(c, &d, base + 64, sizeof(d), hipMemcpyDeviceToHost));
             if (d.waves)
                 fprintf(stderr, "[qp_profile] waves %llu trips/wave %.1f refills/wave %.1f cycles/wave %.0f "
                         "(projection part %.1f%%, mat-vec %.1f%%, step %.1f%%, residual+finish %.1f%%) cycles/trip %.0f\n",

@@ -99,7 +99,7 @@ static int upload_alpha(Ctx *c)
 {
     std::vector<double> a(c->KP, 0.0);
     for (int i = 0; i < c->k; ++i) a[i] = c->alpha[i];
-    AA_CHECK_HIP(hipMemcpy(c->alphaDev.p, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(ctx_memcpy(c, c->alphaDev.p, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice));
     return AA_OK;
 }
 
@@ -121,7 +121,7 @@ static int upload_tall(Ctx *c, DevBuf &dst, const double *src, long ld_row, long
     std::vector<double> tmp((size_t)c->n_pad * c->KP, 0.0);
     for (long r = 0; r < rows; ++r)
         for (int i = 0; i < cols; ++i) tmp[(size_t)r * c->KP + i] = src[r * ld_row + i * ld_col];
-    AA_CHECK_HIP(hipMemcpy(dst.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(ctx_memcpy(c, dst.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
     return AA_OK;
 }
 
@@ -129,7 +129,7 @@ static int download_tall(Ctx *c, const DevBuf &src, double *dst, long ld_row, lo
 {
     std::vector<double> tmp((size_t)c->n_pad * c->KP);
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-    AA_CHECK_HIP(hipMemcpy(tmp.data(), src.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(ctx_memcpy(c, tmp.data(), src.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (long r = 0; r < rows; ++r)
         for (int i = 0; i < cols; ++i) dst[r * ld_row + i * ld_col] = tmp[(size_t)r * c->KP + i];
     return AA_OK;
@@ -635,12 +635,15 @@ int aa_ctx_create(aa_ctx **out, int device, int dtype)
     aa_ctx *h = new aa_ctx();
     h->c.device = device;
     h->c.dtype = dtype;
-    hipError_t e = hipStreamCreate(&h->c.stream);
+    // non-blocking streams: no implicit synchronisation with the legacy null stream, i.e. with the
+    // other contexts of the process (every copy and fill of this library goes through a stream:
+    // ctx_memcpy / ctx_memset)
+    hipError_t e = hipStreamCreateWithFlags(&h->c.stream, hipStreamNonBlocking);
     if (e == hipSuccess) {
         int lo = 0, hi = 0;                       // numerically lower = higher priority
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        e = hipStreamCreateWithPriority(&h->c.stream2, hipStreamDefault, hi);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->c.stream3, hipStreamDefault, hi);
+        e = hipStreamCreateWithPriority(&h->c.stream2, hipStreamNonBlocking, hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->c.stream3, hipStreamNonBlocking, hi);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->c.evFork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->c.evJoin, hipEventDisableTiming);
@@ -747,7 +750,7 @@ int aa_set_data(aa_ctx *h, const void *X, int host_dtype, long n, long p, long l
     AA_CHECK(c->X.alloc((size_t)(c->n_pad + AA_SLACK_ROWS) * c->p_pad * es));
     const size_t hes = host_dtype == AA_F32 ? 4 : 8;
     if (host_dtype == c->dtype) {
-        AA_CHECK_HIP(hipMemcpy2D(c->X.p, (size_t)c->p_pad * es, X, (size_t)ld * hes, (size_t)p * es,
+        AA_CHECK_HIP(ctx_memcpy2d(c, c->X.p, (size_t)c->p_pad * es, X, (size_t)ld * hes, (size_t)p * es,
                                  (size_t)n, hipMemcpyHostToDevice));
     } else {
         const long chunk = 2048;
@@ -765,7 +768,7 @@ int aa_set_data(aa_ctx *h, const void *X, int host_dtype, long n, long p, long l
                 for (long r = 0; r < rows; ++r)
                     for (long q = 0; q < p; ++q) dst[r * p + q] = (double)src[(r0 + r) * ld + q];
             }
-            AA_CHECK_HIP(hipMemcpy2D(reinterpret_cast<unsigned char *>(c->X.p) + (size_t)r0 * c->p_pad * es,
+            AA_CHECK_HIP(ctx_memcpy2d(c, reinterpret_cast<unsigned char *>(c->X.p) + (size_t)r0 * c->p_pad * es,
                                      (size_t)c->p_pad * es, tmp.data(), (size_t)p * es, (size_t)p * es,
                                      (size_t)rows, hipMemcpyHostToDevice));
         }
@@ -830,10 +833,10 @@ int aa_set_data_weighted(aa_ctx *h, const void *raw, int host_dtype, long n_tota
     if (rc == AA_OK) rc = dflag.alloc((size_t)p_full);
     if (rc == AA_OK && col_weight) rc = dw.alloc((size_t)p_full * sizeof(double));
     if (rc != AA_OK) { draw.release(); dflag.release(); dw.release(); return rc; }
-    hipError_t e = hipMemcpy2D(draw.p, (size_t)p_full * hes, raw, (size_t)ld * hes, (size_t)p_full * hes,
+    hipError_t e = ctx_memcpy2d(c, draw.p, (size_t)p_full * hes, raw, (size_t)ld * hes, (size_t)p_full * hes,
                                (size_t)n_total, hipMemcpyHostToDevice);
     if (e == hipSuccess && col_weight)
-        e = hipMemcpy(dw.p, col_weight, (size_t)p_full * sizeof(double), hipMemcpyHostToDevice);
+        e = ctx_memcpy(c, dw.p, col_weight, (size_t)p_full * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         // the mask is taken on the weighted field (run_hadisst_aa.py:133,201)
         rc = launch_col_has_nan(c, draw.p, host_dtype, p_full, n_total, p_full,
@@ -841,7 +844,7 @@ int aa_set_data_weighted(aa_ctx *h, const void *raw, int host_dtype, long n_tota
         if (rc == AA_OK) e = hipStreamSynchronize(c->stream);
     }
     std::vector<unsigned char> flags((size_t)p_full);
-    if (rc == AA_OK && e == hipSuccess) e = hipMemcpy(flags.data(), dflag.p, (size_t)p_full, hipMemcpyDeviceToHost);
+    if (rc == AA_OK && e == hipSuccess) e = ctx_memcpy(c, flags.data(), dflag.p, (size_t)p_full, hipMemcpyDeviceToHost);
     std::vector<int> idx;
     if (rc == AA_OK && e == hipSuccess) {
         idx.reserve((size_t)p_full);
@@ -868,7 +871,7 @@ int aa_set_data_weighted(aa_ctx *h, const void *raw, int host_dtype, long n_tota
         c->X.release();
         rc = c->X.alloc((size_t)(c->n_pad + AA_SLACK_ROWS) * c->p_pad * esize(c));
         if (rc == AA_OK) rc = didx.alloc(idx.size() * sizeof(int));
-        if (rc == AA_OK) e = hipMemcpy(didx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (rc == AA_OK) e = ctx_memcpy(c, didx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice);
         if (rc == AA_OK && e == hipSuccess)
             rc = launch_gather_weight(c, draw.p, host_dtype, p_full, row0, n, didx.as<int>(), p,
                                       col_weight ? dw.as<double>() : (const double *)nullptr);
@@ -904,7 +907,7 @@ int aa_get_data(aa_ctx *h, double *out, long ld)
     hipError_t e = hipSuccess;
     if (rc == AA_OK) e = hipStreamSynchronize(c->stream);
     if (rc == AA_OK && e == hipSuccess)
-        e = hipMemcpy2D(out, (size_t)ld * sizeof(double), tmp.p, (size_t)c->p * sizeof(double),
+        e = ctx_memcpy2d(c, out, (size_t)ld * sizeof(double), tmp.p, (size_t)c->p * sizeof(double),
                         (size_t)c->p * sizeof(double), (size_t)c->n, hipMemcpyDeviceToHost);
     tmp.release();
     if (rc == AA_OK && e != hipSuccess) {
@@ -1020,7 +1023,7 @@ int aa_set_dictionary_inputs(aa_ctx *h, const double *KZ, const double *ZtZ, dou
         std::vector<double> pad((size_t)c->KP * c->KP, 0.0);
         for (int i = 0; i < c->k; ++i)
             for (int j = 0; j < c->k; ++j) pad[(size_t)i * c->KP + j] = ZtZ[(size_t)i * c->k + j];
-        AA_CHECK_HIP(hipMemcpy(dev_ZtZ(c), pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
+        AA_CHECK_HIP(ctx_memcpy(c, dev_ZtZ(c), pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     c->host_grams_valid = false;
     c->trace = trace;
@@ -1189,7 +1192,7 @@ int aa_iterate(aa_ctx *h, const aa_iter_params *ip, const aa_spg_params *spg, co
         if (hs.stop) break;
     }
     const int last = hs.stop ? hs.stop_iter : n_max - 1;
-    AA_CHECK_HIP(hipMemcpy(costs, cd, (size_t)2 * (last + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(ctx_memcpy(c, costs, cd, (size_t)2 * (last + 1) * sizeof(double), hipMemcpyDeviceToHost));
     stats->n_iter = last;
     stats->converged = hs.converged;
     stats->error_stage = hs.error_stage;
@@ -1200,15 +1203,15 @@ int aa_iterate(aa_ctx *h, const aa_iter_params *ip, const aa_spg_params *spg, co
     const bool restore = hs.stop && hs.stop_iter < done - 1 && !hs.error_stage;
     if (scale) {                                 /* the host copy of alpha follows the device's */
         std::vector<double> a(c->KP, 1.0);
-        AA_CHECK_HIP(hipMemcpy(a.data(), restore ? c->snapAlpha.p : c->alphaDev.p, (size_t)c->KP * sizeof(double),
+        AA_CHECK_HIP(ctx_memcpy(c, a.data(), restore ? c->snapAlpha.p : c->alphaDev.p, (size_t)c->KP * sizeof(double),
                                hipMemcpyDeviceToHost));
         for (int i = 0; i < c->k; ++i) c->alpha[i] = a[i];
     }
     if (hs.stop && hs.stop_iter < done - 1 && !hs.error_stage) {
         // iterations behind the stopping one have run: restore its factors and rebuild the
         // products from them (four passes over the data, once per fit)
-        AA_CHECK_HIP(hipMemcpy(c->Ct.p, c->snapC.p, tall_bytes, hipMemcpyDeviceToDevice));
-        AA_CHECK_HIP(hipMemcpy(c->Zt.p, c->snapZ.p, tall_bytes, hipMemcpyDeviceToDevice));
+        AA_CHECK_HIP(ctx_memcpy(c, c->Ct.p, c->snapC.p, tall_bytes, hipMemcpyDeviceToDevice));
+        AA_CHECK_HIP(ctx_memcpy(c, c->Zt.p, c->snapZ.p, tall_bytes, hipMemcpyDeviceToDevice));
         c->products_valid = false;
         c->grams_valid = false;
         c->qp_iters_valid = false;
@@ -1238,7 +1241,7 @@ int aa_get_archetypes(aa_ctx *h, double *CX, long ld)
     AA_REQUIRE(c->grams_valid && c->form == AA_FORM_DATA, AA_ERR_STATE, "no C X available");
     AA_CHECK_HIP(hipSetDevice(c->device));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-    AA_CHECK_HIP(hipMemcpy2D(CX, (size_t)ld * sizeof(double), c->P.p, (size_t)c->p_pad * sizeof(double),
+    AA_CHECK_HIP(ctx_memcpy2d(c, CX, (size_t)ld * sizeof(double), c->P.p, (size_t)c->p_pad * sizeof(double),
                              (size_t)c->p * sizeof(double), (size_t)c->k, hipMemcpyDeviceToHost));
     return AA_OK;
 }
@@ -1305,7 +1308,7 @@ int aa_gpnh_set_factors(aa_ctx *h, int k, const double *Wt, long ld, const doubl
         std::vector<double> tmp((size_t)c->KP * c->p_pad, 0.0);
         for (int i = 0; i < k; ++i)
             for (long q = 0; q < c->p; ++q) tmp[(size_t)i * c->p_pad + q] = Wt[(size_t)i * ld + q];
-        AA_CHECK_HIP(hipMemcpy(c->P.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+        AA_CHECK_HIP(ctx_memcpy(c, c->P.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
         AA_CHECK(launch_wide_to_T(c, c->P.as<double>(), operandT(c, c->P, c->Pw)));
         AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));   // XW
         c->gpnh_valid = true;
@@ -1335,7 +1338,7 @@ int aa_gpnh_reduce(aa_ctx *h, double *ZtX, long ld, double *ZtZ, double *trace_W
     if (ZtX) {
         AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), nullptr));
         AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-        AA_CHECK_HIP(hipMemcpy2D(ZtX, (size_t)ld * sizeof(double), c->ZtX.p, (size_t)c->p_pad * sizeof(double),
+        AA_CHECK_HIP(ctx_memcpy2d(c, ZtX, (size_t)ld * sizeof(double), c->ZtX.p, (size_t)c->p_pad * sizeof(double),
                                  (size_t)c->p * sizeof(double), (size_t)c->k, hipMemcpyDeviceToHost));
     }
     if (ZtZ) {
@@ -1372,7 +1375,7 @@ int aa_gpnh_get_dictionary(aa_ctx *h, double *Wt, long ld)
     AA_REQUIRE(ld >= c->p, AA_ERR_ARG, "ld < p");
     AA_CHECK_HIP(hipSetDevice(c->device));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-    AA_CHECK_HIP(hipMemcpy2D(Wt, (size_t)ld * sizeof(double), c->P.p, (size_t)c->p_pad * sizeof(double),
+    AA_CHECK_HIP(ctx_memcpy2d(c, Wt, (size_t)ld * sizeof(double), c->P.p, (size_t)c->p_pad * sizeof(double),
                              (size_t)c->p * sizeof(double), (size_t)c->k, hipMemcpyDeviceToHost));
     return AA_OK;
 }
@@ -1479,7 +1482,7 @@ int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp,
         return AA_OK;
     }
     const int last = hs.stop ? hs.stop_iter : n_max - 1;
-    AA_CHECK_HIP(hipMemcpy(costs, cd, (size_t)2 * (last + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(ctx_memcpy(c, costs, cd, (size_t)2 * (last + 1) * sizeof(double), hipMemcpyDeviceToHost));
     stats->n_iter = last;
     stats->converged = hs.converged;
     stats->error_stage = hs.error_stage;
@@ -1487,8 +1490,8 @@ int aa_gpnh_iterate(aa_ctx *h, const aa_gpnh_params *gp, const aa_qp_params *qp,
     stats->cost = costs[2 * last + 1];
     if (hs.stop && hs.stop_iter < done - 1 && !hs.error_stage) {
         // iterations behind the stopping one have run: restore its factors, rebuild X W
-        AA_CHECK_HIP(hipMemcpy(c->Zt.p, c->snapZ.p, (size_t)c->n_pad * KP * sizeof(double), hipMemcpyDeviceToDevice));
-        AA_CHECK_HIP(hipMemcpy(c->P.p, c->snapC.p, (size_t)KP * c->p_pad * sizeof(double), hipMemcpyDeviceToDevice));
+        AA_CHECK_HIP(ctx_memcpy(c, c->Zt.p, c->snapZ.p, (size_t)c->n_pad * KP * sizeof(double), hipMemcpyDeviceToDevice));
+        AA_CHECK_HIP(ctx_memcpy(c, c->P.p, c->snapC.p, (size_t)KP * c->p_pad * sizeof(double), hipMemcpyDeviceToDevice));
         AA_CHECK(launch_wide_to_T(c, c->P.as<double>(), operandT(c, c->P, c->Pw)));
         AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));
         c->qp_iters_valid = false;
@@ -1551,17 +1554,17 @@ int aa_slots_begin(aa_ctx *h, int R, int k, const aa_iter_params *ip, const aa_s
     AA_CHECK(c->snapC.alloc(tall_bytes));
     AA_CHECK(c->snapZ.alloc(tall_bytes));
     AA_CHECK(c->slotSnapP.alloc((size_t)c->KP * c->p_pad * sizeof(double)));
-    AA_CHECK_HIP(hipMemset(c->snapC.p, 0, tall_bytes));
-    AA_CHECK_HIP(hipMemset(c->snapZ.p, 0, tall_bytes));
+    AA_CHECK_HIP(ctx_memset(c, c->snapC.p, 0, tall_bytes));
+    AA_CHECK_HIP(ctx_memset(c, c->snapZ.p, 0, tall_bytes));
     std::vector<IterState> st(32);
     memset(st.data(), 0, st.size() * sizeof(IterState));
     for (int r = 0; r < 32; ++r) st[r].stop = 1;      // empty
-    AA_CHECK_HIP(hipMemcpy(c->slotStates.p, st.data(), st.size() * sizeof(IterState), hipMemcpyHostToDevice));
-    AA_CHECK_HIP(hipMemset(c->slotCounters.p, 0, 64 * sizeof(int)));
-    AA_CHECK_HIP(hipMemset(c->Ct.p, 0, tall_bytes));
-    AA_CHECK_HIP(hipMemset(c->Zt.p, 0, tall_bytes));
-    AA_CHECK_HIP(hipMemset(c->Mdev.p, 0, (size_t)c->KP * c->KP * sizeof(double)));
-    AA_CHECK_HIP(hipMemset(c->gramOut.p, 0, (size_t)4 * c->KP * c->KP * sizeof(double)));
+    AA_CHECK_HIP(ctx_memcpy(c, c->slotStates.p, st.data(), st.size() * sizeof(IterState), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(ctx_memset(c, c->slotCounters.p, 0, 64 * sizeof(int)));
+    AA_CHECK_HIP(ctx_memset(c, c->Ct.p, 0, tall_bytes));
+    AA_CHECK_HIP(ctx_memset(c, c->Zt.p, 0, tall_bytes));
+    AA_CHECK_HIP(ctx_memset(c, c->Mdev.p, 0, (size_t)c->KP * c->KP * sizeof(double)));
+    AA_CHECK_HIP(ctx_memset(c, c->gramOut.p, 0, (size_t)4 * c->KP * c->KP * sizeof(double)));
     c->slots_aa = true;
     c->have_state = true;
     c->grams_valid = false;
@@ -1586,7 +1589,7 @@ static int slots_set_alpha(Ctx *c, int r, const double *alpha, bool running)
     // the host copy follows the device's (the scale-factor kernel moves the running slots' factors)
     if (running) {
         std::vector<double> a(c->KP, 1.0);
-        AA_CHECK_HIP(hipMemcpy(a.data(), c->alphaDev.p, (size_t)c->KP * sizeof(double), hipMemcpyDeviceToHost));
+        AA_CHECK_HIP(ctx_memcpy(c, a.data(), c->alphaDev.p, (size_t)c->KP * sizeof(double), hipMemcpyDeviceToHost));
         for (int i = 0; i < c->k; ++i) c->alpha[i] = a[i];
     }
     for (int i = 0; i < c->slots_k; ++i) c->alpha[r * c->slots_k + i] = alpha ? alpha[i] : 1.0;
@@ -1606,14 +1609,14 @@ int aa_slots_load(aa_ctx *h, int r, const double *C, long ldc, const double *Z, 
     std::vector<double> ct((size_t)c->n * k);
     for (long row = 0; row < c->n; ++row)
         for (int i = 0; i < k; ++i) ct[(size_t)row * k + i] = C[(size_t)i * ldc + row];
-    AA_CHECK_HIP(hipMemcpy2D(c->Ct.as<double>() + o, (size_t)c->KP * sizeof(double), ct.data(), (size_t)k * sizeof(double),
+    AA_CHECK_HIP(ctx_memcpy2d(c, c->Ct.as<double>() + o, (size_t)c->KP * sizeof(double), ct.data(), (size_t)k * sizeof(double),
                              (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyHostToDevice));
-    AA_CHECK_HIP(hipMemcpy2D(c->Zt.as<double>() + o, (size_t)c->KP * sizeof(double), Z, (size_t)k * sizeof(double),
+    AA_CHECK_HIP(ctx_memcpy2d(c, c->Zt.as<double>() + o, (size_t)c->KP * sizeof(double), Z, (size_t)k * sizeof(double),
                              (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyHostToDevice));
     IterState zero;
     memset(&zero, 0, sizeof(zero));
-    AA_CHECK_HIP(hipMemcpy(c->slotStates.as<IterState>() + r, &zero, sizeof(zero), hipMemcpyHostToDevice));
-    AA_CHECK_HIP(hipMemset(c->slotCounters.as<int>() + r, 0, sizeof(int)));
+    AA_CHECK_HIP(ctx_memcpy(c, c->slotStates.as<IterState>() + r, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(ctx_memset(c, c->slotCounters.as<int>() + r, 0, sizeof(int)));
     AA_CHECK(slots_set_alpha(c, r, alpha, false));
     c->products_valid = false;
     c->grams_valid = false;
@@ -1637,14 +1640,14 @@ int aa_slots_reload(aa_ctx *h, int r, const double *C, long ldc, const double *Z
     std::vector<double> ct((size_t)c->n * k);
     for (long row = 0; row < c->n; ++row)
         for (int i = 0; i < k; ++i) ct[(size_t)row * k + i] = C[(size_t)i * ldc + row];
-    AA_CHECK_HIP(hipMemcpy2D(c->Ct.as<double>() + o, (size_t)KP * sizeof(double), ct.data(), (size_t)k * sizeof(double),
+    AA_CHECK_HIP(ctx_memcpy2d(c, c->Ct.as<double>() + o, (size_t)KP * sizeof(double), ct.data(), (size_t)k * sizeof(double),
                              (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyHostToDevice));
-    AA_CHECK_HIP(hipMemcpy2D(c->Zt.as<double>() + o, (size_t)KP * sizeof(double), Z, (size_t)k * sizeof(double),
+    AA_CHECK_HIP(ctx_memcpy2d(c, c->Zt.as<double>() + o, (size_t)KP * sizeof(double), Z, (size_t)k * sizeof(double),
                              (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyHostToDevice));
     IterState zero;
     memset(&zero, 0, sizeof(zero));
-    AA_CHECK_HIP(hipMemcpy(c->slotStates.as<IterState>() + r, &zero, sizeof(zero), hipMemcpyHostToDevice));
-    AA_CHECK_HIP(hipMemset(c->slotCounters.as<int>() + r, 0, sizeof(int)));
+    AA_CHECK_HIP(ctx_memcpy(c, c->slotStates.as<IterState>() + r, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(ctx_memset(c, c->slotCounters.as<int>() + r, 0, sizeof(int)));
     AA_CHECK(slots_set_alpha(c, r, alpha, true));
     // a fit starts its projections cold (aa_set_state): a warm threshold of +inf selects nothing, which
     // is the cold start of k_proj_small -- for this slot's columns, in both projection states
@@ -1655,7 +1658,7 @@ int aa_slots_reload(aa_ctx *h, int r, const double *C, long ldc, const double *Z
             if (!b->p) continue;
             ProjState *ps = b->as<ProjState>();
             for (int m = 1; m < 4; ++m)
-                AA_CHECK_HIP(hipMemcpy(&ps->warm[m][o], inf.data(), (size_t)k * sizeof(double), hipMemcpyHostToDevice));
+                AA_CHECK_HIP(ctx_memcpy(c, &ps->warm[m][o], inf.data(), (size_t)k * sizeof(double), hipMemcpyHostToDevice));
         }
     }
     // products: aa_prepare's passes on the stacked state; what the RUNNING slots carry (C X, (C X X')',
@@ -1664,10 +1667,10 @@ int aa_slots_reload(aa_ctx *h, int r, const double *C, long ldc, const double *Z
     const size_t GS = (size_t)KP * KP;
     AA_CHECK(c->slotSaveP.alloc(wide));
     AA_CHECK(c->slotSaveGr.alloc(tall + GS * sizeof(double)));
-    AA_CHECK_HIP(hipMemcpy(c->slotSaveP.p, c->P.p, wide, hipMemcpyDeviceToDevice));
-    AA_CHECK_HIP(hipMemcpy(c->slotSaveGr.p, c->Gr.p, tall, hipMemcpyDeviceToDevice));
+    AA_CHECK_HIP(ctx_memcpy(c, c->slotSaveP.p, c->P.p, wide, hipMemcpyDeviceToDevice));
+    AA_CHECK_HIP(ctx_memcpy(c, c->slotSaveGr.p, c->Gr.p, tall, hipMemcpyDeviceToDevice));
     double *saveCKCt = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(c->slotSaveGr.p) + tall);
-    AA_CHECK_HIP(hipMemcpy(saveCKCt, dev_CKCt(c), GS * sizeof(double), hipMemcpyDeviceToDevice));
+    AA_CHECK_HIP(ctx_memcpy(c, saveCKCt, dev_CKCt(c), GS * sizeof(double), hipMemcpyDeviceToDevice));
     c->products_valid = false;
     c->grams_valid = false;
     AA_CHECK(prepare(c, nullptr));
@@ -1676,12 +1679,12 @@ int aa_slots_reload(aa_ctx *h, int r, const double *C, long ldc, const double *Z
     for (int q = 0; q < c->slots_R; ++q) {
         if ((loaded >> q) & 1u) continue;                 // freshly loaded slots keep what prepare computed
         const int oq = q * k;
-        AA_CHECK_HIP(hipMemcpy(c->P.as<double>() + (size_t)oq * c->p_pad, c->slotSaveP.as<double>() + (size_t)oq * c->p_pad,
+        AA_CHECK_HIP(ctx_memcpy(c, c->P.as<double>() + (size_t)oq * c->p_pad, c->slotSaveP.as<double>() + (size_t)oq * c->p_pad,
                                (size_t)k * c->p_pad * sizeof(double), hipMemcpyDeviceToDevice));
-        AA_CHECK_HIP(hipMemcpy2D(c->Gr.as<double>() + oq, (size_t)KP * sizeof(double),
+        AA_CHECK_HIP(ctx_memcpy2d(c, c->Gr.as<double>() + oq, (size_t)KP * sizeof(double),
                                  c->slotSaveGr.as<double>() + oq, (size_t)KP * sizeof(double),
                                  (size_t)k * sizeof(double), (size_t)c->n_pad, hipMemcpyDeviceToDevice));
-        AA_CHECK_HIP(hipMemcpy2D(dev_CKCt(c) + (size_t)oq * KP + oq, (size_t)KP * sizeof(double),
+        AA_CHECK_HIP(ctx_memcpy2d(c, dev_CKCt(c) + (size_t)oq * KP + oq, (size_t)KP * sizeof(double),
                                  saveCKCt + (size_t)oq * KP + oq, (size_t)KP * sizeof(double),
                                  (size_t)k * sizeof(double), (size_t)k, hipMemcpyDeviceToDevice));
     }
@@ -1694,12 +1697,12 @@ int aa_slots_reload(aa_ctx *h, int r, const double *C, long ldc, const double *Z
     // initial cost of the new slot only (launch_aa_cost_slots takes all slots: the others' cost0 is
     // rewritten with the same bits -- their Gram blocks are what they were)
     std::vector<double> c0(32);
-    AA_CHECK_HIP(hipMemcpy(c0.data(), c->slotCost0.p, 32 * sizeof(double), hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(ctx_memcpy(c, c0.data(), c->slotCost0.p, 32 * sizeof(double), hipMemcpyDeviceToHost));
     AA_CHECK(launch_aa_cost_slots(c, 0, nullptr));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
     for (int q = 0; q < c->slots_R; ++q)
         if (q != r)
-            AA_CHECK_HIP(hipMemcpy(c->slotCost0.as<double>() + q, &c0[q], sizeof(double), hipMemcpyHostToDevice));
+            AA_CHECK_HIP(ctx_memcpy(c, c->slotCost0.as<double>() + q, &c0[q], sizeof(double), hipMemcpyHostToDevice));
     return AA_OK;
 }
 
@@ -1770,8 +1773,8 @@ int aa_slots_finish(aa_ctx *h)
     AA_CHECK(join_side(c));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
     const size_t tall_bytes = (size_t)c->n_pad * c->KP * sizeof(double);
-    AA_CHECK_HIP(hipMemcpy(c->Ct.p, c->snapC.p, tall_bytes, hipMemcpyDeviceToDevice));
-    AA_CHECK_HIP(hipMemcpy(c->Zt.p, c->snapZ.p, tall_bytes, hipMemcpyDeviceToDevice));
+    AA_CHECK_HIP(ctx_memcpy(c, c->Ct.p, c->snapC.p, tall_bytes, hipMemcpyDeviceToDevice));
+    AA_CHECK_HIP(ctx_memcpy(c, c->Zt.p, c->snapZ.p, tall_bytes, hipMemcpyDeviceToDevice));
     c->products_valid = false;
     c->grams_valid = false;
     AA_CHECK(prepare(c, nullptr));
@@ -1793,31 +1796,31 @@ int aa_slots_fetch(aa_ctx *h, int r, double *C, long ldc, double *Z, double *CX,
     AA_CHECK(join_side(c));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
     IterState st;
-    AA_CHECK_HIP(hipMemcpy(&st, c->slotStates.as<IterState>() + r, sizeof(st), hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(ctx_memcpy(c, &st, c->slotStates.as<IterState>() + r, sizeof(st), hipMemcpyDeviceToHost));
     AA_REQUIRE(st.stop, AA_ERR_STATE, "slot %d has not stopped", r);
     const int k = c->slots_k, o = r * k;
     std::vector<double> ct((size_t)c->n * k);
-    AA_CHECK_HIP(hipMemcpy2D(ct.data(), (size_t)k * sizeof(double), c->snapC.as<double>() + o, (size_t)c->KP * sizeof(double),
+    AA_CHECK_HIP(ctx_memcpy2d(c, ct.data(), (size_t)k * sizeof(double), c->snapC.as<double>() + o, (size_t)c->KP * sizeof(double),
                              (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyDeviceToHost));
     for (long row = 0; row < c->n; ++row)
         for (int i = 0; i < k; ++i) C[(size_t)i * ldc + row] = ct[(size_t)row * k + i];
-    AA_CHECK_HIP(hipMemcpy2D(Z, (size_t)k * sizeof(double), c->snapZ.as<double>() + o, (size_t)c->KP * sizeof(double),
+    AA_CHECK_HIP(ctx_memcpy2d(c, Z, (size_t)k * sizeof(double), c->snapZ.as<double>() + o, (size_t)c->KP * sizeof(double),
                              (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyDeviceToHost));
-    AA_CHECK_HIP(hipMemcpy(costs, c->slotCosts.as<double>() + (size_t)r * c->slots_stride,
+    AA_CHECK_HIP(ctx_memcpy(c, costs, c->slotCosts.as<double>() + (size_t)r * c->slots_stride,
                            (size_t)2 * (st.stop_iter + 1) * sizeof(double), hipMemcpyDeviceToHost));
-    AA_CHECK_HIP(hipMemcpy(cost0, c->slotCost0.as<double>() + r, sizeof(double), hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(ctx_memcpy(c, cost0, c->slotCost0.as<double>() + r, sizeof(double), hipMemcpyDeviceToHost));
     if (alpha)                                                // the scale factors of the stopping iteration
-        AA_CHECK_HIP(hipMemcpy(alpha, c->snapAlpha.as<double>() + o, (size_t)k * sizeof(double), hipMemcpyDeviceToHost));
+        AA_CHECK_HIP(ctx_memcpy(c, alpha, c->snapAlpha.as<double>() + o, (size_t)k * sizeof(double), hipMemcpyDeviceToHost));
     AA_REQUIRE(ldx >= c->p, AA_ERR_ARG, "ldx < p");
     if (!carried) {
         // C X recomputed from the stopping iteration's dictionary: the pass aa_prepare runs (on the
         // scratch arrays of the dictionary update, free between iterations)
-        AA_CHECK_HIP(hipMemcpy(c->Dt.p, c->snapC.p, (size_t)c->n_pad * c->KP * sizeof(double), hipMemcpyDeviceToDevice));
+        AA_CHECK_HIP(ctx_memcpy(c, c->Dt.p, c->snapC.p, (size_t)c->n_pad * c->KP * sizeof(double), hipMemcpyDeviceToDevice));
         AA_CHECK(launch_reduce_rows(c, c->Dt.as<double>(), c->Q.as<double>(), nullptr));
         AA_CHECK_HIP(hipStreamSynchronize(c->stream));
     }
     const double *src = (carried ? c->slotSnapP.as<double>() : c->Q.as<double>()) + (size_t)o * c->p_pad;
-    AA_CHECK_HIP(hipMemcpy2D(CX, (size_t)ldx * sizeof(double), src, (size_t)c->p_pad * sizeof(double),
+    AA_CHECK_HIP(ctx_memcpy2d(c, CX, (size_t)ldx * sizeof(double), src, (size_t)c->p_pad * sizeof(double),
                              (size_t)c->p * sizeof(double), (size_t)k, hipMemcpyDeviceToHost));
     return AA_OK;
 }
@@ -1889,11 +1892,11 @@ int aa_gpnh_slots_begin(aa_ctx *h, int R, int k, const aa_gpnh_params *gp, const
     std::vector<IterState> st(32);
     memset(st.data(), 0, st.size() * sizeof(IterState));
     for (int r = 0; r < 32; ++r) st[r].stop = 1;      // empty: the judge leaves it alone
-    AA_CHECK_HIP(hipMemcpy(c->slotStates.p, st.data(), st.size() * sizeof(IterState), hipMemcpyHostToDevice));
-    AA_CHECK_HIP(hipMemset(c->slotCounters.p, 0, 64 * sizeof(int)));
-    AA_CHECK_HIP(hipMemset(c->Zt.p, 0, (size_t)c->n_pad * c->KP * sizeof(double)));
-    AA_CHECK_HIP(hipMemset(c->P.p, 0, (size_t)c->KP * c->p_pad * sizeof(double)));
-    AA_CHECK_HIP(hipMemset(c->gramState.p, 0, (size_t)3 * c->KP * c->KP * sizeof(double)));
+    AA_CHECK_HIP(ctx_memcpy(c, c->slotStates.p, st.data(), st.size() * sizeof(IterState), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(ctx_memset(c, c->slotCounters.p, 0, 64 * sizeof(int)));
+    AA_CHECK_HIP(ctx_memset(c, c->Zt.p, 0, (size_t)c->n_pad * c->KP * sizeof(double)));
+    AA_CHECK_HIP(ctx_memset(c, c->P.p, 0, (size_t)c->KP * c->p_pad * sizeof(double)));
+    AA_CHECK_HIP(ctx_memset(c, c->gramState.p, 0, (size_t)3 * c->KP * c->KP * sizeof(double)));
     c->gpnh_valid = true;
     c->have_state = true;
     c->grams_valid = false;
@@ -1912,15 +1915,15 @@ int aa_gpnh_slots_load(aa_ctx *h, int r, const double *Wt, long ld, const double
     AA_REQUIRE(ld >= c->p, AA_ERR_ARG, "ld < p");
     const int k = c->slots_k, o = r * k;
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-    AA_CHECK_HIP(hipMemcpy2D(c->P.as<double>() + (size_t)o * c->p_pad, (size_t)c->p_pad * sizeof(double), Wt,
+    AA_CHECK_HIP(ctx_memcpy2d(c, c->P.as<double>() + (size_t)o * c->p_pad, (size_t)c->p_pad * sizeof(double), Wt,
                              (size_t)ld * sizeof(double), (size_t)c->p * sizeof(double), (size_t)k,
                              hipMemcpyHostToDevice));
-    AA_CHECK_HIP(hipMemcpy2D(c->Zt.as<double>() + o, (size_t)c->KP * sizeof(double), Z, (size_t)k * sizeof(double),
+    AA_CHECK_HIP(ctx_memcpy2d(c, c->Zt.as<double>() + o, (size_t)c->KP * sizeof(double), Z, (size_t)k * sizeof(double),
                              (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyHostToDevice));
     IterState zero;
     memset(&zero, 0, sizeof(zero));
-    AA_CHECK_HIP(hipMemcpy(c->slotStates.as<IterState>() + r, &zero, sizeof(zero), hipMemcpyHostToDevice));
-    AA_CHECK_HIP(hipMemset(c->slotCounters.as<int>() + r, 0, sizeof(int)));
+    AA_CHECK_HIP(ctx_memcpy(c, c->slotStates.as<IterState>() + r, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(ctx_memset(c, c->slotCounters.as<int>() + r, 0, sizeof(int)));
     // the products of the stacked factors (the other slots' parts come out as they were) and this
     // slot's initial cost, the way aa_gpnh_iterate forms it
     AA_CHECK(launch_wide_to_T(c, c->P.as<double>(), operandT(c, c->P, c->Pw)));
@@ -1985,18 +1988,18 @@ int aa_gpnh_slots_fetch(aa_ctx *h, int r, double *Wt, long ld, double *Z, double
     AA_REQUIRE(ld >= c->p, AA_ERR_ARG, "ld < p");
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
     IterState st;
-    AA_CHECK_HIP(hipMemcpy(&st, c->slotStates.as<IterState>() + r, sizeof(st), hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(ctx_memcpy(c, &st, c->slotStates.as<IterState>() + r, sizeof(st), hipMemcpyDeviceToHost));
     AA_REQUIRE(st.stop, AA_ERR_STATE, "slot %d has not stopped", r);
     const int k = c->slots_k, o = r * k;
     // the factors of the stopping iteration (k_gpnh_snap_slots)
-    AA_CHECK_HIP(hipMemcpy2D(Wt, (size_t)ld * sizeof(double), c->snapC.as<double>() + (size_t)o * c->p_pad,
+    AA_CHECK_HIP(ctx_memcpy2d(c, Wt, (size_t)ld * sizeof(double), c->snapC.as<double>() + (size_t)o * c->p_pad,
                              (size_t)c->p_pad * sizeof(double), (size_t)c->p * sizeof(double), (size_t)k,
                              hipMemcpyDeviceToHost));
-    AA_CHECK_HIP(hipMemcpy2D(Z, (size_t)k * sizeof(double), c->snapZ.as<double>() + o, (size_t)c->KP * sizeof(double),
+    AA_CHECK_HIP(ctx_memcpy2d(c, Z, (size_t)k * sizeof(double), c->snapZ.as<double>() + o, (size_t)c->KP * sizeof(double),
                              (size_t)k * sizeof(double), (size_t)c->n, hipMemcpyDeviceToHost));
-    AA_CHECK_HIP(hipMemcpy(costs, c->slotCosts.as<double>() + (size_t)r * c->slots_stride,
+    AA_CHECK_HIP(ctx_memcpy(c, costs, c->slotCosts.as<double>() + (size_t)r * c->slots_stride,
                            (size_t)2 * (st.stop_iter + 1) * sizeof(double), hipMemcpyDeviceToHost));
-    AA_CHECK_HIP(hipMemcpy(cost0, c->slotCost0.as<double>() + r, sizeof(double), hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(ctx_memcpy(c, cost0, c->slotCost0.as<double>() + r, sizeof(double), hipMemcpyDeviceToHost));
     return AA_OK;
 }
 
@@ -2026,6 +2029,7 @@ int aa_simplex_project_rows(int device, const double *in, double *out, long rows
     AA_CHECK(a.alloc(bytes));
     int rc = b.alloc(bytes);
     if (rc == AA_OK) {
+        // (everything of this stateless entry point runs on the null stream, waited for by the host)
         hipError_t e = hipMemcpy(a.p, in, bytes, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             rc = launch_simplex_rows_generic(nullptr, a.as<double>(), b.as<double>(), rows, cols);
@@ -2070,8 +2074,8 @@ int aa_quad_simplex_spg_batch(int device, const double *A, const double *B, long
     if (rc == AA_OK) rc = dZ.alloc((size_t)n * k * sizeof(double));
     if (rc == AA_OK) rc = dI.alloc((size_t)n * sizeof(int));
     if (rc == AA_OK) {
-        hipError_t e = hipMemcpy(dB.p, B, extent * sizeof(double), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dZ.p, Z0, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice);
+        hipError_t e = ctx_memcpy(c, dB.p, B, extent * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = ctx_memcpy(c, dZ.p, Z0, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             set_error("qp batch upload: %s", hipGetErrorString(e));
             rc = AA_ERR_HIP;
@@ -2083,8 +2087,8 @@ int aa_quad_simplex_spg_batch(int device, const double *A, const double *B, long
                        dI.as<int>(), g_qp_profile ? &prof_stats : (aa_qp_stats *)nullptr);
     if (rc == AA_OK) {
         hipError_t e = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess) e = hipMemcpy(Zout, dZ.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && iters) e = hipMemcpy(iters, dI.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = ctx_memcpy(c, Zout, dZ.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && iters) e = ctx_memcpy(c, iters, dI.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
         if (e != hipSuccess) {
             set_error("qp batch: %s", hipGetErrorString(e));
             rc = AA_ERR_HIP;
@@ -2105,7 +2109,7 @@ int aa_get_spg_scalars(aa_ctx *h, double *out)
     static_assert(AA_SPG_SCALARS == SC_FMEM0, "include/aa_hip.h documents the ScalarSlot layout");
     AA_CHECK_HIP(hipSetDevice(c->device));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-    AA_CHECK_HIP(hipMemcpy(out, c->scalars.p, AA_SPG_SCALARS * sizeof(double), hipMemcpyDeviceToHost));
+    AA_CHECK_HIP(ctx_memcpy(c, out, c->scalars.p, AA_SPG_SCALARS * sizeof(double), hipMemcpyDeviceToHost));
     return AA_OK;
 }
 
@@ -2133,7 +2137,7 @@ int aa_pass_reduce_rows(aa_ctx *h, int k, const double *A, double *out, long ldo
     AA_CHECK(upload_tall(c, c->Dt, A, k, 1, c->n, k));
     AA_CHECK(launch_reduce_rows(c, c->Dt.as<double>(), c->Q.as<double>(), nullptr));
     AA_CHECK_HIP(hipStreamSynchronize(c->stream));
-    AA_CHECK_HIP(hipMemcpy2D(out, (size_t)ldo * sizeof(double), c->Q.p, (size_t)c->p_pad * sizeof(double),
+    AA_CHECK_HIP(ctx_memcpy2d(c, out, (size_t)ldo * sizeof(double), c->Q.p, (size_t)c->p_pad * sizeof(double),
                              (size_t)c->p * sizeof(double), (size_t)k, hipMemcpyDeviceToHost));
     return AA_OK;
 }
@@ -2149,7 +2153,7 @@ int aa_pass_row_local(aa_ctx *h, int k, const double *B, long ldb, double *out)
     std::vector<double> tmp((size_t)c->KP * c->p_pad, 0.0);
     for (int i = 0; i < k; ++i)
         for (long q = 0; q < c->p; ++q) tmp[(size_t)i * c->p_pad + q] = B[(size_t)i * ldb + q];
-    AA_CHECK_HIP(hipMemcpy(c->P.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    AA_CHECK_HIP(ctx_memcpy(c, c->P.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
     AA_CHECK(launch_wide_to_T(c, c->P.as<double>(), operandT(c, c->P, c->Pw)));
     AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gn.as<double>()));
     return download_tall(c, c->Gn, out, k, 1, c->n, k);
