@@ -908,7 +908,7 @@ __device__ __forceinline__ void dma16(const float *src, float *lds_uniform)
 template <int R, bool NT>
 __global__ __launch_bounds__(1024) void k_row_local_f32_dma(const float *__restrict__ X, long ldx,
                                                             const float *__restrict__ B, int p_pad,
-                                                            double *__restrict__ out, long n_pad, int W)
+                                                            double *__restrict__ out, long n_pad, int W, int prio)
 {
     constexpr int KP = 32, SB = 64, TC = 32;
     static_assert(R >= 8 && R <= 12, "ring of 8..12 pieces");
@@ -985,8 +985,12 @@ __global__ __launch_bounds__(1024) void k_row_local_f32_dma(const float *__restr
             for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[m], acc, 0, 0, 0);
         }
         // the four slots of this tile are free again (their reads were waited for before the MFMAs)
+        // prio: the wave that is about to put 4 KB in flight goes ahead of the waves that have
+        // matrix instructions and float64 sums to issue (experiment, aa_set_option row_local_prio)
+        if (prio) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int i = 0; i < 4; ++i) issue_piece();
+        if (prio) __builtin_amdgcn_s_setprio(0);
     };
     auto flush = [&](f32x16 &acc) {
 #pragma unroll
@@ -1296,6 +1300,7 @@ int g_row_local_acc64 = 1;     // float32 row-local kernels: cut the fp32 accumu
 int g_row_local_ring = 8;      // LDS-DMA kernel: pieces in a wave's ring (8: one tile in flight per wave -- measured
                                // fastest, 0.376 ms back to back against 0.388 at 11; 0: what LDS allows)
 int g_row_local_nt = 0;        // LDS-DMA kernel: non-temporal hint on the X stream
+int g_row_local_prio = 0;      // LDS-DMA kernel: raised wave priority while a wave issues its DMA pieces
 int g_row_local_chunk = 0;     // experiment: force the column chunk of the block-tiled float32 kernel (0: by size)
 int g_row_local_split = 1;     // block-tiled kernels: split the contraction over column chunks when there are few row blocks
 static int row_local_variant(const Ctx *c)
@@ -1334,7 +1339,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
             attr_done[c->device & 63] = true;                                                      \
         }                                                                                          \
         hipLaunchKernelGGL((k_row_local_f32_dma<RV, NTV>), grid, blk, lds, c->stream, c->X.as<float>(),   \
-                           c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W);                     \
+                           c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, g_row_local_prio);   \
     } while (0)
 #define RLD2(RV) do { if (g_row_local_nt) RLD(RV, true); else RLD(RV, false); } while (0)
         PASS_NAME(1, "k_row_local_f32_dma<%d>", R);

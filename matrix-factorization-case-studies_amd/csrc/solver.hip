@@ -508,6 +508,8 @@ int aa_set_option(const char *name, int value)
         g_row_local_ring = value;
     } else if (!strcmp(name, "row_local_nt")) {
         g_row_local_nt = value != 0;
+    } else if (!strcmp(name, "row_local_prio")) {
+        g_row_local_prio = value != 0;
     } else if (!strcmp(name, "row_local_chunk")) {
         AA_REQUIRE(value >= 0, AA_ERR_ARG, "row_local_chunk must be >= 0");
         g_row_local_chunk = value;
@@ -1075,7 +1077,8 @@ int aa_outer_iterations(aa_ctx *h, int n_outer, const aa_spg_params *spg, const 
     // the gradient / Gram buffer pairs swap once per iteration -- are captured into a
     // hipGraph and replayed.  Single rank only (RCCL stays outside graphs).
     const bool graph = g_use_graph && c->world <= 1 && !c->force_comm && c->form == AA_FORM_DATA &&
-                       spg->max_iterations == 1 && n_outer >= 8 && !g_qp_overlap_tail && !g_qp_live;
+                       spg->max_iterations == 1 && n_outer >= 8 && !g_qp_overlap_tail && !g_qp_live &&
+                       !c->time_gemm;      // (timing events recorded inside a capture cannot be read)
     int i = 0;
     const int eager = graph ? 2 : n_outer;
     for (; i < eager; ++i) AA_CHECK(one_iteration());
