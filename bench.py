@@ -198,8 +198,11 @@ def main():
     ctx = _backend.Context(dtype=args.dtype, device=local_rank)
     uid_path = None
     if world > 1:
-        uid, uid_path = exchange_unique_id(rank, world, _backend)
-        ctx.comm_init(uid, rank, world)
+        if _backend.comm_transport() == "p2p":             # AA_COMM=p2p: one-shot peer-to-peer all-reduce
+            ctx.p2p_init(rank, world, "bench")
+        else:
+            uid, uid_path = exchange_unique_id(rank, world, _backend)
+            ctx.comm_init(uid, rank, world)
     ctx.set_data(X, n_global=n, row_offset=lo)
     ctx.set_state(np.ascontiguousarray(C0[:, lo:hi]), Z0[lo:hi], np.ones(k))
     cost0 = ctx.prepare()

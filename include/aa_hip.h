@@ -206,6 +206,16 @@ int aa_ctx_destroy(aa_ctx *ctx);
  * run only on the small k x k / k x p Gram products and packed scalars. */
 int aa_comm_get_unique_id(void *id128);
 int aa_ctx_comm_init(aa_ctx *ctx, const void *id128, int rank, int world);
+/* The second transport: a one-shot peer-to-peer all-reduce for the path's
+ * latency-bound messages (<= 1 MiB; larger ones go in pieces) -- every rank stores its vector
+ * straight into a receive buffer of every peer (mapped with hipIpcOpenMemHandle), raises a flag per
+ * block, and reduces the world slots in rank order once the peers' flags are up: one kernel per rank
+ * and collective, identical bits on every rank, no RCCL (csrc/comm.hip).  Every rank calls
+ * aa_ctx_p2p_export (allocates the buffer; 64-byte IPC handle out), the handles travel out of band
+ * like the RCCL unique id, then every rank calls aa_ctx_p2p_init with all `world` handles in rank
+ * order; all collectives of the context then use this transport.  At most 8 ranks (one node). */
+int aa_ctx_p2p_export(aa_ctx *ctx, int world, void *handle64);
+int aa_ctx_p2p_init(aa_ctx *ctx, const void *handles, int rank, int world);
 /* all-reduce of a small host vector through the context's communicator (used by
  * bench.py for the barrier + max-over-ranks timing); op: 0 = sum, 1 = max. */
 int aa_ctx_allreduce_host(aa_ctx *ctx, double *buf, int count, int op);

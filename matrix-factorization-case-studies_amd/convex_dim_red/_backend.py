@@ -104,6 +104,8 @@ _SIGNATURES = {
     "aa_ctx_destroy": (ctypes.c_int, [_vp]),
     "aa_comm_get_unique_id": (ctypes.c_int, [_vp]),
     "aa_ctx_comm_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+    "aa_ctx_p2p_export": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    "aa_ctx_p2p_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
     "aa_ctx_allreduce_host": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int]),
     "aa_set_data": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_long,
                                    ctypes.c_int, ctypes.c_long, ctypes.c_long]),
@@ -393,6 +395,24 @@ class Context(object):
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         _check(self.lib.aa_ctx_comm_init(self.h, ctypes.cast(buf, _vp), rank, world))
         self.world = world
+
+    def p2p_init(self, rank, world, tag="fit"):
+        """The one-shot peer-to-peer all-reduce as this context's transport (aa_ctx_p2p_*): the IPC
+        handles of the ranks' receive buffers travel through files of the launch, like the RCCL
+        unique id.  No RCCL involved; the ranks may even share a GPU."""
+        mine = ctypes.create_string_buffer(64)
+        _check(self.lib.aa_ctx_p2p_export(self.h, int(world), ctypes.cast(mine, _vp)))
+        handles, paths = exchange_blobs(rank, world, mine.raw, "p2p_" + tag)
+        buf = ctypes.create_string_buffer(b"".join(handles), 64 * world)
+        _check(self.lib.aa_ctx_p2p_init(self.h, ctypes.cast(buf, _vp), int(rank), int(world)))
+        self._p2p_paths = paths
+        self.allreduce_host([0.0])               # everybody has opened everybody's buffer before the files go
+        if rank == 0:
+            for path in paths:
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
 
     def allreduce_host(self, values, op="sum"):
         a = _c64(np.atleast_1d(values)).copy()
@@ -907,6 +927,15 @@ def release_device_cache():
 atexit.register(release_device_cache)
 
 
+def comm_transport():
+    """'rccl' (default: ncclAllReduce over xGMI) or 'p2p' (AA_COMM=p2p: the one-shot peer-to-peer
+    all-reduce of csrc/comm.hip, one kernel per rank and collective; single node, <= 8 ranks)."""
+    v = os.environ.get("AA_COMM", "rccl").lower()
+    if v not in ("rccl", "p2p"):
+        raise ValueError("AA_COMM must be rccl or p2p, got %r" % v)
+    return v
+
+
 def comm_unique_id():
     buf = ctypes.create_string_buffer(128)
     _check(load_library().aa_comm_get_unique_id(ctypes.cast(buf, _vp)))
@@ -916,30 +945,62 @@ def comm_unique_id():
 _uid_serial = [0]
 
 
+def _publish(path, blob):
+    """A rendezvous file other ranks of this launch read: created exclusively with mode 0600 (a file
+    somebody else put there first is an error, not an input) and moved into place when complete."""
+    tmp = path + ".tmp%d" % os.getpid()
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    try:
+        os.write(fd, blob)
+    finally:
+        os.close(fd)
+    os.replace(tmp, path)
+
+
+def _await(path, size, what, rank):
+    import time
+    deadline = time.time() + 300
+    while time.time() < deadline:
+        try:
+            st = os.stat(path)
+            if st.st_size == size and st.st_uid == os.getuid():       # only our own launch's files are trusted
+                with open(path, "rb") as fh:
+                    return fh.read()
+        except OSError:
+            pass
+        time.sleep(0.02)
+    raise RuntimeError("rank %d: timed out waiting for %s (%s)" % (rank, what, path))
+
+
+def exchange_blobs(rank, world, blob, tag):
+    """All-gather of one small byte string per rank through files in the temporary directory of the
+    node (single node: the ranks of one launch share MASTER_PORT and the launcher's agent as parent).
+    Returns (blobs in rank order, paths)."""
+    import tempfile
+    _uid_serial[0] += 1
+    base = os.path.join(tempfile.gettempdir(), "aa_%s_%s_%d_%d_%d" % (
+        tag, os.environ.get("MASTER_PORT", "0"), int(os.environ.get("AA_LAUNCH_ID", os.getppid())), world, _uid_serial[0]))
+    paths = ["%s.%d" % (base, r) for r in range(world)]
+    _publish(paths[rank], blob)
+    return [blob if r == rank else _await(paths[r], len(blob), "rank %d's %s" % (r, tag), rank) for r in range(world)], paths
+
+
 def exchange_unique_id(rank, world, tag="fit"):
     """Rank 0 draws an RCCL unique id and publishes it through a file in the temporary directory;
-    the other ranks of the same launch (same MASTER_PORT, same parent: the launcher's agent) wait
-    for it.  Every communicator of a process gets its own file (`tag` + a per-process serial,
+    the other ranks of the same launch (same MASTER_PORT, same parent: the launcher's agent -- or the
+    same AA_LAUNCH_ID for launchers whose ranks have different parents; single node) wait for it:
+    the file is created exclusively with mode 0600, and readers accept only files of their own user.  Every communicator of a process gets its own file (`tag` + a per-process serial,
     which all ranks advance in the same order).  Returns ``(id, path)``."""
     import tempfile
     import time
     _uid_serial[0] += 1
     path = os.path.join(tempfile.gettempdir(), "aa_uid_%s_%d_%d_%s_%d" % (
-        os.environ.get("MASTER_PORT", "0"), os.getppid(), world, tag, _uid_serial[0]))
+        os.environ.get("MASTER_PORT", "0"), int(os.environ.get("AA_LAUNCH_ID", os.getppid())), world, tag, _uid_serial[0]))
     if rank == 0:
         uid = comm_unique_id()
-        tmp = path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as fh:
-            fh.write(uid)
-        os.replace(tmp, path)
+        _publish(path, uid)
         return uid, path
-    deadline = time.time() + 300
-    while time.time() < deadline:
-        if os.path.exists(path) and os.path.getsize(path) == 128:
-            with open(path, "rb") as fh:
-                return fh.read(), path
-        time.sleep(0.02)
-    raise RuntimeError("rank %d: timed out waiting for the RCCL unique id (%s)" % (rank, path))
+    return _await(path, 128, "the RCCL unique id", rank), path
 
 
 class _Sharded(object):
@@ -980,10 +1041,14 @@ def sharded_context(X, form=FORM_DATA, dtype=None):
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     if hi <= lo:
         raise ValueError("fewer samples (%d) than ranks (%d)" % (n, world))
-    ctx = Context(dtype=dtype, device=local_rank)
+    ctx = Context(dtype=dtype, device=device_index())      # LOCAL_RANK, or CONVEX_DIM_RED_DEVICE when set
     try:
-        uid, path = exchange_unique_id(rank, world)
-        ctx.comm_init(uid, rank, world)
+        path = None
+        if comm_transport() == "p2p":
+            ctx.p2p_init(rank, world)
+        else:
+            uid, path = exchange_unique_id(rank, world)
+            ctx.comm_init(uid, rank, world)
         ctx.set_data(X[lo:hi], form=form, n_global=n, row_offset=lo)
         ctx.global_view = True
     except Exception:

@@ -140,6 +140,7 @@ struct IterState {          // aa_iterate: device-side loop status
 
 // ------------------------------------------------------------------ context
 struct Comm;   // RCCL wrapper (comm.hip)
+struct P2P;    // one-shot peer-to-peer all-reduce over IPC-mapped buffers (comm.hip)
 
 struct Ctx {
     int device = 0;
@@ -186,6 +187,7 @@ struct Ctx {
     const int *qp_tail_rows = nullptr;         // device: overflow slot -> row
     const unsigned int *qp_tail_count = nullptr;   // device: number of overflow slots
     Comm *comm = nullptr;
+    P2P *p2p = nullptr;
     int rank = 0, world = 1;
     bool force_comm = false;                   // AA_FORCE_RCCL=1: use RCCL even with one rank
 
@@ -410,5 +412,8 @@ int comm_unique_id(void *id128);
 int comm_init(Ctx *c, const void *id128, int rank, int world);
 void comm_destroy(Ctx *c);
 int comm_allreduce(Ctx *c, double *dev, long count, int op);   // in place, on c->stream
+int p2p_export(Ctx *c, int world, void *handle64);   // this rank's receive buffer as an IPC handle
+int p2p_init(Ctx *c, const void *handles, int rank, int world);   // handles: world x 64 bytes, in rank order
+int p2p_check(Ctx *c);             // a kernel of the peer-to-peer all-reduce gave up waiting?
 
 }  // namespace aa

@@ -2054,6 +2054,7 @@ static int proj_iterative_passes(Ctx *c, const double *wsrc, int mode, long rpb,
 int proj_poll_multirank(Ctx *c)
 {
     if (!(c->world > 1 || c->force_comm) || !c->proj.p) return AA_OK;
+    AA_CHECK(p2p_check(c));
     ProjState *ps = c->proj.as<ProjState>();
     int h[5] = {0, 0, 0, 0, 0};
     AA_CHECK_HIP(hipMemcpyAsync(h, &ps->overflow_sticky, sizeof(h), hipMemcpyDeviceToHost, c->stream));

@@ -703,6 +703,18 @@ int aa_ctx_comm_init(aa_ctx *h, const void *id128, int rank, int world)
     return comm_init(&h->c, id128, rank, world);
 }
 
+int aa_ctx_p2p_export(aa_ctx *h, int world, void *handle64)
+{
+    AA_REQUIRE(h && handle64, AA_ERR_ARG, "null argument");
+    return p2p_export(&h->c, world, handle64);
+}
+
+int aa_ctx_p2p_init(aa_ctx *h, const void *handles, int rank, int world)
+{
+    AA_REQUIRE(h && handles, AA_ERR_ARG, "null argument");
+    return p2p_init(&h->c, handles, rank, world);
+}
+
 int aa_ctx_allreduce_host(aa_ctx *h, double *buf, int count, int op)
 {
     AA_REQUIRE(h && buf && count >= 0, AA_ERR_ARG, "bad arguments");

@@ -598,6 +598,45 @@ def test_two_ranks_match_one_rank(cdr):
                          timeout=420, universal_newlines=True)
     assert out.returncode == 0 and "MULTI_RANK_OK world=2" in out.stdout, out.stdout[-3000:]
     assert "MULTI_RANK_ESTIMATORS_OK world=2" in out.stdout, out.stdout[-3000:]
+    assert "RESTARTS_OVER_DEVICES_OK" in out.stdout, out.stdout[-3000:]
+
+
+def test_two_ranks_on_one_gpu_peer_to_peer(cdr):
+    """The multi-rank algorithm with TWO real ranks on the one GPU of this box (round 4): two processes,
+    X row-sharded between them, every collective through the one-shot peer-to-peer all-reduce
+    (csrc/comm.hip: each rank's receive buffer mapped into the other process with
+    hipIpcOpenMemHandle, one kernel per rank and collective, slots reduced in rank order) -- RCCL
+    refuses two ranks on one device, this transport does not need it.  tools/two_rank_check.py then
+    compares with the single-rank run: libaa_hip itself (outer iterations, the device loop, a
+    FurthestSum distance column) and the estimators in distributed mode (AA and GPNH, FurthestSum
+    and random starts).  The processes are started before they touch the GPU; this test process
+    only waits."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AA_LAUNCH_ID=str(os.getpid()), AA_COMM="p2p",
+                   CONVEX_DIM_RED_DEVICE="0")
+        env.pop("CONVEX_DIM_RED_DISTRIBUTED", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tools", "two_rank_check.py")], env=env, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True))
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=400)[0])
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    assert all(pr.returncode == 0 for pr in procs), "\n---\n".join(o[-2500:] for o in outs)
+    assert "MULTI_RANK_OK world=2" in outs[0] and "MULTI_RANK_ESTIMATORS_OK world=2" in outs[0], outs[0][-3000:]
 
 
 @pytest.mark.parametrize("case", ["stopping_rule", "iteration_cap", "float32", "three_slots", "long_qp"])

@@ -860,14 +860,16 @@ def test_rccl_path_single_rank(cdr, orc):
     C = orc.right_stochastic_matrix((k, n), rng)
     Z = orc.right_stochastic_matrix((n, k), rng)
 
-    def run(force, **opts):
-        if force:
+    def run(force, p2p=False, **opts):
+        if force and not p2p:
             os.environ["AA_FORCE_RCCL"] = "1"
         for name, value in opts.items():
             _backend.set_option(name, value)
         try:
             with _backend.Context(dtype="float32") as ctx:
-                if force:
+                if force and p2p:
+                    ctx.p2p_init(0, 1, "test")          # the one-shot peer-to-peer transport, one rank
+                elif force:
                     ctx.comm_init(_backend.comm_unique_id(), 0, 1)
                 ctx.set_data(X)
                 ctx.set_state(C, Z, np.ones(k))
@@ -895,6 +897,11 @@ def test_rccl_path_single_rank(cdr, orc):
         assert np.allclose(a[2], b[2], rtol=1e-6, atol=1e-6)   # the row travels through float64
         assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
         assert np.array_equal(b[5], [1.5, 2.5])
+    # the same multi-rank code path over the peer-to-peer transport (round 4): same bits as over RCCL
+    b2 = run(True, p2p=True, proj_small=0)
+    b1 = run(True, proj_small=0)
+    assert b1[0] == b2[0] and np.array_equal(b1[1], b2[1]) and np.array_equal(b1[3], b2[3]) and np.array_equal(b1[4], b2[4])
+    assert np.array_equal(b2[5], [1.5, 2.5])
     small = run(False)                                   # one-kernel threshold search: rounding level
     assert abs(small[0] - a[0]) < 1e-12 * abs(a[0]) and np.abs(small[1] - a[1]).max() < 1e-6 * abs(a[0])
     assert np.abs(small[3] - a[3]).max() < 1e-6 and np.abs(small[4] - a[4]).max() < 1e-5

@@ -3,7 +3,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P tools/two_rank_check.py
 
-Every rank loads its row shard, the ranks build an RCCL communicator (unique id through a file),
+(or, for the one-shot peer-to-peer transport, as N plain processes with RANK / WORLD_SIZE / MASTER_PORT /
+AA_LAUNCH_ID / AA_COMM=p2p in the environment -- with CONVEX_DIM_RED_DEVICE=0 the ranks may share one GPU:
+tests/test_gpu_configs.py::test_two_ranks_on_one_gpu_peer_to_peer).
+Every rank loads its row shard, the ranks build a communicator (RCCL: unique id through a file),
 run production outer iterations and a FurthestSum distance column; rank 0 then solves the
 unsharded problem on its own GPU with a single-rank context and compares: costs and factors
 agree to rounding (the partition only changes summation orders).  Prints MULTI_RANK_OK."""
@@ -18,13 +21,19 @@ _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(_R, "matrix-factorization-case-studies_amd"))
 sys.path.insert(0, _R)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-import bench  # noqa: E402
+sys.path.insert(0, os.path.join(_R, "tests"))
+import bench  # noqa: E402,F401
 from convex_dim_red import _backend  # noqa: E402
+from conftest import oracle_twins  # noqa: E402  (the yardstick of every comparison that is not at rounding level)
+from oracle import aa_oracle as orc  # noqa: E402  (test infrastructure: the checker, not the thing checked)
+
+
+N_OUTER = int(os.environ.get("TWO_RANK_OUTER", "6"))
 
 
 def main():
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("CONVEX_DIM_RED_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     n, p, k = 6001, 300, 7
     rng = np.random.RandomState(0)
@@ -36,7 +45,8 @@ def main():
     Z0 = rng.uniform(size=(n, k)); Z0 /= Z0.sum(axis=1, keepdims=True)
     bounds = np.linspace(0, n, world + 1).astype(np.int64)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    share = os.path.join(tempfile.gettempdir(), "aa_two_rank_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+    share = os.path.join(tempfile.gettempdir(), "aa_two_rank_%s_%d" % (
+        os.environ.get("MASTER_PORT", "0"), int(os.environ.get("AA_LAUNCH_ID", os.getppid()))))
     if rank == 0:
         os.makedirs(share, exist_ok=True)
     results = {}
@@ -44,13 +54,15 @@ def main():
         Xd = X.astype(np.float32) if dtype == "float32" else X
         ctx = _backend.Context(dtype=dtype, device=local)
         uid_path = None
-        if world > 1:
+        if world > 1 and _backend.comm_transport() == "p2p":   # AA_COMM=p2p: one-shot peer-to-peer all-reduce
+            ctx.p2p_init(rank, world, "check")
+        elif world > 1:
             uid, uid_path = _backend.exchange_unique_id(rank, world, "check")
             ctx.comm_init(uid, rank, world)
         ctx.set_data(np.ascontiguousarray(Xd[lo:hi]), n_global=n, row_offset=lo)
         ctx.set_state(np.ascontiguousarray(C0[:, lo:hi]), Z0[lo:hi], np.ones(k))
         cost0 = ctx.prepare()
-        costs = ctx.outer_iterations(6, dict(max_iterations=1), {})
+        costs = ctx.outer_iterations(N_OUTER, dict(max_iterations=1), {})
         dcol = ctx.distance_column(n // 2 + 3)
         Cs, Zs, _ = ctx.get_state()
         # the estimators' device-side loop (aa_iterate) over the sharded state: 4 more iterations,
@@ -83,7 +95,7 @@ def main():
             ctx.set_data(Xd)
             ctx.set_state(C0, Z0, np.ones(k))
             c0 = ctx.prepare()
-            want = ctx.outer_iterations(6, dict(max_iterations=1), {})
+            want = ctx.outer_iterations(N_OUTER, dict(max_iterations=1), {})
             wd = ctx.distance_column(n // 2 + 3)
             wC, wZ, _ = ctx.get_state()
             wloop, wst = ctx.iterate(float(want[-1]), 4, 0.0, "abs_delta_f", False, True, True,
@@ -93,18 +105,41 @@ def main():
         d = np.concatenate([q["d"] for q in parts])
         for q in parts:                                  # every rank holds the same replicated scalars
             assert np.array_equal(q["costs"], parts[0]["costs"]) and q["cost0"] == parts[0]["cost0"]
-        rel = np.abs(parts[0]["costs"] - want).max() / abs(c0)
-        print("%s: %d ranks vs 1: cost0 rel diff %.2e, costs %.2e, C %.2e, Z %.2e, distance column %.2e"
-              % (dtype, world, abs(parts[0]["cost0"] - c0) / abs(c0), rel, np.abs(C - wC).max(),
+        # Yardstick: the partition only changes summation orders, i.e. last bits -- and on this problem
+        # (random start, nearly equal archetypes in the first iterations, per-sample QPs that stop at
+        # their tolerance on flat directions) the ORACLE ITSELF answers a one-ulp change of the data with
+        # 2e-16, 2e-15, 5e-13, 2e-9, 3e-6, 1e-6, 2e-5, ... in the cost after the successive updates.
+        # The ranks are held to 20 x the oracle's own twins (conftest.oracle_twins), update by update.
+        import warnings
+
+        def oracle(Xin):
+            log = []
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out = orc.iterate_aa(Xin, Z0.copy(), C0.copy(), np.ones(k), trace_XXt=float((Xin * Xin).sum()), tolerance=0,
+                                     max_iterations=N_OUTER + 4, dictionary_solver_kwargs=dict(max_iterations=1),
+                                     require_monotonic_cost_decrease=False, cost_log=log)
+            return out, np.array([v for _, v in log])
+        bcosts = oracle(X)[1]
+        twins = oracle_twins(orc, oracle, X, dtype, operands=True)
+        t_costs = np.max([np.abs(t[1] - bcosts) for t in twins], axis=0) / abs(c0)
+        floor = tol
+        all_costs = np.concatenate([parts[0]["costs"], parts[0]["loop_costs"]])
+        all_want = np.concatenate([want, np.asarray(wloop)])
+        rel = np.abs(all_costs - all_want) / abs(c0)
+        bound = np.maximum(floor, 20 * t_costs[:len(rel)])
+        print("%s: %d ranks vs 1: cost0 rel diff %.2e, C %.2e, Z %.2e, distance column %.2e"
+              % (dtype, world, abs(parts[0]["cost0"] - c0) / abs(c0), np.abs(C - wC).max(),
                  np.abs(Z - wZ).max(), np.abs(d - wd).max()), flush=True)
-        assert rel < tol and abs(parts[0]["cost0"] - c0) < tol * abs(c0)
+        print("   cost after every update, relative difference: %s" % " ".join("%.1e" % v for v in rel), flush=True)
+        print("   bound (20 x the oracle's own twins):          %s" % " ".join("%.1e" % v for v in bound), flush=True)
+        assert abs(parts[0]["cost0"] - c0) < tol * abs(c0)
+        assert np.all(rel <= bound), (rel, bound)
         for q in parts:
             assert np.array_equal(q["loop_costs"], parts[0]["loop_costs"]) and int(q["loop_n_iter"]) == wst.n_iter
-        assert np.abs(parts[0]["loop_costs"] - np.asarray(wloop)).max() < 10 * tol * abs(c0)
-        assert np.abs(C - wC).max() < (1e-9 if dtype == "float64" else 1e-4)
-        assert np.abs(Z - wZ).max() < (1e-6 if dtype == "float64" else 1e-2)
         assert np.abs(d - wd).max() < (1e-9 if dtype == "float64" else 1e-3)
         assert np.all(C >= 0) and np.allclose(C.sum(axis=1), 1, rtol=0, atol=1e-12)
+        assert np.all(Z >= 0) and np.allclose(Z.sum(axis=1), 1, rtol=0, atol=1e-12)
     print("MULTI_RANK_OK world=%d" % world, flush=True)
 
 
@@ -146,8 +181,24 @@ def estimators():
     os.environ["CONVEX_DIM_RED_DISTRIBUTED"] = "0"
     if rank != 0:
         return
-    os.environ["CONVEX_DIM_RED_DEVICE"] = os.environ.get("LOCAL_RANK", "0")
+    os.environ.setdefault("CONVEX_DIM_RED_DEVICE", os.environ.get("LOCAL_RANK", "0"))
     alone = fits()
+    # yardsticks: the oracle's estimators on the data moved by one ulp (three draws), x 20
+    import warnings
+    twin_bounds = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for init in ("furthest_sum", "random"):
+            akw = dict(init=init, random_state=0, tolerance=0, max_iterations=12, dictionary_solver_kwargs=dict(max_iterations=1),
+                       require_monotonic_cost_decrease=False)
+            gkw = dict(lambda_W=0.5, init=init, random_state=0, tolerance=0, max_iterations=12, stopping_criterion="rel_delta_f",
+                       require_monotonic_cost_decrease=False, weights_solver_kwargs=dict(max_iterations=1))
+            for name, fn, kw in (("AA " + init, orc.archetypal_analysis, akw), ("GPNH " + init, orc.gpnh_convex_coding, gkw)):
+                base = fn(X, k, **kw)
+                tws = oracle_twins(orc, lambda Xin: fn(Xin, k, **kw), X, "float64")
+                twin_bounds[name] = (20 * max(abs(t["cost"] - base["cost"]) for t in tws) / abs(base["cost"]),
+                                     20 * max(np.abs(t["weights"] - base["weights"]).max() for t in tws),
+                                     20 * max(np.abs(t["dictionary"] - base["dictionary"]).max() for t in tws))
     for a, b in zip(alone, dist):
         print("%-18s %d ranks vs 1: n_iter %d / %d, cost rel diff %.2e, weights %.2e, dictionary %.2e"
               % (a[0], world, b[2], a[2], abs(a[1] - b[1]) / abs(a[1]), np.abs(a[3] - b[3]).max(),
@@ -155,11 +206,44 @@ def estimators():
         # twelve iterations: the partition only changes summation orders, and a last-bit difference
         # grows about 2x per outer iteration
         # (test_rccl_path_single_rank: 1e-6 after six iterations between two projection variants)
-        assert a[2] == b[2] and abs(a[1] - b[1]) < 1e-6 * abs(a[1])
-        assert np.abs(a[3] - b[3]).max() < 1e-4 and np.abs(a[4] - b[4]).max() < 1e-4
+        tw = twin_bounds[a[0]]
+        print("      bound (20 x the oracle's own one-ulp twins): cost %.2e, weights %.2e, dictionary %.2e" % tw, flush=True)
+        assert a[2] == b[2] and abs(a[1] - b[1]) <= max(1e-10 * abs(a[1]), tw[0] * abs(a[1]))
+        assert np.abs(a[3] - b[3]).max() <= max(1e-9, tw[1]) and np.abs(a[4] - b[4]).max() <= max(1e-9, tw[2])
     print("MULTI_RANK_ESTIMATORS_OK world=%d" % world, flush=True)
+
+
+def restarts_over_devices():
+    """fit_restarts(devices=[0, 1, ...]): whole restarts dealt over the GPUs of the node, side by side
+    in the slots of every device (no collective at all) -- rank 0 only, when it sees more than one
+    device; every restart must come out as on one device."""
+    import warnings
+    import convex_dim_red as cdr
+    if int(os.environ.get("RANK", "0")) != 0 or _backend.require_gpu() < 2:
+        return
+    n, p, k = 2400, 150, 5
+    rng = np.random.RandomState(9)
+    B = rng.standard_normal((k, p))
+    Zt = rng.uniform(size=(n, k)) ** 4
+    Zt /= Zt.sum(axis=1, keepdims=True)
+    X = Zt.dot(B) + 0.05 * rng.standard_normal((n, p))
+
+    def run(devices):
+        shared = np.random.RandomState(0)
+        make = lambda: cdr.ArchetypalAnalysis(k, init="random", tolerance=1e-5, max_iterations=300, random_state=shared,
+                                              dictionary_solver_kwargs=dict(max_iterations=1))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return cdr.fit_restarts(make, X, 12, devices=devices)
+    one, b1 = run([0])
+    two, b2 = run([0, 1])
+    assert b1 == b2 and all(a.cost == b.cost and a.n_iter == b.n_iter and np.array_equal(a.weights, b.weights)
+                            for a, b in zip(one, two))
+    print("RESTARTS_OVER_DEVICES_OK", flush=True)
 
 
 if __name__ == "__main__":
     main()
-    estimators()
+    if os.environ.get("TWO_RANK_ONLY_MAIN", "0") != "1":
+        estimators()
+        restarts_over_devices()
