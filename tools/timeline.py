@@ -2,7 +2,8 @@
 # usage: timeline.py <dir> [iteration index]
 import csv, glob, sys
 d = sys.argv[1]; which = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-f = sorted(glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv"))[0]
+import os
+f = max(glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv"), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 short = lambda n: n.split("(")[0].replace("void aa::", "").replace("aa::", "")[:40]

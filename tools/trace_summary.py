@@ -2,7 +2,8 @@
 # usage: trace_summary.py <dir with *_kernel_trace.csv> [n_iterations_from_the_end]
 import csv, glob, sys, collections
 d = sys.argv[1]; last = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-f = sorted(glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv"))[0]
+import os
+f = max(glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv"), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
