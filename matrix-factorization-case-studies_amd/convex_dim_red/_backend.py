@@ -837,7 +837,8 @@ def _digest(X):
     """Checksum of the WHOLE buffer (an in-place edit of any entry between two fits must not be
     served from the stale device copy).  xxh3 runs at memory speed (~0.15 s for the 1.6 GB
     headline matrix, against an upload of the same order); zlib.crc32 when xxhash is missing."""
-    buf = memoryview(np.ascontiguousarray(X)).cast("B")
+    # (a uint8 view: memoryview.cast refuses non-native-endian and structured dtypes)
+    buf = memoryview(np.ascontiguousarray(X).reshape(-1).view(np.uint8))
     try:
         import xxhash
         return xxhash.xxh3_64_intdigest(buf)

@@ -905,7 +905,7 @@ __device__ __forceinline__ void dma16(const float *src, float *lds_uniform)
                                      (__attribute__((address_space(3))) void *)lds_uniform, 16, 0, NT ? 2 : 0);
 }
 
-template <int R, bool NT>
+template <int R, bool NT, bool EARLY = false>
 __global__ __launch_bounds__(1024) void k_row_local_f32_dma(const float *__restrict__ X, long ldx,
                                                             const float *__restrict__ B, int p_pad,
                                                             double *__restrict__ out, long n_pad, int W, int prio)
@@ -975,6 +975,27 @@ __global__ __launch_bounds__(1024) void k_row_local_f32_dma(const float *__restr
         slot = slot >= R ? slot - R : slot;
         const float *xb = xs + slot * 256 + (j & 7) * TC;
         const float *bb = bs + (s & 1) * (KP * SB) + j * SB;
+        if constexpr (EARLY) {
+            // all fragments of the tile into registers first (32 VGPRs), the LDS reads waited for, and
+            // the tile's four ring slots handed back to the DMA BEFORE the 16 matrix instructions run:
+            // 8 KB per wave in flight during the arithmetic instead of 4 (experiment, row_local_early)
+            f32x4 av[4], bvv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pcx = ((2 * q + h) ^ ((j >> 1) & 7)) << 2;
+                const int pcb = ((ts * 8 + 2 * q + h) ^ (j & 15)) << 2;
+                av[q] = *reinterpret_cast<const f32x4 *>(xb + pcx);
+                bvv[q] = *reinterpret_cast<const f32x4 *>(bb + pcb);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_piece();
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][m], bvv[q][m], acc, 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int pcx = ((2 * q + h) ^ ((j >> 1) & 7)) << 2;
@@ -1300,6 +1321,7 @@ int g_row_local_acc64 = 1;     // float32 row-local kernels: cut the fp32 accumu
 int g_row_local_ring = 8;      // LDS-DMA kernel: pieces in a wave's ring (8: one tile in flight per wave -- measured
                                // fastest, 0.376 ms back to back against 0.388 at 11; 0: what LDS allows)
 int g_row_local_nt = 0;        // LDS-DMA kernel: non-temporal hint on the X stream
+int g_row_local_early = 0;     // LDS-DMA kernel: fragments to registers first, the next pieces issued before the MFMAs
 int g_row_local_prio = 0;      // LDS-DMA kernel: raised wave priority while a wave issues its DMA pieces
 int g_row_local_chunk = 0;     // experiment: force the column chunk of the block-tiled float32 kernel (0: by size)
 int g_row_local_split = 1;     // block-tiled kernels: split the contraction over column chunks when there are few row blocks
@@ -1330,6 +1352,17 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
         if (R < 8) R = 8;
         const size_t lds = ((size_t)2 * 32 * 64 + (size_t)W * R * 256) * sizeof(float);
         dim3 grid((unsigned)((tiles + W - 1) / W)), blk((unsigned)(64 * W));
+#define RLDE()                                                                                     \
+    do {                                                                                           \
+        static bool attr_done_e[64] = {false};                                                     \
+        if (!attr_done_e[c->device & 63]) {                                                        \
+            AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_local_f32_dma<8, false, true>), \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
+            attr_done_e[c->device & 63] = true;                                                    \
+        }                                                                                          \
+        hipLaunchKernelGGL((k_row_local_f32_dma<8, false, true>), grid, blk, lds, c->stream, c->X.as<float>(), \
+                           c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, g_row_local_prio);   \
+    } while (0)
 #define RLD(RV, NTV)                                                                               \
     do {                                                                                           \
         static bool attr_done[64] = {false};                                                       \
@@ -1341,7 +1374,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
         hipLaunchKernelGGL((k_row_local_f32_dma<RV, NTV>), grid, blk, lds, c->stream, c->X.as<float>(),   \
                            c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, g_row_local_prio);   \
     } while (0)
-#define RLD2(RV) do { if (g_row_local_nt) RLD(RV, true); else RLD(RV, false); } while (0)
+#define RLD2(RV) do { if (g_row_local_early && RV == 8) RLDE(); else if (g_row_local_nt) RLD(RV, true); else RLD(RV, false); } while (0)
         PASS_NAME(1, "k_row_local_f32_dma<%d>", R);
         switch (R) {
             case 8: RLD2(8); break;
@@ -1352,6 +1385,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
         }
 #undef RLD2
 #undef RLD
+#undef RLDE
     } else if (c->dtype == AA_F32 && row_local_variant(c) == 8) {
         // wave-streaming kernel: W waves per block, one block per CU where possible
         const float *B = reinterpret_cast<const float *>(B_wideT);

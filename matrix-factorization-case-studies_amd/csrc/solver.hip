@@ -508,6 +508,8 @@ int aa_set_option(const char *name, int value)
         g_row_local_ring = value;
     } else if (!strcmp(name, "row_local_nt")) {
         g_row_local_nt = value != 0;
+    } else if (!strcmp(name, "row_local_early")) {
+        g_row_local_early = value != 0;
     } else if (!strcmp(name, "row_local_prio")) {
         g_row_local_prio = value != 0;
     } else if (!strcmp(name, "row_local_chunk")) {
