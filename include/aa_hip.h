@@ -281,6 +281,13 @@ int aa_share_data(aa_ctx *ctx, const aa_ctx *owner);
  * where _aa_dictionary_gradient :291-300 divides by n_samples) -- the one place where the two
  * forms of the reference differ for K = X X'.  Reset by aa_set_data. */
 int aa_set_linear_kernel(aa_ctx *ctx, int on);
+/* KernelAA on an implicit RBF kernel (archetypal_analysis.py:673-910 with the n x n kernel
+ * matrix K_ij = exp(-gamma ||x_i - x_j||^2) NEVER formed): uploads the n x p feature matrix (float64) and
+ * switches the context to the kernel form of the algorithm; every product C K / K Z is one fused
+ * distance + exp + multiply pass over the features (csrc/kernels_gemm.hip: k_rbf_kv), tr K = n, and
+ * aa_distance_column returns sqrt(2 - 2 K_ij).  Single rank, float64 context.  Everything downstream
+ * (aa_set_state, aa_prepare, aa_iterate, aa_get_state ...) is the explicit kernel form's. */
+int aa_set_rbf_features(aa_ctx *ctx, const double *X, long n, long p, long ld, double gamma);
 
 /* Driver-side preprocessing on the device (bin/run_hadisst_aa.py:133-146 weight_and_flatten_data,
  * :196-209 NaN-column removal and training / validation split; the same steps in

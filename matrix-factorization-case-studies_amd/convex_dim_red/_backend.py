@@ -111,6 +111,7 @@ _SIGNATURES = {
                                    ctypes.c_int, ctypes.c_long, ctypes.c_long]),
     "aa_data_trace": (ctypes.c_int, [_vp, _dp]),
     "aa_set_linear_kernel": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "aa_set_rbf_features": (ctypes.c_int, [_vp, _dp, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_double]),
     "aa_share_data": (ctypes.c_int, [_vp, _vp]),
     "aa_set_data_weighted": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_long,
                                             _dp, ctypes.c_long, ctypes.c_long,
@@ -369,6 +370,7 @@ class Context(object):
         # row shard of a distributed fit (sharded_context): with `global_view` the factor methods
         # below take and return arrays of the WHOLE problem and slice / gather this rank's rows
         self.global_view = False
+        self.implicit = False      # an implicit kernel (set_rbf_features): no stored matrix behind the products
         self.row_lo = 0
         self.n_global = 0
 
@@ -458,6 +460,20 @@ class Context(object):
         _check(self.lib.aa_share_data(self.h, owner.h))
         self.n, self.p = owner.n, owner.p
         self._data_owner = owner                  # keeps the owner alive
+
+    def set_rbf_features(self, X, gamma):
+        """The implicit RBF kernel exp(-gamma ||x_i - x_j||^2) of the rows of X as this context's kernel
+        matrix (never formed): kernel form of the algorithm, float64."""
+        X = _c64(X)
+        if X.ndim != 2:
+            raise ValueError("feature matrix must be 2-D")
+        if self.dtype_code != AA_F64:
+            raise ValueError("the implicit RBF kernel needs a float64 context")
+        n, p = X.shape
+        _check(self.lib.aa_set_rbf_features(self.h, _ptr(X), n, p, p, float(gamma)))
+        self.n, self.p = n, n
+        self.form = FORM_KERNEL
+        self.implicit = True
 
     def set_linear_kernel(self, on):
         """The resident data matrix X stands in for the kernel K = X X' of KernelAA
@@ -604,7 +620,7 @@ class Context(object):
         """FurthestSum on the device (aa_furthest_sum); returns the selected indices, or None when a
         pick met a shared maximum (the caller then uses the host's list logic) or the context is
         row-sharded."""
-        if self.global_view or n_components < 1 or n_components > MAX_K:
+        if self.global_view or self.implicit or n_components < 1 or n_components > MAX_K:
             return None
         ex = np.ascontiguousarray([] if exclude is None else exclude, dtype=np.int32)
         sel = np.zeros(int(n_components), dtype=np.int32)

@@ -593,7 +593,15 @@ class KernelAA(_BaseAA):
     def _kernel_aa(self, kernel, dictionary=None, weights=None, alpha=None,
                    update_dictionary=True, update_weights=True,
                    update_scale_factors=True, **kwargs):
-        if kwargs.pop('features', False):
+        features = kwargs.pop('features', False)
+        which = kwargs.pop('implicit_kernel', 'linear')
+        gamma = kwargs.pop('gamma', None)
+        if features and which == 'rbf':
+            return self._kernel_aa_rbf(kernel, gamma, dictionary, weights, alpha, update_dictionary,
+                                       update_weights, update_scale_factors, **kwargs)
+        if which not in ('linear', 'rbf') or (which == 'rbf' and not features):
+            raise ValueError("kernel must be 'linear' or 'rbf' (with features=True); got %r" % (which,))
+        if features:
             # `kernel` is the n x p feature matrix X (or a DeviceData) of the linear
             # kernel K = X X', which is never formed -- n = 100 000 would be 80 GB.  Same
             # algorithm, conventions and RNG order as the explicit-kernel path below; FurthestSum
@@ -632,10 +640,63 @@ class KernelAA(_BaseAA):
             update_scale_factors=update_scale_factors, tolerance=self.tolerance,
             max_iterations=self.max_iterations, verbose=self.verbose, **self._solver_kwargs()))
 
+    def _kernel_aa_rbf(self, X, gamma, dictionary, weights, alpha, update_dictionary, update_weights,
+                       update_scale_factors, **kwargs):
+        """SURVEY 8(f4), the alternative it names: the RBF kernel ``exp(-gamma ||x_i - x_j||^2)`` of the
+        rows of ``X``, never formed -- the kernel form of the algorithm (reference :399-531, :673-910)
+        with every product ``C K`` / ``K Z`` computed as one fused distance + exp + multiply pass over
+        the features (aa_set_rbf_features).  Same conventions, initialisers and RNG order as the
+        explicit-kernel path: ``KernelAA(...).fit_transform(rbf_kernel(X, gamma=g))`` is what it
+        reproduces (tests/test_gpu_parity.py::test_kernel_aa_on_the_implicit_rbf_kernel)."""
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError('Expected a feature matrix (n_samples x n_features); got shape %s' % (X.shape,))
+        if gamma is None:
+            gamma = 1.0 / X.shape[1]                      # scikit-learn's rbf_kernel default
+        n_samples = X.shape[0]
+        if self.n_components is None:
+            self.n_components = n_samples
+            self._n_components_defaulted_from = 'n_samples'
+        self._check_hyper_parameters()
+        shape_only = _ShapeOnly(n_samples)
+        with _backend.Context(dtype=np.float64) as ctx:
+            ctx.set_rbf_features(X, gamma)
+
+            def init_dictionary():
+                init = 'furthest_sum' if self.init is None else self.init
+                if init == 'furthest_sum':
+                    rng = self.random_state
+                    start_index = kwargs.get('start_index', None)
+                    if start_index is None:
+                        start_index = rng.randint(n_samples)
+                    exclude = kwargs.get('exclude', None)
+                    if exclude is None:
+                        exclude = np.array([], dtype='i8')
+                    selected = _furthest_sum_on_device(ctx, n_samples, self.n_components, start_index,
+                                                       kwargs.get('n_extra_steps', 10), exclude)
+                    return _one_hot_rows(selected, n_samples, np.float64)
+                return _initialize_kernel_aa_dictionary(shape_only, self.n_components, init=init,
+                                                        random_state=self.random_state)
+
+            dictionary, weights, alpha = self._resolve_factors(
+                n_samples, dictionary, weights, alpha, update_dictionary, update_weights, init_dictionary,
+                lambda: _initialize_kernel_aa_weights(shape_only, self.n_components, init=self.init,
+                                                      random_state=self.random_state))
+            self.weights = weights.copy()
+            self.dictionary = dictionary.copy()
+            self.alpha = alpha.copy()
+            return self._finish(_iterate_on_device(
+                ctx, "Kernel AA", self.weights, self.dictionary, self.alpha, self.delta, update_weights,
+                update_dictionary, update_scale_factors, self.tolerance, self.max_iterations, self.verbose,
+                **self._solver_kwargs()))
+
     def fit_transform(self, data, dictionary=None, weights=None, alpha=None, **kwargs):
         """Factorise the kernel matrix ``data`` (n x n) and return the weights.  With
         ``features=True`` (an extension of the reference's signature) ``data`` is the n x p
-        feature matrix of the linear kernel ``data.dot(data.T)``, which is then never formed."""
+        feature matrix of the linear kernel ``data.dot(data.T)`` -- or, with ``kernel='rbf',
+        gamma=g``, of the RBF kernel ``exp(-g ||x_i - x_j||^2)`` -- which is then never formed."""
+        if 'kernel' in kwargs:                 # (`kernel` is also the name of _kernel_aa's first argument)
+            kwargs['implicit_kernel'] = kwargs.pop('kernel')
         self.cost, self.n_iter, self.avg_time_per_iter, self.cost_deltas = self._kernel_aa(
             data, dictionary=dictionary, weights=weights, alpha=alpha, **kwargs)
         return self.weights

@@ -230,6 +230,10 @@ struct Ctx {
     DevBuf iterState, snapC, snapZ, snapAlpha; // aa_iterate: status record, factors at the stopping iteration
     DevBuf qpIters;                            // n ints: pass counts of the latest weights update
     DevBuf qpPerm;                             // n ints: sample order of the lane kernel
+    DevBuf feat, featNorm;                     // implicit RBF kernel: features [n_pad][feat_ld] (float64) and their squared norms
+    long feat_p = 0, feat_ld = 0;
+    int implicit_kernel = 0;                   // 0: none; 1: K_ij = exp(-rbf_gamma ||x_i - x_j||^2), never formed (aa_set_rbf_features)
+    double rbf_gamma = 0.0;
     DevBuf fsScratch;                          // FurthestSum on the device: running sums, one distance column, state, alive flags
     bool qp_iters_valid = false;               // qpIters belongs to the current rows / state
     bool linear_kernel = false;                // data form, KernelAA conventions: K = X X' implicit (aa_set_linear_kernel)
@@ -321,6 +325,8 @@ int launch_gpnh_judge(Ctx *c, int it, double cost0, const double *costs, IterSta
 enum { ST_INIT_F = 0, ST_ALPHA = 1, ST_LINESEARCH = 2, ST_BB = 3, ST_CONV = 4 };
 int launch_row_sqnorm_sum(Ctx *c, double *trace_out_host);
 int launch_distance_column(Ctx *c, long j_local, int owner_has_row, const double *xj_host, double *d_host);
+int launch_implicit_kv(Ctx *c, const double *V_tall, double *out_tall);   // out = K V for the implicit kernel (tall in, tall out)
+int launch_rbf_norms(Ctx *c);
 int launch_furthest_sum(Ctx *c, int k, int start, const int *exclude_host, int n_ex, int extra_steps,
                         int *selected_host, int *tie_host);
 int launch_row_broadcast(Ctx *c, long j_local, bool own);

@@ -1300,6 +1300,150 @@ int launch_reduce_rows_fixup(Ctx *c, const unsigned int *count_dev, const int *r
     return AA_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Implicit RBF kernel (archetypal_analysis.py:673-910 with K never formed):
+//   out[r][i] = sum_c exp(-gamma ||x_r - x_c||^2) V[c][i]        (V, out tall [n_pad][KP], float64)
+// Both pass shapes of the kernel form reduce to this product (K is symmetric: C K = (K C')').  A block
+// owns 64 rows and walks over 64-column tiles of K: S = X_R X_C' through LDS in chunks of 16 features
+// (a thread holds a 4 x 4 patch), E = exp(-gamma max(|x_r|^2 + |x_c|^2 - 2 S, 0)) goes to LDS, then
+// out_R += E V_C (a thread holds KP / 4 components of one row).  float64 VALU throughout: the
+// per-sample QPs behind it need a float64 gradient.  n^2 (2 p + 2 KP) flop per
+// product: for n up to a few ten thousand; grid.y splits the columns so that the chip is full.
+// ---------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(256) void k_rbf_kv(const double *__restrict__ F, long ldf, int pf,
+                                                const double *__restrict__ nrm, double gamma,
+                                                const double *__restrict__ V, long n, long n_pad,
+                                                long tiles_per_split, double *__restrict__ out)
+{
+    constexpr int PC = 16, CPT = KP / 4;
+    extern __shared__ __attribute__((aligned(16))) double rbf_smem[];     // 67 KB (KP = 32) / 83 KB (KP = 64)
+    double (*es)[65] = reinterpret_cast<double (*)[65]>(rbf_smem);
+    double (*vs)[KP] = reinterpret_cast<double (*)[KP]>(rbf_smem + 64 * 65);
+    double (*xr)[PC + 1] = reinterpret_cast<double (*)[PC + 1]>(rbf_smem + 64 * 65 + 64 * KP);
+    double (*xc)[PC + 1] = reinterpret_cast<double (*)[PC + 1]>(rbf_smem + 64 * 65 + 64 * KP + 64 * (PC + 1));
+    const int t = threadIdx.x;
+    const long r0 = (long)blockIdx.x * 64;
+    const int tr = t >> 4, tc = t & 15;                  // 4 x 4 patch of S
+    const int orow = t >> 2, oc0 = (t & 3) * CPT;        // one row, CPT components of the output
+    double acc[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) acc[i] = 0.0;
+    const long ntile = n_pad / 64;
+    long ct0 = (long)blockIdx.y * tiles_per_split, ct1 = ct0 + tiles_per_split;
+    if (ct1 > ntile) ct1 = ntile;
+    for (long ct = ct0; ct < ct1; ++ct) {
+        const long c0 = ct * 64;
+        if (c0 >= n) break;                              // columns past n carry zero rows of V
+        double sv[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) sv[a][b] = 0.0;
+        for (int q0 = 0; q0 < pf; q0 += PC) {
+            __syncthreads();
+            for (int e = t; e < 64 * PC; e += 256) {
+                const int rr = e / PC, qq = e % PC;
+                const bool ok = q0 + qq < pf;
+                xr[rr][qq] = ok ? F[(r0 + rr) * ldf + q0 + qq] : 0.0;      // rows < n_pad exist (zero padded)
+                xc[rr][qq] = ok ? F[(c0 + rr) * ldf + q0 + qq] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int qq = 0; qq < PC; ++qq) {
+                double ra[4], cb[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) ra[a] = xr[4 * tr + a][qq];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) cb[b] = xc[4 * tc + b][qq];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) sv[a][b] = fma(ra[a], cb[b], sv[a][b]);
+            }
+        }
+        __syncthreads();                                 // the previous tile's E and V have been consumed
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long r = r0 + 4 * tr + a, cc = c0 + 4 * tc + b;
+                const double d2 = fmax(nrm[r] + nrm[cc] - 2.0 * sv[a][b], 0.0);
+                es[4 * tr + a][4 * tc + b] = (r == cc) ? 1.0 : exp(-gamma * d2);
+            }
+        for (int e = t; e < 64 * KP; e += 256) vs[e / KP][e % KP] = V[(c0 + e / KP) * KP + e % KP];
+        __syncthreads();
+        for (int cc = 0; cc < 64; ++cc) {
+            const double ev = es[orow][cc];
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) acc[i] = fma(ev, vs[cc][oc0 + i], acc[i]);
+        }
+    }
+    double *dst = out + (size_t)blockIdx.y * n_pad * KP;
+    const long r = r0 + orow;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) dst[r * KP + oc0 + i] = r < n ? acc[i] : 0.0;     // padding rows stay zero
+}
+
+__global__ __launch_bounds__(256) void k_rbf_norms(const double *__restrict__ F, long ldf, int pf, long n_pad,
+                                                   double *__restrict__ nrm)
+{
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_pad) return;
+    double s = 0.0;
+    for (int q = 0; q < pf; ++q) s = fma(F[r * ldf + q], F[r * ldf + q], s);
+    nrm[r] = s;
+}
+
+int launch_rbf_norms(Ctx *c)
+{
+    hipLaunchKernelGGL(k_rbf_norms, dim3((unsigned)((c->n_pad + 255) / 256)), dim3(256), 0, c->stream,
+                       (const double *)c->feat.as<double>(), c->feat_ld, (int)c->feat_p, c->n_pad, c->featNorm.as<double>());
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_implicit_kv(Ctx *c, const double *V_tall, double *out_tall)
+{
+    AA_REQUIRE(c->implicit_kernel == 1 && c->feat.p, AA_ERR_STATE, "no implicit kernel set");
+    const long rtiles = c->n_pad / 64, ntile = c->n_pad / 64;
+    long nsplit = (1024 + rtiles - 1) / rtiles;          // ~4 blocks per CU
+    if (nsplit > ntile) nsplit = ntile;
+    if (nsplit < 1) nsplit = 1;
+    const long tps = (ntile + nsplit - 1) / nsplit;
+    nsplit = (ntile + tps - 1) / tps;
+    double *dst = out_tall;
+    if (nsplit > 1) {
+        AA_CHECK(c->rlPartial.alloc((size_t)nsplit * c->n_pad * c->KP * sizeof(double)));
+        dst = c->rlPartial.as<double>();
+    }
+    const dim3 grid((unsigned)rtiles, (unsigned)nsplit);
+    const size_t lds = (size_t)(64 * 65 + 64 * c->KP + 2 * 64 * 17) * sizeof(double);
+    static bool attr_rbf[64] = {false};
+    if (!attr_rbf[c->device & 63]) {
+        AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rbf_kv<32>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rbf_kv<64>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_rbf[c->device & 63] = true;
+    }
+    if (c->KP == 32)
+        hipLaunchKernelGGL(k_rbf_kv<32>, grid, dim3(256), lds, c->stream, (const double *)c->feat.as<double>(), c->feat_ld,
+                           (int)c->feat_p, (const double *)c->featNorm.as<double>(), c->rbf_gamma, V_tall, c->n, c->n_pad,
+                           tps, dst);
+    else
+        hipLaunchKernelGGL(k_rbf_kv<64>, grid, dim3(256), lds, c->stream, (const double *)c->feat.as<double>(), c->feat_ld,
+                           (int)c->feat_p, (const double *)c->featNorm.as<double>(), c->rbf_gamma, V_tall, c->n, c->n_pad,
+                           tps, dst);
+    if (nsplit > 1) {
+        const long elems = c->n_pad * c->KP;
+        hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double *)dst, elems, (int)nsplit, out_tall);
+    }
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
 // 0: operands straight from global memory; 1: X staged in wave-private LDS;
 // >= 2: block-tiled, B shared through LDS: 2 = 64-column tiles, 3 = 64 double-buffered,
 // 4 (default) = 128, 5 = 32 double-buffered, 6 = 128 double-buffered, 7 = 32;

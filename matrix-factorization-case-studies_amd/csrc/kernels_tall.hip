@@ -1834,6 +1834,23 @@ __global__ __launch_bounds__(256) void k_distance_data(const T *__restrict__ X, 
     if (lane == 0) d[r] = sqrt(fmax(sii - 2.0 * sij + sjj, 0.0));
 }
 
+// implicit RBF kernel: d[i] = sqrt(K_ii - 2 K_ij + K_jj) = sqrt(2 - 2 exp(-gamma ||x_i - x_j||^2)), one wave per
+// row, the squared distance summed directly (i == j gives exactly 0)
+__global__ __launch_bounds__(256) void k_distance_rbf(const double *__restrict__ F, long ldf, int pf, long n, long j,
+                                                      double gamma, double *__restrict__ d)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + wave;
+    if (r >= n) return;
+    double s = 0.0;
+    for (int q = lane; q < pf; q += 64) {
+        const double df = F[r * ldf + q] - F[j * ldf + q];
+        s = fma(df, df, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) d[r] = sqrt(fmax(2.0 - 2.0 * exp(-gamma * s), 0.0));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_distance_kernel(const T *__restrict__ K, long ldx, long n,
                                                          long j, double *__restrict__ d)
@@ -3623,7 +3640,10 @@ int launch_distance_column(Ctx *c, long j_local, int owner_has_row, const double
     (void)owner_has_row;
     (void)xj_host;
     double *dd = c->tmpTall.as<double>();
-    if (c->form == AA_FORM_DATA) {
+    if (c->implicit_kernel) {
+        hipLaunchKernelGGL(k_distance_rbf, dim3((unsigned)((c->n + 3) / 4)), dim3(256), 0, c->stream,
+                           (const double *)c->feat.as<double>(), c->feat_ld, (int)c->feat_p, c->n, j_local, c->rbf_gamma, dd);
+    } else if (c->form == AA_FORM_DATA) {
         dim3 grid((unsigned)((c->n + 3) / 4));
         if (c->dtype == AA_F32)
             hipLaunchKernelGGL(k_distance_data<float>, grid, dim3(256), 0, c->stream,

@@ -184,6 +184,11 @@ static int device_cost(Ctx *c, double *cost)
 static int ensure_trace(Ctx *c)
 {
     if (c->have_trace) return AA_OK;
+    if (c->implicit_kernel) {                    // RBF: every diagonal entry is exp(0) = 1
+        c->trace = (double)c->n_global;
+        c->have_trace = true;
+        return AA_OK;
+    }
     AA_CHECK(launch_row_sqnorm_sum(c, &c->trace));
     c->have_trace = true;
     return AA_OK;
@@ -208,7 +213,9 @@ static int refresh_after_dictionary(Ctx *c, bool recompute_products, bool ckct_d
         }
         AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), gpp));
     } else {
-        if (recompute_products) {
+        if (recompute_products && c->implicit_kernel) {
+            AA_CHECK(launch_implicit_kv(c, c->Ct.as<double>(), c->Gr.as<double>()));      // (C K)' = K C'
+        } else if (recompute_products) {
             AA_CHECK(launch_reduce_rows(c, c->Ct.as<double>(), c->wideScratch.as<double>(), nullptr));
             AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gr.as<double>()));
         }
@@ -239,9 +246,13 @@ static int refresh_after_weights(Ctx *c)
     } else {
         if (c->qp_tail_pending) AA_CHECK(launch_qp_tail_fixup(c, c->Zt.as<double>()));   // not used
         AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
-        AA_CHECK(launch_transpose_tall_to_wide(c, c->Zt.as<double>(), c->ZtX.as<double>(),
-                                               operandT(c, c->ZtX, c->Qw)));
-        AA_CHECK(launch_row_local(c, operandT(c, c->ZtX, c->Qw), c->H.as<double>()));
+        if (c->implicit_kernel) {
+            AA_CHECK(launch_implicit_kv(c, c->Zt.as<double>(), c->H.as<double>()));       // K Z
+        } else {
+            AA_CHECK(launch_transpose_tall_to_wide(c, c->Zt.as<double>(), c->ZtX.as<double>(),
+                                                   operandT(c, c->ZtX, c->Qw)));
+            AA_CHECK(launch_row_local(c, operandT(c, c->ZtX, c->Qw), c->H.as<double>()));
+        }
     }
     AA_CHECK(launch_gram_tall(c, c->Ct.as<double>(), c->H.as<double>(), dev_CKZ(c)));
     c->ckz_valid = true;
@@ -345,8 +356,12 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
                 if (mixed) AA_CHECK(slots_restore_P_warm(c));
                 AA_CHECK(launch_gram_wide(c, c->P.as<double>(), c->P.as<double>(), gram));
             } else {
-                AA_CHECK(launch_reduce_rows(c, x, c->wideScratch.as<double>(), nullptr));
-                AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gr.as<double>()));
+                if (c->implicit_kernel) {
+                    AA_CHECK(launch_implicit_kv(c, x, c->Gr.as<double>()));
+                } else {
+                    AA_CHECK(launch_reduce_rows(c, x, c->wideScratch.as<double>(), nullptr));
+                    AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gr.as<double>()));
+                }
                 AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), x, gram));
             }
         } else {
@@ -384,8 +399,12 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
                 AA_CHECK(launch_scalar_stage(c, ST_LINESEARCH, sp, 1));
             }
         } else {
-            AA_CHECK(launch_reduce_rows(c, c->Dt.as<double>(), c->wideScratch.as<double>(), nullptr));
-            AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gn.as<double>()));
+            if (c->implicit_kernel) {
+                AA_CHECK(launch_implicit_kv(c, c->Dt.as<double>(), c->Gn.as<double>()));  // (D K)' = K D'
+            } else {
+                AA_CHECK(launch_reduce_rows(c, c->Dt.as<double>(), c->wideScratch.as<double>(), nullptr));
+                AA_CHECK(launch_transpose_wide_to_tall(c, c->wideScratch.as<double>(), c->Gn.as<double>()));
+            }
             AA_CHECK(launch_gram_tall(c, c->Gn.as<double>(), x, gram + GS));
             AA_CHECK(launch_gram_tall(c, c->Gn.as<double>(), c->Dt.as<double>(), gram + 2 * GS));
             AA_CHECK(launch_gram_tall(c, c->Gr.as<double>(), c->Dt.as<double>(), gram + 3 * GS));
@@ -671,7 +690,7 @@ int aa_ctx_destroy(aa_ctx *h)
     comm_destroy(c);
     DevBuf *all[] = {&c->X, &c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall,
                      &c->P, &c->Q, &c->ZtX, &c->Pw, &c->Qw, &c->wideScratch, &c->partial, &c->rlPartial, &c->redPartial,
-                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->iterState, &c->snapC, &c->snapZ, &c->snapAlpha, &c->qpIters, &c->qpPerm, &c->fsScratch,
+                     &c->gramOut, &c->gramState, &c->costDev, &c->costSlot, &c->redOut, &c->redGather, &c->listGather, &c->scalars, &c->proj, &c->projList, &c->projSegCnt, &c->Mdev, &c->alphaDev, &c->iterState, &c->snapC, &c->snapZ, &c->snapAlpha, &c->qpIters, &c->qpPerm, &c->fsScratch, &c->feat, &c->featNorm,
                      &c->qpStats, &c->qpLive, &c->slotCosts, &c->slotCounters, &c->slotStates, &c->slotCost0, &c->slotSnapP, &c->slotSaveP, &c->slotSaveGr, &c->tmpTall2, &c->redPartial2, &c->redOut2, &c->proj2, &c->projList2, &c->projSegCnt2};
     for (DevBuf *b : all) b->release();
     if (c->evFork2) (void)hipEventDestroy(c->evFork2);
@@ -694,6 +713,42 @@ int aa_set_linear_kernel(aa_ctx *h, int on)
     AA_REQUIRE(h, AA_ERR_ARG, "null ctx");
     AA_REQUIRE(!on || h->c.form == AA_FORM_DATA, AA_ERR_STATE, "aa_set_linear_kernel needs a data matrix");
     h->c.linear_kernel = on != 0;
+    return AA_OK;
+}
+
+int aa_set_rbf_features(aa_ctx *h, const double *X, long n, long p, long ld, double gamma)
+{
+    AA_REQUIRE(h && X, AA_ERR_ARG, "null argument");
+    AA_REQUIRE(n >= 1 && p >= 1 && ld >= p && p < (1L << 30), AA_ERR_ARG, "bad shape n=%ld p=%ld ld=%ld", n, p, ld);
+    AA_REQUIRE(gamma > 0.0 && gamma < 1e300, AA_ERR_ARG, "gamma must be positive");
+    Ctx *c = &h->c;
+    AA_REQUIRE(c->world == 1 && !c->force_comm, AA_ERR_STATE, "the implicit RBF kernel is single-rank");
+    AA_CHECK_HIP(hipSetDevice(c->device));
+    c->form = AA_FORM_KERNEL;                    // the kernel form of the algorithm (/k conventions, tr K)
+    c->linear_kernel = false;
+    c->implicit_kernel = 1;
+    c->rbf_gamma = gamma;
+    c->n = n;
+    c->p = n;                                    // the (virtual) kernel matrix is n x n
+    c->n_pad = round_up(n, 128);
+    c->p_pad = c->n_pad;
+    c->n_global = n;
+    c->row_offset = 0;
+    c->X.release();                              // nothing stands in for K
+    c->feat_p = p;
+    c->feat_ld = round_up(p, 2);
+    AA_CHECK(c->feat.alloc((size_t)(c->n_pad + AA_SLACK_ROWS) * c->feat_ld * sizeof(double)));
+    AA_CHECK_HIP(ctx_memset(c, c->feat.p, 0, c->feat.bytes));
+    AA_CHECK_HIP(ctx_memcpy2d(c, c->feat.p, (size_t)c->feat_ld * sizeof(double), X, (size_t)ld * sizeof(double),
+                              (size_t)p * sizeof(double), (size_t)n, hipMemcpyHostToDevice));
+    AA_CHECK(c->featNorm.alloc((size_t)(c->n_pad + AA_SLACK_ROWS) * sizeof(double)));
+    AA_CHECK(launch_rbf_norms(c));
+    c->have_data = true;
+    c->have_trace = false;
+    c->k = 0;
+    c->KP = 0;
+    c->have_state = false;
+    c->grams_valid = false;
     return AA_OK;
 }
 
@@ -754,6 +809,7 @@ int aa_set_data(aa_ctx *h, const void *X, int host_dtype, long n, long p, long l
     AA_REQUIRE(n_global >= n && row_offset >= 0 && row_offset + n <= n_global, AA_ERR_ARG, "bad shard");
     c->form = form;
     c->linear_kernel = false;
+    c->implicit_kernel = 0;
     c->n = n;
     c->p = p;
     c->n_pad = round_up(n, 128);
@@ -803,6 +859,7 @@ int aa_share_data(aa_ctx *h, const aa_ctx *owner)
     AA_REQUIRE(h && owner && h != owner, AA_ERR_ARG, "two different contexts needed");
     Ctx *c = &h->c;
     const Ctx *o = &owner->c;
+    AA_REQUIRE(!o->implicit_kernel, AA_ERR_STATE, "aa_share_data: implicit kernels are not shared");
     AA_REQUIRE(o->have_data, AA_ERR_STATE, "the owner holds no data matrix");
     AA_REQUIRE(o->device == c->device && o->dtype == c->dtype, AA_ERR_ARG,
                "aa_share_data: same device and same data type needed");
@@ -914,6 +971,7 @@ int aa_get_data(aa_ctx *h, double *out, long ld)
 {
     AA_REQUIRE(h && out, AA_ERR_ARG, "null argument");
     Ctx *c = &h->c;
+    AA_REQUIRE(!c->implicit_kernel, AA_ERR_STATE, "aa_get_data: no stored matrix behind an implicit kernel");
     AA_REQUIRE(c->have_data, AA_ERR_STATE, "no data");
     AA_REQUIRE(ld >= c->p, AA_ERR_ARG, "ld < p");
     AA_CHECK_HIP(hipSetDevice(c->device));
@@ -1300,6 +1358,7 @@ int aa_furthest_sum(aa_ctx *h, int k, long start_index, const int *exclude, int 
     AA_REQUIRE(c->have_data, AA_ERR_STATE, "no data");
     AA_REQUIRE(c->world <= 1 && !c->force_comm, AA_ERR_STATE,
                "aa_furthest_sum is single-rank (row-sharded runs pull distance columns: aa_distance_column)");
+    AA_REQUIRE(!c->implicit_kernel, AA_ERR_STATE, "aa_furthest_sum: implicit kernels pull distance columns (aa_distance_column)");
     AA_REQUIRE(k >= 1 && k <= AA_MAX_K, AA_ERR_ARG, "k = %d out of range", k);
     AA_REQUIRE(start_index >= 0 && start_index < c->n, AA_ERR_ARG, "start index %ld out of range", start_index);
     AA_REQUIRE(n_exclude >= 0 && (n_exclude == 0 || exclude), AA_ERR_ARG, "bad exclude list");
@@ -2147,6 +2206,7 @@ int aa_pass_reduce_rows(aa_ctx *h, int k, const double *A, double *out, long ldo
 {
     AA_REQUIRE(h && A && out, AA_ERR_ARG, "null argument");
     Ctx *c = &h->c;
+    AA_REQUIRE(!c->implicit_kernel, AA_ERR_STATE, "aa_pass_reduce_rows: no stored matrix behind an implicit kernel");
     AA_CHECK_HIP(hipSetDevice(c->device));
     AA_CHECK(ensure_problem(c, k));
     AA_REQUIRE(ldo >= (c->form == AA_FORM_KERNEL ? c->n : c->p), AA_ERR_ARG, "ldo too small");
@@ -2163,6 +2223,7 @@ int aa_pass_row_local(aa_ctx *h, int k, const double *B, long ldb, double *out)
 {
     AA_REQUIRE(h && B && out, AA_ERR_ARG, "null argument");
     Ctx *c = &h->c;
+    AA_REQUIRE(!c->implicit_kernel, AA_ERR_STATE, "aa_pass_row_local: no stored matrix behind an implicit kernel");
     AA_CHECK_HIP(hipSetDevice(c->device));
     AA_CHECK(ensure_problem(c, k));
     AA_REQUIRE(ldb >= c->p, AA_ERR_ARG, "ldb < p");
@@ -2220,6 +2281,7 @@ int aa_time_kernel(aa_ctx *h, int which, int reps, double *ms_avg)
 {
     AA_REQUIRE(h && ms_avg && reps >= 1, AA_ERR_ARG, "bad arguments");
     Ctx *c = &h->c;
+    AA_REQUIRE(!c->implicit_kernel, AA_ERR_STATE, "aa_time_kernel: no stored matrix behind an implicit kernel");
     AA_REQUIRE(c->have_state && c->form == AA_FORM_DATA, AA_ERR_STATE, "needs data-form state");
     AA_CHECK_HIP(hipSetDevice(c->device));
     hipEvent_t e0, e1;

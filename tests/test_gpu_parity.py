@@ -1424,3 +1424,94 @@ def test_furthest_sum_on_the_device(cdr, orc, dtype):
             want = host(ctx, 300, k, start, extra, np.asarray(exclude, dtype="i8"))
             got = ctx.furthest_sum(k, start, exclude, extra)
             assert got is not None and np.array_equal(got, want), (k, start, extra, exclude, got, want)
+
+
+# ---------------------------------------------------------------- KernelAA on an implicit RBF kernel
+def test_kernel_aa_on_the_implicit_rbf_kernel(cdr, orc):
+    """SURVEY 8(f4), the alternative it names: KernelAA on K_ij = exp(-gamma ||x_i - x_j||^2) with K
+    NEVER formed (aa_set_rbf_features: every C K / K Z is one fused distance + exp + multiply pass
+    over the features).  Against (1) the ORACLE's kernel form on the explicit matrix
+    (orc.iterate_kernel_aa, reference archetypal_analysis.py:399-531): fixed iterations from a
+    custom start at rounding level; (2) the product's own explicit-kernel path on the same matrix:
+    the estimators run to the stopping rule from FurthestSum and random starts -- same picks, same
+    n_iter, costs and factors to rounding; (3) one K V product against NumPy."""
+    from convex_dim_red import _backend
+    rng = np.random.RandomState(21)
+    n, p, k, gamma = 900, 12, 5, 0.35
+    centers = rng.standard_normal((k, p)) * 2.0
+    X = centers[rng.randint(k, size=n)] + 0.4 * rng.standard_normal((n, p))
+    sq = (X * X).sum(axis=1)
+    K = np.exp(-gamma * np.maximum(sq[:, None] + sq[None, :] - 2 * X.dot(X.T), 0.0))
+    np.fill_diagonal(K, 1.0)
+    C0 = orc.right_stochastic_matrix((k, n), rng)
+    Z0 = orc.right_stochastic_matrix((n, k), rng)
+    # (3) the product K Z through the kernel-form state of a context
+    with _backend.Context(dtype="float64") as ctx:
+        ctx.set_rbf_features(X, gamma)
+        ctx.set_state(C0, Z0, np.ones(k))
+        ctx.prepare()
+        ZtZ, CKCt, CKZ, tr = ctx.grams()
+        assert tr == float(n)
+        assert np.abs(CKCt - C0.dot(K).dot(C0.T)).max() < 1e-12 * np.abs(CKCt).max()
+        assert np.abs(CKZ - C0.dot(K).dot(Z0)).max() < 1e-12 * np.abs(CKZ).max()
+        d = ctx.distance_column(17)
+        assert np.abs(d - np.sqrt(np.maximum(2 - 2 * K[:, 17], 0))).max() < 1e-7 and d[17] == 0.0
+    # (1) fixed iterations against the oracle on the explicit matrix
+    kw = dict(tolerance=0, max_iterations=4, dictionary_solver_kwargs=dict(max_iterations=1),
+              require_monotonic_cost_decrease=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wZ, wC, _, wcost, _, _, wdeltas = orc.iterate_kernel_aa(K, Z0.copy(), C0.copy(), np.ones(k), **kw)
+        m = cdr.KernelAA(k, init="custom", tolerance=0, max_iterations=4, dictionary_solver_kwargs=dict(max_iterations=1),
+                         require_monotonic_cost_decrease=False)
+        W = m.fit_transform(X, features=True, kernel="rbf", gamma=gamma, dictionary=C0, weights=Z0, alpha=np.ones(k))
+    assert abs(m.cost - wcost) < 1e-10 * abs(wcost)
+    assert np.abs(np.asarray(m.cost_deltas) - np.asarray(wdeltas)).max() < 1e-9 * abs(wcost)
+    assert np.abs(m.dictionary - wC).max() < 1e-8 and np.abs(W - wZ).max() < 1e-5
+    _assert_simplex(W, 1e-12)
+    _assert_simplex(m.dictionary, 1e-12)
+    # (2) 25 iterations, implicit against the product's explicit-kernel path and the oracle, from the same
+    # custom start; the yardstick of a run this long is the oracle's own response to a one-ulp change
+    # of K (the explicit matrix and the fused exp differ in last bits)
+    kw25 = dict(kw, max_iterations=25)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        base = orc.iterate_kernel_aa(K, Z0.copy(), C0.copy(), np.ones(k), **kw25)
+        twins = oracle_twins(orc, lambda Kin: orc.iterate_kernel_aa(Kin, Z0.copy(), C0.copy(), np.ones(k), **kw25), K, "float64")
+        t_cost = max(abs(t[3] - base[3]) for t in twins) / abs(base[3])
+        t_C = max(np.abs(t[1] - base[1]).max() for t in twins)
+        fits = []
+        for data, extra in ((K, {}), (X, dict(features=True, kernel="rbf", gamma=gamma))):
+            m = cdr.KernelAA(k, init="custom", tolerance=0, max_iterations=25, dictionary_solver_kwargs=dict(max_iterations=1),
+                             require_monotonic_cost_decrease=False)
+            m.fit_transform(data, dictionary=C0, weights=Z0, alpha=np.ones(k), **extra)
+            fits.append(m)
+    for m in fits:
+        print("implicit RBF, 25 iterations: cost rel diff from the oracle %.2e (bound %.2e), dictionary %.2e (bound %.2e)"
+              % (abs(m.cost - base[3]) / abs(base[3]), max(1e-10, 20 * t_cost), np.abs(m.dictionary - base[1]).max(),
+                 max(1e-9, 20 * t_C)))
+        assert abs(m.cost - base[3]) <= max(1e-10, 20 * t_cost) * abs(base[3])
+        assert np.abs(m.dictionary - base[1]).max() <= max(1e-9, 20 * t_C)
+        assert np.array_equal(m.dictionary.argmax(axis=1), base[1].argmax(axis=1))
+    # FurthestSum on the implicit kernel.  Far-apart points of clustered data all sit at sqrt(2 - 2 exp(-big))
+    # = sqrt(2) to the last bits, so the picks are decided by rounding and need not be the explicit
+    # matrix's; they ARE the reference selection rule on the dissimilarities the context serves, and
+    # those agree with the explicit ones to 1e-7.
+    from convex_dim_red import archetypal_analysis as aa
+    with _backend.Context(dtype="float64") as ci:
+        ci.set_rbf_features(X, gamma)
+        D = np.stack([ci.distance_column(j) for j in range(n)], axis=1)
+        assert np.abs(D - np.sqrt(np.maximum(2 - 2 * K, 0))).max() < 1e-7
+        for start, extra_steps in ((0, 10), (123, 3)):
+            pi = aa._furthest_sum_on_device(ci, n, k, start, extra_steps, np.array([], dtype="i8"))
+            assert np.array_equal(pi, cdr.furthest_sum(D, k, start, extra_steps=extra_steps)), (start, pi)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bb = cdr.KernelAA(k, init="furthest_sum", random_state=3, tolerance=1e-5, max_iterations=40,
+                          dictionary_solver_kwargs=dict(max_iterations=1))
+        Wb = bb.fit_transform(X, features=True, kernel="rbf", gamma=gamma)
+    assert bb.cost_deltas[0] < 0 and bb.cost > 0 and Wb.shape == (n, k)
+    _assert_simplex(Wb, 1e-12)
+    _assert_simplex(bb.dictionary, 1e-12)
+    with pytest.raises(ValueError):
+        cdr.KernelAA(k).fit_transform(K, kernel="rbf")          # rbf needs features=True
