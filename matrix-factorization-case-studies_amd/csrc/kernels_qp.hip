@@ -950,7 +950,7 @@ __device__ __forceinline__ double qw_matvec_bcast(const double (&Acol)[16], doub
 // MEM1: the non-monotone memory is 1 (spg.py:310 default, and always on the continuation path): the
 // f_mem array -- 32 wave-uniform doubles, i.e. 64 SGPRs that hipcc spills to VGPR lanes around every
 // reduction -- does not exist.
-template <int KQ, bool MEM1 = false>
+template <int KQ, bool MEM1 = false, bool LAZY = true>
 __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ][KQ]*/,
                                                  const double *__restrict__ B, long stride_j,
                                                  long stride_t, const double *__restrict__ bscale,
@@ -1090,6 +1090,28 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
         }
 
         bool parked = false;
+        // The stopping test of a pass (spg.py:378-396: r = P(x - g) - x at the new point, ||r||_2 < eps_two
+        // or ||r||_inf < eps_one) costs a projection, a reduction and a compare -- a quarter of the pass --
+        // and on all but the last one or two passes of a sample its answer is "no".  Round 4: the test of
+        // pass i is decided at the top of pass i + 1, where d = P(x - alpha g) - x at the same point has
+        // just been formed: for a feasible x the projected-gradient map satisfies
+        //     ||P(x - g) - x||_2  >=  ||P(x - alpha g) - x||_2 / max(1, alpha)
+        // (||d(alpha)|| is nondecreasing and ||d(alpha)|| / alpha nonincreasing in alpha), and
+        // ||r||_inf >= ||r||_2 / sqrt(k); so  <d, d>  >  4 max(1, alpha)^2 max(eps_two^2, k eps_one^2)
+        // PROVES that neither stopping test fires (a factor 2 in the norm against rounding), and the
+        // residual projection is skipped.  Whenever the certificate fails the reference's test runs as
+        // before: same decisions, same pass counts, same iterates -- 25 % fewer instructions on the
+        // dependent chain of the longest sample.
+        const double cert = 4.0 * fmax(p.epsilon_two * p.epsilon_two, (double)k * p.epsilon_one * p.epsilon_one);
+        auto stop_test = [&]() -> bool {
+            const double tr = qw_threshold<HALF>(live ? x - g : -INFINITY, comp, support_r);
+            const double r = live ? fmax(x - g - tr, 0.0) - x : 0.0;
+            const double r2 = qw_sum<HALF>(r * r);
+            // max |r| < epsilon_one  <=>  no lane has |r| >= epsilon_one (no reduction)
+            const bool rinf_small = __ballot(!(fabs(r) < p.epsilon_one)) == 0ull;
+            return (sq_ok ? r2 < sq_lim : sqrt(r2) < p.epsilon_two) || rinf_small;
+        };
+        bool pending = false;                      // the stopping test of the previous pass is still open
         // `guard_w` bounds the loop even if the arithmetic goes non-finite
         for (int guard_w = 0; guard_w < p.max_iterations + 2; ++guard_w) {
             if (n_iter == 0) {
@@ -1106,6 +1128,11 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
             const double d = live ? fmax(x - alpha * g - td, 0.0) - x : 0.0;
             double delta, dd;
             qw_sum2<HALF>(d * g, d * d, lane, delta, dd);
+            if (pending) {
+                const double am = fmax(1.0, alpha);
+                if (!(dd > cert * am * am) && stop_test()) break;      // converged at the point the last pass left
+                pending = false;
+            }
             const double Ad = matvec(d);
             const double dAd = qw_sum<HALF>(d * Ad);
 
@@ -1141,15 +1168,16 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
             alpha = (beta <= 0.0) ? p.alpha_max : fmin(p.alpha_max, fmax(p.alpha_min, sksk / beta));
             f = f_new;
             n_feval += 1;
-
-            const double tr = qw_threshold<HALF>(live ? x - g : -INFINITY, comp, support_r);
-            const double r = live ? fmax(x - g - tr, 0.0) - x : 0.0;
-            const double r2 = qw_sum<HALF>(r * r);
-            // max |r| < epsilon_one  <=>  no lane has |r| >= epsilon_one (no reduction)
-            const bool rinf_small = __ballot(!(fabs(r) < p.epsilon_one)) == 0ull;
             n_iter += 1;
-            const bool conv = (sq_ok ? r2 < sq_lim : sqrt(r2) < p.epsilon_two) || rinf_small;
-            if (conv || n_feval > p.max_feval || n_iter >= p.max_iterations) break;
+            // the caps end the sample whatever the stopping test says (spg.py:391-396: same iterate)
+            if (n_feval > p.max_feval || n_iter >= p.max_iterations) break;
+            if constexpr (!LAZY) {                 // (A/B switch qp_wave_lazy = 0: the test after every pass, as before round 4)
+                if (stop_test()) break;
+            } else if (n_iter >= park_at) {
+                if (stop_test()) break;            // decided here: a parked sample starts its next launch clean
+            } else {
+                pending = true;
+            }
             if (n_iter >= park_at) {
                 parked = true;
                 break;
@@ -1193,8 +1221,8 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
                 QpLive lv = QpLive{0, 0, 0u, 0u, nullptr, nullptr}, int rst_b = 0, long rst_n = 0
 #define QW_PASS A, B, stride_j, stride_t, bscale, Z, ldz, n_fresh, k, p, iters, hdr, ovf_rows, ovf, zslot,           \
                 fresh_list, count_ptr, park_at, n_parked, park_rows, park, lv, rst_b, rst_n
-template <int KQ, bool MEM1 = false>
-__global__ __launch_bounds__(256) void k_qp_wave(QW_ARGS) { qp_wave_body<KQ, MEM1>(QW_PASS); }
+template <int KQ, bool MEM1 = false, bool LAZY = true>
+__global__ __launch_bounds__(256) void k_qp_wave(QW_ARGS) { qp_wave_body<KQ, MEM1, LAZY>(QW_PASS); }
 // the live consumers (QpLive mode 1): blocks of 16 waves that are launched with a whole CU's LDS
 // as (unused) dynamic shared memory while k_qp_quad asks for 1/12 of it per wave -- LDS becomes the
 // resource that keeps the two kernels on DIFFERENT CUs: the latency-bound chains of the consumers
@@ -1206,7 +1234,8 @@ __global__ __launch_bounds__(1024) void k_qp_wave_live(QW_ARGS) { qp_wave_body<3
 // continuation launches (memory == 1 by construction of the callers)
 #define QW32_LAUNCH(...)                                                              \
     do {                                                                              \
-        if (g_qp_wave_mem1) hipLaunchKernelGGL((k_qp_wave<32, true>), __VA_ARGS__);   \
+        if (g_qp_wave_mem1 && g_qp_wave_lazy) hipLaunchKernelGGL((k_qp_wave<32, true, true>), __VA_ARGS__);  \
+        else if (g_qp_wave_mem1) hipLaunchKernelGGL((k_qp_wave<32, true, false>), __VA_ARGS__);   \
         else hipLaunchKernelGGL((k_qp_wave<32, false>), __VA_ARGS__);                 \
     } while (0)
 
@@ -2154,6 +2183,7 @@ int g_qp_live_blocks = 48;     // CUs given to the consumers (one block of 16 wa
 #define QP_LIVE_LDS 163840     // a CU's LDS
 int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)
 int g_qp_prefetch_order = 0;   // four-lane QP, opt-in: the sample order of the NEXT update (by this update's pass counts) is formed on the side stream right after this one, beside the Z'X pass -- 25 us of kernels off the critical path, but the fork and the join cost two ~6 us bubbles on the main stream and the ordering kernels run 3 x slower beside the pass: 488-490 it/s with, 489-491 without (profiles/round4_ab.txt)
+int g_qp_wave_lazy = 1;        // wave-per-sample kernel: stopping test of a pass decided at the top of the next one, skipped when <d, d> proves it negative (0: after every pass)
 int g_qp_wave_mem1 = 1;        // continuation launches of the wave-per-sample kernel: 1 = the memory-1 instantiation (no f_mem array: 311 fewer SGPR spills), 0 = the generic one (A/B)
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
 int g_qp_tail_cap = 96;        // with qp_overlap_tail: only samples beyond this many passes go to the side stream (0: all parked ones)

@@ -562,6 +562,8 @@ int aa_set_option(const char *name, int value)
         g_qp_prefetch_order = value != 0;
     } else if (!strcmp(name, "grad_side")) {
         g_grad_side = value != 0;
+    } else if (!strcmp(name, "qp_wave_lazy")) {
+        g_qp_wave_lazy = value != 0;
     } else if (!strcmp(name, "qp_wave_mem1")) {
         g_qp_wave_mem1 = value != 0;
     } else if (!strcmp(name, "qp_overlap_tail")) {
