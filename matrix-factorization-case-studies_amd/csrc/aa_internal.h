@@ -130,6 +130,8 @@ struct ProjState {          // per projection, device memory
     // deferred to the next point where the host reads device state anyway (sticky flag).
     int overflow_sticky;          // set when any column of any projection was left unconverged
     int list_max[4];              // longest gathered list (over the columns) of the last projection per kind
+    int fin_arrived;              // blocks of the running first / finish pass that have written their partials
+                                  // (FinTail: the last one finalizes and puts it back to 0)
 };
 
 #define AA_SC_STRIDE 64      // doubles per slot of the per-slot scalar blocks (>= SC_COUNT)
@@ -174,8 +176,7 @@ struct Ctx {
     // the residual projection of the dictionary SPG (spg.py:250-276: convergence flags only) runs on
     // the side stream beside the weights QP, on its own scratch set (launch_proj_side / join_side)
     hipEvent_t evFork2 = nullptr, evJoin2 = nullptr;
-    hipEvent_t evOrderFork = nullptr, evOrder = nullptr;   // sample order of the NEXT weights QP, formed on the side stream
-    bool qp_perm_ready = false;                // qpPerm holds (or will hold, after evOrder) the order by the pass counts in qpIters
+    bool qp_perm_ready = false;                // the previous QP launch of this context left the order of the next one in qpPerm (k_qp_wave_ord)
     long qp_perm_n = 0;
     bool side_pending = false;
     DevBuf tmpTall2, redPartial2, redOut2, proj2, projList2, projSegCnt2;
@@ -273,7 +274,8 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
 enum { PROJ_FEAS = 0, PROJ_ALPHA = 1, PROJ_DIR = 2, PROJ_RES = 3 };
 int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, double scale,
                 const double *d_for_dot /*nullable*/, int dot_slot, double *xupd = nullptr,
-                const aa_spg_params *sp = nullptr, int stage_after = -1);
+                const aa_spg_params *sp = nullptr, int stage_after = -1,
+                const aa_spg_params *setup_sp = nullptr /* the update's set-up as block 0 */, double setup_fnorm = 0.0);
 int launch_tall_axpy_lambda(Ctx *c, double *x, const double *d);             // x += lambda * d
 int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const double *alpha_dev,
                            int slot);   // sum x*H*alpha (alpha_dev nullable => 1)
@@ -360,6 +362,7 @@ inline hipError_t ctx_memset(Ctx *c, void *dst, int value, size_t nbytes)
 }
 bool side_available(const Ctx *c);  // side stream + second scratch set usable (single rank, fused stages)
 int side_begin(Ctx *c);            // launch_* calls go to the side stream (own scratch set) until side_end
+int side_begin_behind(Ctx *c);
 int side_end(Ctx *c);
 extern int g_proj_res_side, g_grad_side;
 int proj_poll_multirank(Ctx *c);   // multi-rank: read the deferred overflow flag / list lengths (host sync point)   // multi-rank: row j -> wideScratch on every rank
@@ -410,7 +413,7 @@ extern int g_qp_refill_min;       // kernels_qp.hip
 extern int g_qp_waves;            // kernels_qp.hip
 extern int g_qp_sort;             // kernels_qp.hip
 extern int g_qp_profile;          // kernels_qp.hip
-extern int g_qp_wave_mem1, g_qp_prefetch_order, g_qp_wave_lazy;
+extern int g_qp_wave_mem1, g_qp_fused_order, g_qp_wave_lazy, g_fin_in_last, g_gram_side, g_setup_in_grad;
 extern int g_qp_overlap_tail, g_qp_tail_cap, g_qp_live, g_qp_live_blocks, g_qp_live_occ;     // kernels_qp.hip
 
 // ------------------------------------------------------------------ comm.hip

@@ -966,8 +966,9 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
                                                  int *__restrict__ park_rows = nullptr,
                                                  QpCarry *__restrict__ park = nullptr,
                                                  QpLive lv = QpLive{0, 0, 0u, 0u, nullptr, nullptr},
-                                                 int rst_b = 0, long rst_n = 0)
+                                                 int rst_b = 0, long rst_n = 0, unsigned int blk0 = 0u)
 {
+    // blk0: the first blk0 blocks of the grid do something else (k_qp_wave_ord)
     if (gridDim.y > 1) {                               // restarts side by side: blockIdx.y = slot
         const int rst = blockIdx.y;
         A += (long)rst * KQ * KQ;
@@ -1011,8 +1012,8 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
                                          : (fresh_list ? hdr->n_long : (fresh ? (unsigned int)n_fresh : hdr->n_overflow));
 
     const unsigned int wave_id =
-        (unsigned int)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    const unsigned int n_waves = gridDim.x * (blockDim.x >> 6);
+        (unsigned int)__builtin_amdgcn_readfirstlane((int)((blockIdx.x - blk0) * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const unsigned int n_waves = (gridDim.x - blk0) * (blockDim.x >> 6);
     unsigned long long wv_total = 0ull;      // pass statistics of this wave: one atomic pair at exit
     int wv_max = 0;
     unsigned int static_slot = wave_id;
@@ -1861,6 +1862,7 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
         ovf += rst * rst_n;
         if (iters) iters += rst * rst_n;
     }
+    if (perm && hdr->pad1 == 0u) perm = nullptr;    // the order of k_qp_wave_ord did not complete (k_qp_setup)
     constexpr int J = 4 * MT;
     const int lane = threadIdx.x, sl = lane & 15, q = lane >> 4;
     bool sq_ok;
@@ -2099,6 +2101,9 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
                             cr.n_iter = n_iter;
                             cr.n_feval = n_feval;
                             ovf[slot] = cr;
+                            // "at least the cap": what the ordering blocks of k_qp_wave_ord may read
+                            // before the wave that finishes this sample has written the final count
+                            if (iters) iters[row] = n_iter;
                         }
                     }
                 }
@@ -2182,7 +2187,7 @@ int g_qp_live_occ = 3;         // register budget of k_qp_quad beside the consum
 int g_qp_live_blocks = 48;     // CUs given to the consumers (one block of 16 waves each)
 #define QP_LIVE_LDS 163840     // a CU's LDS
 int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)
-int g_qp_prefetch_order = 0;   // four-lane QP, opt-in: the sample order of the NEXT update (by this update's pass counts) is formed on the side stream right after this one, beside the Z'X pass -- 25 us of kernels off the critical path, but the fork and the join cost two ~6 us bubbles on the main stream and the ordering kernels run 3 x slower beside the pass: 488-490 it/s with, 489-491 without (profiles/round4_ab.txt)
+int g_qp_fused_order = 1;   // four-lane QP: the sample order of the NEXT update is formed by extra blocks of this update's continuation launch (k_qp_wave_ord)
 int g_qp_wave_lazy = 1;        // wave-per-sample kernel: stopping test of a pass decided at the top of the next one, skipped when <d, d> proves it negative (0: after every pass)
 int g_qp_wave_mem1 = 1;        // continuation launches of the wave-per-sample kernel: 1 = the memory-1 instantiation (no f_mem array: 311 fewer SGPR spills), 0 = the generic one (A/B)
 int g_qp_overlap_tail = 0;     // 1: stragglers on a side stream, overlapped with the Z'X pass
@@ -2262,17 +2267,111 @@ __global__ __launch_bounds__(256) void k_qp_order_scatter(const int *__restrict_
         if (bk[j] >= 0) perm[atomicAdd(&cursor[bk[j]], 1)] = (int)(r0 + t + 256 * j);
 }
 
+// The same counting sort as extra blocks of the continuation launch (k_qp_wave_ord): the order the
+// NEXT update's k_qp_quad takes its samples in is formed while this update's stragglers run, off the
+// critical path (the two ordering launches above cost 33 us per update in front of k_qp_quad, on a
+// chip that idles).  A sample's bucket is read ONCE, into a register, and serves both the histogram
+// and the scatter, so the order is a permutation whatever the concurrent waves of this launch write
+// to the pass counts of the parked samples meanwhile (k_qp_quad leaves "the cap" there, the wave that
+// finishes the sample the final count: the head of the list either way).  area: [64] histogram,
+// [64] cursors, [0] blocks past the histogram, [1] blocks past the scatter -- zeroed by k_qp_setup,
+// which also turns [1] == blocks of the PREVIOUS update into QpHeader::pad1 (order complete: use it).
+// The blocks are the first of the grid, hence resident together; a wait that does not end (it cannot,
+// short of a dead chip) gives up after 2 ms and the next update runs unordered.
+struct QpOrder {
+    const int *iters;
+    int *perm, *area;
+    long n;
+    int blocks;
+};
+#define QP_ORDER_AREA (2 * QP_SORT_BUCKETS + 4)
+#define QP_ORDER_MAX_BLOCKS 256
+
+__device__ __forceinline__ void qp_order_block(const QpOrder &od)
+{
+    __shared__ int hist[QP_SORT_BUCKETS], cursor[QP_SORT_BUCKETS], ok;
+    int *ghist = od.area, *gcursor = od.area + QP_SORT_BUCKETS, *flags = od.area + 2 * QP_SORT_BUCKETS;
+    const int t = threadIdx.x;
+    if (t < QP_SORT_BUCKETS) hist[t] = 0;
+    __syncthreads();
+    const long r0 = (long)blockIdx.x * QP_SORT_ROWS_PER_BLOCK;
+    int bk[QP_SORT_ROWS_PER_BLOCK / 256];
+#pragma unroll
+    for (int j = 0; j < QP_SORT_ROWS_PER_BLOCK / 256; ++j) {
+        const long r = r0 + t + 256 * j;
+        bk[j] = r < od.n ? qp_sort_bucket(od.iters[r]) : -1;
+        if (bk[j] >= 0) atomicAdd(&hist[bk[j]], 1);
+    }
+    __syncthreads();
+    if (t < QP_SORT_BUCKETS && hist[t]) atomicAdd(&ghist[t], hist[t]);
+    __threadfence();
+    __syncthreads();
+    if (t == 0) {
+        __hip_atomic_fetch_add(&flags[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = (long long)wall_clock64();         // 100 MHz
+        int good = 1;
+        while (__hip_atomic_load(&flags[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < od.blocks) {
+            if ((long long)wall_clock64() - t0 > 200000ll) { good = 0; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        ok = good;
+    }
+    __syncthreads();
+    if (!ok) return;
+    if (t < QP_SORT_BUCKETS) {
+        int base = 0;
+        for (int b = QP_SORT_BUCKETS - 1; b > t; --b)
+            base += __hip_atomic_load(&ghist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cursor[t] = base + (hist[t] ? atomicAdd(&gcursor[t], hist[t]) : 0);   // this block's range
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < QP_SORT_ROWS_PER_BLOCK / 256; ++j)
+        if (bk[j] >= 0) od.perm[atomicAdd(&cursor[bk[j]], 1)] = (int)(r0 + t + 256 * j);
+    __threadfence();
+    __syncthreads();
+    if (t == 0) __hip_atomic_fetch_add(&flags[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// continuation launch of k_qp_wave<32, true, LAZY> (the overflow list of k_qp_quad) with od.blocks
+// ordering blocks in front
+template <bool LAZY>
+__global__ __launch_bounds__(256) void k_qp_wave_ord(QpOrder od, const double *__restrict__ A,
+                                                     const double *__restrict__ B, long stride_j, long stride_t,
+                                                     const double *__restrict__ bscale, double *__restrict__ Z,
+                                                     int ldz, int k, aa_qp_params p, int *__restrict__ iters,
+                                                     QpHeader *__restrict__ hdr, const int *__restrict__ ovf_rows,
+                                                     const QpCarry *__restrict__ ovf)
+{
+    if ((int)blockIdx.x < od.blocks) {
+        qp_order_block(od);
+        return;
+    }
+    qp_wave_body<32, true, LAZY>(A, B, stride_j, stride_t, bscale, Z, ldz, (long)-1, k, p, iters, hdr, ovf_rows, ovf,
+                                 (double *)nullptr, (const int *)nullptr, (const unsigned int *)nullptr, 1 << 30,
+                                 (unsigned int *)nullptr, (int *)nullptr, (QpCarry *)nullptr,
+                                 QpLive{0, 0, 0u, 0u, nullptr, nullptr}, 0, 0L, (unsigned int)od.blocks);
+}
+
 // device-side set-up of the QP scratch: header zeroed, A = D G D padded to KQ and KW,
 // b-scale = D.  One block.
 __global__ __launch_bounds__(256) void k_qp_setup(QpHeader *__restrict__ hdr, double *__restrict__ Ad,
                                                   double *__restrict__ A2d, double *__restrict__ bsd,
                                                   const double *__restrict__ gram,
                                                   const double *__restrict__ alpha, int k, int KQ,
-                                                  int KW, int KP, int *__restrict__ sort_hist)
+                                                  int KW, int KP, int *__restrict__ sort_hist,
+                                                  int order_blocks = 0)
 {
     const int t = threadIdx.x;
-    if (sort_hist && t < 2 * QP_SORT_BUCKETS) sort_hist[t] = 0;   // histogram + cursors of qp_order_rows
+    // order_blocks: the ordering blocks the previous update's k_qp_wave_ord ran with -- all of them through?
+    __shared__ int order_ok;
+    if (t == 0)
+        order_ok = order_blocks < 0 ? 1     // (an order, if any, comes from the ordering launches in stream order)
+                                    : ((sort_hist && order_blocks > 0 && sort_hist[2 * QP_SORT_BUCKETS + 1] == order_blocks) ? 1 : 0);
+    __syncthreads();
+    if (sort_hist && t < QP_ORDER_AREA) sort_hist[t] = 0;   // histogram + cursors (+ flags) of the ordering
     if (t == 0) {
+        hdr->pad1 = (unsigned int)order_ok;
         hdr->total_passes = 0ull;
         hdr->max_passes = 0ull;
         hdr->next_row = 0u;
@@ -2298,7 +2397,7 @@ __global__ __launch_bounds__(256) void k_qp_setup(QpHeader *__restrict__ hdr, do
 static int qp_order_rows(Ctx *c, const int *iters_dev, long n, const int **perm_out,
                          QpHeader *hdr = nullptr, int long_from = 0, bool zeroed = false)
 {
-    AA_CHECK(c->qpPerm.alloc((size_t)n * sizeof(int) + 2 * QP_SORT_BUCKETS * sizeof(int)));
+    AA_CHECK(c->qpPerm.alloc((size_t)n * sizeof(int) + QP_ORDER_AREA * sizeof(int)));
     int *pm = c->qpPerm.as<int>();
     int *ghist = pm + n, *gcursor = ghist + QP_SORT_BUCKETS;
     if (!zeroed) AA_CHECK_HIP(hipMemsetAsync(ghist, 0, 2 * QP_SORT_BUCKETS * sizeof(int), c->stream));
@@ -2504,11 +2603,19 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     const bool will_sort = g_qp_sort && p->max_iterations > 2 && n > 4096 && !wave_only && iters_dev &&
                            iters_dev == c->qpIters.as<int>() && c->qp_iters_valid;
     int *sort_hist = nullptr;
-    // the order formed ahead of time on the side stream (end of the previous call, below)
-    const bool prefetched = c->qp_perm_ready;
-    const bool use_prefetched = prefetched && will_sort && quad_mode && c->qp_perm_n == n && !A_host;
+    // four-lane kernel: the order is formed by extra blocks of the PREVIOUS update's continuation launch
+    // (k_qp_wave_ord) and this update's launch forms the next one; an update without a predecessor runs
+    // unordered
+    int quad_cap = g_qp_quad_cap > 0 ? g_qp_quad_cap : (n >= 65536 ? 32 : 24);
+    if (p->memory > 1 || p->max_iterations <= quad_cap) quad_cap = p->max_iterations;
+    const bool fused_order = g_qp_fused_order && g_qp_sort && quad_mode && !A_host && KW == 32 && p->memory <= 1 &&
+                             g_qp_wave_mem1 && !g_qp_live && !defer_tail && quad_cap < p->max_iterations &&
+                             p->max_iterations > 2 && n > 4096 &&
+                             n <= (long)QP_ORDER_MAX_BLOCKS * QP_SORT_ROWS_PER_BLOCK && iters_dev &&
+                             iters_dev == c->qpIters.as<int>();
+    const int order_blocks = (int)((n + QP_SORT_ROWS_PER_BLOCK - 1) / QP_SORT_ROWS_PER_BLOCK);
+    const bool use_prefetched = fused_order && c->qp_perm_ready && c->qp_perm_n == n;
     c->qp_perm_ready = false;
-    if (prefetched) AA_CHECK_HIP(hipStreamWaitEvent(c->stream, c->evOrder, 0));   // used or dropped: qpPerm is ours again
     if (A_host) {
         std::vector<unsigned char> host(off_rows, 0);
         double *Ah = reinterpret_cast<double *>(host.data() + off_A);
@@ -2520,19 +2627,21 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
             }
         double *bs = reinterpret_cast<double *>(host.data() + off_bs);
         for (int i = 0; i < 64; ++i) bs[i] = (bscale_host && i < k) ? bscale_host[i] : 1.0;
+        reinterpret_cast<QpHeader *>(host.data())->pad1 = 1u;      // an order, if any, is formed in stream order
         AA_CHECK_HIP(hipMemcpyAsync(c->qpStats.p, host.data(), off_rows, hipMemcpyHostToDevice, c->stream));
         AA_CHECK_HIP(hipStreamSynchronize(c->stream));   // host vector goes out of scope
     } else {
         AA_REQUIRE(gram_dev != nullptr, AA_ERR_ARG, "QP: no Hessian");
-        if (will_sort && !use_prefetched) {            // its histograms are zeroed by the set-up kernel
-            AA_CHECK(c->qpPerm.alloc((size_t)n * sizeof(int) + 2 * QP_SORT_BUCKETS * sizeof(int)));
+        if (will_sort || fused_order) {                // its histograms are zeroed by the set-up kernel
+            AA_CHECK(c->qpPerm.alloc((size_t)n * sizeof(int) + QP_ORDER_AREA * sizeof(int)));
             sort_hist = c->qpPerm.as<int>() + n;
         }
         unsigned char *b0 = reinterpret_cast<unsigned char *>(c->qpStats.p);
         hipLaunchKernelGGL(k_qp_setup, dim3(1), dim3(256), 0, c->stream, reinterpret_cast<QpHeader *>(b0),
                            reinterpret_cast<double *>(b0 + off_A), reinterpret_cast<double *>(b0 + off_A2),
                            reinterpret_cast<double *>(b0 + off_bs), gram_dev,
-                           (const double *)c->alphaDev.as<double>(), k, KQ, KW, c->KP, sort_hist);
+                           (const double *)c->alphaDev.as<double>(), k, KQ, KW, c->KP, sort_hist,
+                           fused_order ? (use_prefetched ? order_blocks : 0) : -1);
     }
     unsigned char *base = reinterpret_cast<unsigned char *>(c->qpStats.p);
     QpHeader *hdr = reinterpret_cast<QpHeader *>(base);
@@ -2640,7 +2749,7 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         }
         // (the ordering kernels run while the cross-stream dependency of the consumers resolves: the
         // consumers are resident on their CUs before k_qp_quad fills the chip)
-        if (use_prefetched) perm = c->qpPerm.as<int>();
+        if (fused_order) perm = use_prefetched ? c->qpPerm.as<int>() : nullptr;   // (the kernel checks QpHeader::pad1)
         else if (will_sort) AA_CHECK(qp_order_rows(c, iters_dev, n, &perm, nullptr, 0, sort_hist != nullptr));
         const int quad_occ = live ? g_qp_live_occ : g_qp_quad_occ;
         // beside live consumers every wave of k_qp_quad asks for its share of a CU's LDS (see k_qp_wave_live)
@@ -2705,6 +2814,20 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                     s2 = c->stream2;
                     zslot = c->tmpTall.as<double>();
                 }
+                if (fused_order && !defer) {
+                    const QpOrder od{iters_dev, c->qpPerm.as<int>(), c->qpPerm.as<int>() + n, n, order_blocks};
+                    const dim3 og((unsigned)(g_qp_wave_blocks + order_blocks));
+                    if (g_qp_wave_lazy)
+                        hipLaunchKernelGGL(k_qp_wave_ord<true>, og, dim3(256), 0, s2, od, A2d, Btall, stride_j, stride_t,
+                                           bsd, Ztall, ldz, k, *p, iters_dev, hdr, (const int *)ovf_rows,
+                                           (const QpCarry *)ovf);
+                    else
+                        hipLaunchKernelGGL(k_qp_wave_ord<false>, og, dim3(256), 0, s2, od, A2d, Btall, stride_j, stride_t,
+                                           bsd, Ztall, ldz, k, *p, iters_dev, hdr, (const int *)ovf_rows,
+                                           (const QpCarry *)ovf);
+                    c->qp_perm_ready = true;
+                    c->qp_perm_n = n;
+                } else
                 QW32_LAUNCH(dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, s2, A2d, Btall, stride_j,
                                    stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                    (const int *)ovf_rows, (const QpCarry *)ovf, zslot);
@@ -2715,25 +2838,6 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                     c->qp_tail_count = &hdr->n_overflow;
                 }
             }
-        }
-        // the order of the NEXT update by the pass counts of this one: on the side stream, behind this
-        // update's kernels, beside the Z'X pass
-        if (g_qp_prefetch_order && g_qp_sort && !A_host && !stats && !live && !defer_tail && c->stream2 && c->world <= 1 &&
-            !c->force_comm && p->max_iterations > 2 && n > 4096 && iters_dev && iters_dev == c->qpIters.as<int>()) {
-            if (!c->evOrder) {
-                AA_CHECK_HIP(hipEventCreateWithFlags(&c->evOrderFork, hipEventDisableTiming));
-                AA_CHECK_HIP(hipEventCreateWithFlags(&c->evOrder, hipEventDisableTiming));
-            }
-            AA_CHECK_HIP(hipEventRecord(c->evOrderFork, c->stream));
-            AA_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->evOrderFork, 0));
-            const int *unused = nullptr;
-            std::swap(c->stream, c->stream2);
-            const int rc = qp_order_rows(c, iters_dev, n, &unused, nullptr, 0, false);
-            std::swap(c->stream, c->stream2);
-            AA_CHECK(rc);
-            AA_CHECK_HIP(hipEventRecord(c->evOrder, c->stream2));
-            c->qp_perm_ready = true;
-            c->qp_perm_n = n;
         }
     } else if (wave_only) {
         long blocks = (n + 3) / 4;

@@ -29,9 +29,21 @@ namespace aa {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- helpers
+__device__ __forceinline__ void store_agent(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// agent: the block's results go out with agent-scope stores, drained before the closing barrier (FinTail)
 template <int KP, int NV, int NT = 256>
 __device__ __forceinline__ void block_col_combine(const double (&v)[NV], unsigned max_mask,
-                                                  double *sm, double *dst)
+                                                  double *sm, double *dst, bool agent = false)
 {
     constexpr int RS = NT / KP;
     const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
@@ -46,7 +58,12 @@ __device__ __forceinline__ void block_col_combine(const double (&v)[NV], unsigne
         } else {
             for (int q = 1; q < RS; ++q) s += sm[a * NT + q * KP + comp];
         }
-        dst[a * KP + comp] = s;
+        if (agent) {
+            store_agent(&dst[a * KP + comp], s);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            dst[a * KP + comp] = s;
+        }
     }
     __syncthreads();
 }
@@ -68,11 +85,59 @@ enum { POST_NONE = -1, POST_COLMAX = 0, POST_MICHELOT, POST_FIN, POST_SCALAR_SUM
 #define FIN_NT 1024
 __device__ void post_step(int kind, int mode, const double *__restrict__ red, int KP, int k,
                           ProjState *__restrict__ ps, double *__restrict__ scal, int slot);
-__device__ __forceinline__ void finalize_sum_block(const double *__restrict__ partial, int nb, int NV,
+template <bool AGENT = false>
+__device__ __forceinline__ void finalize_sum_block(const double *partial, int nb, int NV,
                                                    int KP, unsigned max_mask, double *__restrict__ red,
                                                    double *sm, double *__restrict__ gather, int rank,
                                                    int world);
 __device__ void scalar_stage_simple(int stage, double *__restrict__ sc, const aa_spg_params &sp);
+__device__ void post_step_slots(int kind, int mode, const double *__restrict__ red, int KP, int kslot, int R,
+                                ProjState *__restrict__ ps, double *__restrict__ scal, int slot, int stage_after,
+                                const aa_spg_params &sp);
+
+// The second reduction stage of a pass (k_finalize_sum's work) done by the LAST block of the pass to
+// arrive instead of by a launch of its own: one launch, ~6 us of dependent-launch latency, less per
+// reduction -- four of them sit in front of the Z'X pass of every dictionary update.  Single rank only
+// (the multi-rank stage has a collective in the middle).  Every block writes its partials with
+// agent-scope stores and drains them (the XCDs' L2s are not coherent with each other; a full release
+// fence -- an L2 write-back per block, of the pass's whole output -- cost 100 us per pass), counts
+// itself in; the block that counts last reads all partials with agent-scope loads in the fixed order
+// of finalize_sum_block, so the bits do not depend on which block that was.
+struct FinTail {
+    int on;                 // 0: the caller launches k_finalize_sum
+    int NV;
+    unsigned max_mask;
+    double *red;
+    int kind, mode, k;
+    ProjState *ps;          // (its fin_arrived is the counter)
+    double *scal;
+    int slot, stage_after;
+    aa_spg_params sp;
+    int kslot, R;
+};
+
+template <int KP>
+__device__ __forceinline__ void fin_tail(const FinTail &ft, const double *__restrict__ partial, double *sm /* 4 * FIN_NT */)
+{
+    // (block_col_combine(agent) has drained this block's partials and closed with a barrier)
+    __shared__ int fin_last;
+    if (threadIdx.x == 0)
+        fin_last = __hip_atomic_fetch_add(&ft.ps->fin_arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                   (int)gridDim.x - 1;
+    __syncthreads();
+    if (!fin_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(&ft.ps->fin_arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    finalize_sum_block<true>(partial, (int)gridDim.x, ft.NV, KP, ft.max_mask, ft.red, sm, (double *)nullptr, 0, 1);
+    if (ft.kslot > 0 && (ft.kind == POST_FIN || ft.kind == POST_SCALAR_SUM)) {
+        post_step_slots(ft.kind, ft.mode, ft.red, KP, ft.kslot, ft.R, ft.ps, ft.scal, ft.slot, ft.stage_after, ft.sp);
+        return;
+    }
+    if (ft.kind != POST_NONE) post_step(ft.kind, ft.mode, ft.red, KP, ft.k, ft.ps, ft.scal, ft.slot);
+    if (ft.stage_after >= 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) scalar_stage_simple(ft.stage_after, ft.scal, ft.sp);
+    }
+}
 
 // ---------------------------------------------------------------- projection passes
 // w[r][i] = x[r][i] - a * g[r][i]   (g == nullptr => w = x)
@@ -144,11 +209,12 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_finish(int mode, const double 
                                                      const double *__restrict__ H,
                                                      const double *__restrict__ alpha, long n,
                                                      long rows_pb, int k,
-                                                     const ProjState *__restrict__ ps,
+                                                     const ProjState *ps,
                                                      double *__restrict__ out,
-                                                     double *__restrict__ partial, int kslot = 0,
-                                                     unsigned colmask = 0xffffffffu)
+                                                     double *__restrict__ partial, int kslot,
+                                                     unsigned colmask, FinTail ft)
 {
+    static_assert(PROJ_NT == FIN_NT, "fin_tail: the last block runs finalize_sum_block");
     __shared__ double sm[4 * PROJ_NT];
     constexpr int RS = PROJ_NT / KP;
     const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
@@ -186,7 +252,8 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_finish(int mode, const double 
             }
         }
     }
-    block_col_combine<KP, 4, PROJ_NT>(v, 8u, sm, partial + (size_t)blockIdx.x * 4 * KP);
+    block_col_combine<KP, 4, PROJ_NT>(v, 8u, sm, partial + (size_t)blockIdx.x * 4 * KP, ft.on != 0);
+    if (ft.on) fin_tail<KP>(ft, partial, sm);
 }
 
 // ---------------------------------------------------------------- candidate-list projection
@@ -205,11 +272,11 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_first(const double *__restrict
                                                     const double *__restrict__ g, double a_const,
                                                     const double *__restrict__ scal, int a_slot,
                                                     long n, long rows_pb, int k, int warm_slot,
-                                                    const ProjState *__restrict__ ps,
+                                                    const ProjState *ps,
                                                     double *__restrict__ wout,
-                                                    double *__restrict__ partial, int kslot = 0)
+                                                    double *__restrict__ partial, int kslot, FinTail ft)
 {
-    __shared__ double sm[3 * PROJ_NT];
+    __shared__ double sm[4 * PROJ_NT];
     constexpr int RS = PROJ_NT / KP;
     const int t = threadIdx.x, comp = t % KP, rsub = t / KP;
     const double a = load_a(a_const, scal, a_slot, comp, kslot);
@@ -230,7 +297,8 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_first(const double *__restrict
             }
         }
     }
-    block_col_combine<KP, 3, PROJ_NT>(v, 1u, sm, partial + (size_t)blockIdx.x * 3 * KP);
+    block_col_combine<KP, 3, PROJ_NT>(v, 1u, sm, partial + (size_t)blockIdx.x * 3 * KP, ft.on != 0);
+    if (ft.on) fin_tail<KP>(ft, partial, sm);
 }
 
 // candidates {w > t_lower}: thread (rsub, comp) of block b appends its own rows, in row
@@ -824,7 +892,8 @@ __device__ void post_step_slots(int kind, int mode, const double *__restrict__ r
 
 // partial [nb][NV][KP] -> red [NV][KP], fixed order; all FIN_NT threads of one block; sm holds
 // 4 * FIN_NT doubles.  `gather`: multi-rank slot buffer (see k_finalize_sum).
-__device__ __forceinline__ void finalize_sum_block(const double *__restrict__ partial, int nb, int NV,
+template <bool AGENT>     // AGENT: the partials were written by blocks of THIS launch (FinTail): agent-scope loads
+__device__ __forceinline__ void finalize_sum_block(const double *partial, int nb, int NV,
                                                    int KP, unsigned max_mask, double *__restrict__ red,
                                                    double *sm, double *__restrict__ gather, int rank,
                                                    int world)
@@ -844,8 +913,11 @@ __device__ __forceinline__ void finalize_sum_block(const double *__restrict__ pa
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const bool is_max = (max_mask >> a) & 1u;
-                val[u][a] = (a < NV && b < nb) ? partial[((size_t)b * NV + a) * KP + comp]
-                                               : (is_max ? -INFINITY : 0.0);
+                if (a < NV && b < nb)
+                    val[u][a] = AGENT ? load_agent(&partial[((size_t)b * NV + a) * KP + comp])
+                                      : partial[((size_t)b * NV + a) * KP + comp];
+                else
+                    val[u][a] = is_max ? -INFINITY : 0.0;
             }
         }
 #pragma unroll
@@ -931,6 +1003,55 @@ __global__ __launch_bounds__(256) void k_post(int kind, int mode, double *__rest
     }
 }
 
+// ---------------------------------------------------------------- dictionary set-up (one block)
+// Everything a dictionary update needs from the Gram state (after the previous weights
+// update leaves: Z'Z, C K C', C K Z in the Gram state): M = D Z'Z D
+// (archetypal_analysis.py:310,330), gram[0] = C K C', the scalars, tr(C H D) = sum_i
+// alpha_i (C K Z)_ii, and f(x) (spg.py:153-157) -- one block instead of seven launches.  Its own
+// launch (k_dict_setup) or block 0 of the update's first gradient launch (k_grad, DictSetup).
+__device__ double block_trace_MG(const double *__restrict__ M, const double *__restrict__ G, int k,
+                                 int KP, bool transposed, double *sm);
+struct DictSetup {
+    int on;
+    const double *state;     // ZtZ | CKCt | CKZ
+    double trace, fnorm;
+    double *Mout, *gram, *sc;
+    aa_spg_params sp;
+};
+__device__ __forceinline__ void dict_setup_body(const double *__restrict__ state, const double *__restrict__ alpha,
+                                                int k, int KP, double trace, double fnorm, double *__restrict__ Mout,
+                                                double *__restrict__ gram, double *__restrict__ sc,
+                                                const aa_spg_params &sp, double *sm /* 256 */)
+{
+    const int GS = KP * KP, t = threadIdx.x;
+    const double *ZtZ = state, *CKCt = state + GS, *CKZ = state + 2 * GS;
+    for (int e = t; e < GS; e += 256) {
+        const int i = e / KP, j = e % KP;
+        Mout[e] = (i < k && j < k) ? alpha[i] * ZtZ[e] * alpha[j] : 0.0;
+        gram[e] = CKCt[e];
+    }
+    __syncthreads();
+    const double a0 = block_trace_MG(Mout, gram, k, KP, false, sm);
+    sm[t] = t < k ? alpha[t] * CKZ[t * KP + t] : 0.0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) sm[t] += sm[t + o];
+        __syncthreads();
+    }
+    if (t == 0) {
+        sc[SC_TRACE] = trace;
+        sc[SC_FNORM] = fnorm;
+        sc[SC_S1] = sm[0];
+        sc[SC_A0] = a0;
+        sc[SC_F_OLD] = 0.5 * (trace - 2.0 * sm[0] + a0) / fnorm;
+        sc[SC_NFEVAL] = 1.0;
+        sc[SC_FLAGS] = 0.0;
+        for (int i = 0; i < 16; ++i) sc[SC_FMEM0 + i] = 0.0;   // f_mem = zeros (spg.py:153)
+        sc[SC_ALPHA_SET] = (sp.alpha0 >= 0.0) ? 1.0 : 0.0;
+        sc[SC_ALPHA] = sp.alpha0;
+    }
+}
+
 // ---------------------------------------------------------------- gradient
 // g[r][i] = (sum_j M[i][j] * Graw[r][j] - H[r][i] * alpha[i]) * scale
 //   data form:   Graw = (C X X')', H = XX'Z, scale = 1/n   (archetypal_analysis.py:293-301)
@@ -950,22 +1071,34 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
                                               const double *__restrict__ d,
                                               double *__restrict__ partial,
                                               double *__restrict__ xupd,
-                                              const double *__restrict__ scalw, int kslot = 0, int nslot = 0)
+                                              const double *__restrict__ scalw, int kslot, int nslot,
+                                              DictSetup ds)
 {
     constexpr int T = KP / 16;       // component tiles
     constexpr int S = KP / 4;        // contraction steps
     __shared__ double sm[256];
+    // ds.on: the update's set-up (M, the scalars, f(x)) is block 0 of this launch, beside the row blocks,
+    // which form their operand tiles of M = D Z'Z D from the Gram state themselves (the same products)
+    if (ds.on && blockIdx.x == 0) {
+        dict_setup_body(ds.state, alpha, k, KP, ds.trace, ds.fnorm, ds.Mout, ds.gram, ds.sc, ds.sp, sm);
+        return;
+    }
+    const long bx = (long)blockIdx.x - (ds.on ? 1 : 0);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lr = lane >> 4, lc = lane & 15;
     double mreg[T][S];
 #pragma unroll
     for (int ti = 0; ti < T; ++ti)
 #pragma unroll
-        for (int s = 0; s < S; ++s) mreg[ti][s] = M[(16 * ti + lc) * KP + 4 * s + lr];
+        for (int s = 0; s < S; ++s) {
+            const int i = 16 * ti + lc, j = 4 * s + lr;
+            if (ds.on) mreg[ti][s] = (i < k && j < k) ? alpha[i] * ds.state[i * KP + j] * alpha[j] : 0.0;
+            else mreg[ti][s] = M[i * KP + j];
+        }
     double al[T];
 #pragma unroll
     for (int ti = 0; ti < T; ++ti) al[ti] = alpha[16 * ti + lc];
-    const long rb = (long)blockIdx.x * rows_pb;      // rows_pb is a multiple of 64
+    const long rb = bx * rows_pb;      // rows_pb is a multiple of 64
     long re = rb + rows_pb;
     double dot = 0.0;
     // xupd: x <- x + lambda d for the rows of this block (the accepted SPG step, spg.py:208-222;
@@ -1046,7 +1179,7 @@ __global__ __launch_bounds__(256) void k_grad(const double *__restrict__ Graw,
             if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
             __syncthreads();
         }
-        if (threadIdx.x < KP) partial[(size_t)blockIdx.x * KP + threadIdx.x] = threadIdx.x == 0 ? sm[0] : 0.0;
+        if (threadIdx.x < KP) partial[(size_t)bx * KP + threadIdx.x] = threadIdx.x == 0 ? sm[0] : 0.0;
     }
 }
 
@@ -1693,33 +1826,7 @@ __global__ __launch_bounds__(256) void k_dict_setup(const double *__restrict__ s
                                                     aa_spg_params sp)
 {
     __shared__ double sm[256];
-    const int GS = KP * KP, t = threadIdx.x;
-    const double *ZtZ = state, *CKCt = state + GS, *CKZ = state + 2 * GS;
-    for (int e = t; e < GS; e += 256) {
-        const int i = e / KP, j = e % KP;
-        Mout[e] = (i < k && j < k) ? alpha[i] * ZtZ[e] * alpha[j] : 0.0;
-        gram[e] = CKCt[e];
-    }
-    __syncthreads();
-    const double a0 = block_trace_MG(Mout, gram, k, KP, false, sm);
-    sm[t] = t < k ? alpha[t] * CKZ[t * KP + t] : 0.0;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) sm[t] += sm[t + o];
-        __syncthreads();
-    }
-    if (t == 0) {
-        sc[SC_TRACE] = trace;
-        sc[SC_FNORM] = fnorm;
-        sc[SC_S1] = sm[0];
-        sc[SC_A0] = a0;
-        sc[SC_F_OLD] = 0.5 * (trace - 2.0 * sm[0] + a0) / fnorm;
-        sc[SC_NFEVAL] = 1.0;
-        sc[SC_FLAGS] = 0.0;
-        for (int i = 0; i < 16; ++i) sc[SC_FMEM0 + i] = 0.0;   // f_mem = zeros (spg.py:153)
-        sc[SC_ALPHA_SET] = (sp.alpha0 >= 0.0) ? 1.0 : 0.0;
-        sc[SC_ALPHA] = sp.alpha0;
-    }
+    dict_setup_body(state, alpha, k, KP, trace, fnorm, Mout, gram, sc, sp, sm);
 }
 
 // restarts side by side: block r sets up slot r from the diagonal blocks of the Gram state -- the
@@ -2035,10 +2142,13 @@ int g_proj_check_always = 0; // multi-rank: 1 = every list projection is checked
                              // ends the fit with an error instead of being handled
 int g_pq_blocks = 128;          // most blocks of k_gram_wide_pq (their partial Grams are summed by ONE block; 64 -> 128:
                                 // C2, p = 25 000, 0.553 -> 0.537 ms per iteration; 256: 0.548)
+int g_setup_in_grad = 1;        // the dictionary update's set-up block inside its first gradient launch (DictSetup)
+int g_gram_side = 0;            // Z'Z of the refresh after a weights update on the side stream, beside the Z'X pass
 int g_grad_side = 1;            // one SPG iteration per dictionary update: g_new, x += lambda d and the BB stage on the side stream too
 int g_proj_res_side = 1;        // the SPG's residual projection (flags only) on the side stream, beside the weights QP
 int g_proj_small = 1;           // short columns: threshold search of a projection in one kernel (k_proj_small)
-int g_fuse_finalize = 1;    // 1: second reduction stages run in the last block of their producer (single rank)
+int g_fuse_finalize = 1;    // 1: the scalar stage that consumes a reduction rides in the kernel that finalizes it
+int g_fin_in_last = 1;      // 1: the projections' reductions are finalized by the last block of the pass (FinTail, single rank)
 int g_proj_list_cap = 2048; // multi-rank: most candidates per rank and column in the list all-reduce
                             // (the union must fit the solver's LDS: effective cap = min(this, 2048 / world))
 
@@ -2100,18 +2210,24 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     double *wbuf = g ? c->tmpTall.as<double>() : (double *)nullptr;
     const double *wsrc = g ? (const double *)wbuf : x;
     const bool multi = c->world > 1 || c->force_comm;
-    if (!sp || !g_fuse_finalize) {
-        // unfused: the caller launches the stage itself (see below)
-    }
+    // the reductions' second stages in the last block of their pass (FinTail)
+    const bool fin_in_last = g_fin_in_last && !multi && g_fuse_finalize && (int)c->tallBlocks > 1;
     if (g_proj_mode == 0 && !multi && g_proj_small && c->n <= 256L * PROJ_SMALL_RPT) {
         hipLaunchKernelGGL(k_proj_small, dim3(c->k), dim3(256), 0, c->stream, x, g, a_const, (const double *)scal,
                            a_slot, c->n, c->KP, c->projWarm[mode] ? mode : 0, ps, c->slots_aa ? c->slots_k : 0);
     } else if (g_proj_mode == 0) {
         const int RS = 256 / c->KP;
         const long nseg = (long)c->tallBlocks * RS, segcap = rpb / RS;
+        FinTail ft1;
+        memset(&ft1, 0, sizeof(ft1));
+        if (fin_in_last) {
+            ft1.on = 1; ft1.NV = 3; ft1.max_mask = 1u; ft1.red = red_buf(c); ft1.kind = POST_FIRST; ft1.mode = 0;
+            ft1.k = c->k; ft1.ps = ps; ft1.scal = scal; ft1.slot = 0; ft1.stage_after = -1;
+            ft1.kslot = c->slots_aa ? c->slots_k : 0; ft1.R = c->slots_aa ? c->slots_R : 0;
+        }
         TALL_DISPATCH_NT(PROJ_NT, k_proj_first, x, g, a_const, (const double *)scal, a_slot, c->n, rpb, c->k,
-                      c->projWarm[mode] ? mode : 0, (const ProjState *)ps, wbuf, part, c->slots_aa ? c->slots_k : 0);
-        AA_CHECK(finalize_and_post(c, 3, 1u, POST_FIRST, 0, 0, false));
+                      c->projWarm[mode] ? mode : 0, (const ProjState *)ps, wbuf, part, c->slots_aa ? c->slots_k : 0, ft1);
+        if (!fin_in_last) AA_CHECK(finalize_and_post(c, 3, 1u, POST_FIRST, 0, 0, false));
         TALL_DISPATCH(k_proj_collect, wsrc, c->n, rpb, c->k, (const ProjState *)ps,
                       c->projList.as<double>(), c->projSegCnt.as<int>());
         if (!multi) {
@@ -2167,11 +2283,20 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     double *out = nullptr;
     if (mode == PROJ_FEAS) out = const_cast<double *>(x);
     if (mode == PROJ_DIR) out = c->Dt.as<double>();
+    FinTail ft2;
+    memset(&ft2, 0, sizeof(ft2));
+    if (fin_in_last) {
+        ft2.on = 1; ft2.NV = 4; ft2.max_mask = 8u; ft2.red = red_buf(c); ft2.kind = POST_FIN; ft2.mode = mode;
+        ft2.k = c->k; ft2.ps = ps; ft2.scal = scal; ft2.slot = 0; ft2.stage_after = sp ? stage_after : -1;
+        if (sp) ft2.sp = *sp;
+        ft2.kslot = c->slots_aa ? c->slots_k : 0; ft2.R = c->slots_aa ? c->slots_R : 0;
+    }
     TALL_DISPATCH_NT(PROJ_NT, k_proj_finish, mode, x, g, a_const, (const double *)scal, a_slot,
                   (const double *)c->H.as<double>(), (const double *)c->alphaDev.as<double>(), c->n, rpb,
                   c->k, (const ProjState *)ps, out, part, c->slots_aa ? c->slots_k : 0,
-                  (c->slots_aa && mode == PROJ_FEAS) ? c->slots_cold_cols : 0xffffffffu);
-    if (sp && stage_after >= 0 && !g_fuse_finalize) {
+                  (c->slots_aa && mode == PROJ_FEAS) ? c->slots_cold_cols : 0xffffffffu, ft2);
+    if (fin_in_last) {
+    } else if (sp && stage_after >= 0 && !g_fuse_finalize) {
         AA_CHECK(finalize_and_post(c, 4, 8u, POST_FIN, mode, 0, false));
         AA_CHECK(launch_scalar_stage(c, stage_after, sp, 0));
     } else {
@@ -2228,6 +2353,16 @@ int side_begin(Ctx *c)
     return AA_OK;
 }
 
+// more side work behind whatever is pending there, after everything the main stream holds so far
+// (no join in between: the main stream keeps going)
+int side_begin_behind(Ctx *c)
+{
+    AA_CHECK_HIP(hipEventRecord(c->evFork2, c->stream));
+    AA_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->evFork2, 0));
+    side_swap(c);
+    return AA_OK;
+}
+
 int side_end(Ctx *c)
 {
     side_swap(c);
@@ -2250,8 +2385,21 @@ int launch_proj_side(Ctx *c, const double *x, const double *g, double a_const, i
 // sp): the scalar stage that consumes <d, g> (ST_BB) runs inside the finalize kernel.
 int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, double scale,
                 const double *d_for_dot, int dot_slot, double *xupd, const aa_spg_params *sp,
-                int stage_after)
+                int stage_after, const aa_spg_params *setup_sp, double setup_fnorm)
 {
+    // setup_sp: the dictionary update's set-up rides along as block 0 (DictSetup)
+    DictSetup ds;
+    memset(&ds, 0, sizeof(ds));
+    if (setup_sp) {
+        ds.on = 1;
+        ds.state = c->gramState.as<double>();
+        ds.trace = c->trace;
+        ds.fnorm = setup_fnorm;
+        ds.Mout = c->Mdev.as<double>();
+        ds.gram = c->gramOut.as<double>();
+        ds.sc = c->scalars.as<double>();
+        ds.sp = *setup_sp;
+    }
     // 16 rows per wave and step with nothing in flight across steps: ~4 blocks per CU
     long gb = (c->n + 63) / 64;
     if (gb > 1024) gb = 1024;
@@ -2263,15 +2411,15 @@ int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, doubl
     const int kslot = c->slots_aa ? c->slots_k : 0;
     if (kslot && d_for_dot) pdot = c->tmpTall.as<double>();      // k_grad's mixed dot is not used: per slot below
     if (c->KP == 32)
-        hipLaunchKernelGGL(k_grad<32>, dim3(nb), dim3(256), 0, c->stream, Graw, H,
+        hipLaunchKernelGGL(k_grad<32>, dim3(nb + ds.on), dim3(256), 0, c->stream, Graw, H,
                            (const double *)c->Mdev.as<double>(), (const double *)c->alphaDev.as<double>(),
                            scale, c->n, rpb, c->k, gout, d_for_dot, pdot, xupd,
-                           (const double *)c->scalars.as<double>(), kslot, c->slots_R);
+                           (const double *)c->scalars.as<double>(), kslot, c->slots_R, ds);
     else
-        hipLaunchKernelGGL(k_grad<64>, dim3(nb), dim3(256), 0, c->stream, Graw, H,
+        hipLaunchKernelGGL(k_grad<64>, dim3(nb + ds.on), dim3(256), 0, c->stream, Graw, H,
                            (const double *)c->Mdev.as<double>(), (const double *)c->alphaDev.as<double>(),
                            scale, c->n, rpb, c->k, gout, d_for_dot, pdot, xupd,
-                           (const double *)c->scalars.as<double>(), kslot, c->slots_R);
+                           (const double *)c->scalars.as<double>(), kslot, c->slots_R, ds);
     if (kslot && d_for_dot) {
         const dim3 gd((unsigned)nb, (unsigned)c->slots_R);
         if (c->KP == 32)

@@ -236,11 +236,20 @@ static int refresh_after_weights(Ctx *c)
         // enter as a rank-m correction (launch_qp_tail_fixup), so the latency-bound tail of
         // the weights update hides behind an HBM-bound pass.
         const bool tail = c->qp_tail_pending;
+        // Z'Z needs the weights only: on the side stream, beside the HBM-bound pass, instead of 16 us of
+        // two small launches between the two passes (joined below, with the dictionary's side work)
+        const bool gram_on_side = g_gram_side && !tail && !c->slots_aa && side_available(c);
+        if (gram_on_side) {
+            AA_CHECK(side_begin_behind(c));
+            const int rc = launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c));
+            AA_CHECK(side_end(c));
+            AA_CHECK(rc);
+        }
         AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), operandT(c, c->ZtX, c->Qw), true));
         if (tail) AA_CHECK(launch_qp_tail_fixup(c, c->Zt.as<double>()));
         AA_CHECK(launch_reduce_rows_finish(c, c->ZtX.as<double>(), operandT(c, c->ZtX, c->Qw),
                                            tail ? QP_FIX_SLABS : 0));
-        AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
+        if (!gram_on_side) AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
         AA_CHECK(join_side(c));                  // the side stream's gradient kernel reads the old H and updates C
         AA_CHECK(launch_row_local(c, operandT(c, c->ZtX, c->Qw), c->H.as<double>()));
     } else {
@@ -341,8 +350,10 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
     // state, one block sets up M, the scalars and f(x)
     const bool fused = data && g_fuse_finalize;
     const bool fast = fused && warm && c->grams_valid && c->ckz_valid && !c->dict_inputs_overridden;
+    // (single fit: the set-up block rides in the gradient launch below, beside its row blocks)
+    const bool setup_in_grad = fast && g_setup_in_grad && !c->slots_aa;
     if (fast) {
-        AA_CHECK(launch_dict_setup(c, sp, (double)k));                          // spg.py:153-157
+        if (!setup_in_grad) AA_CHECK(launch_dict_setup(c, sp, (double)k));      // spg.py:153-157
     } else {
         // M = D Z'Z D  (archetypal_analysis.py:310,330), formed on the device
         AA_CHECK(launch_scale_gram(c, c->Mdev.as<double>(), dev_ZtZ(c)));
@@ -374,7 +385,8 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
         if (data && !warm) AA_CHECK(launch_row_local(c, operandT(c, c->P, c->Pw), c->Gr.as<double>()));
     }
     c->products_valid = false;
-    AA_CHECK(launch_grad(c, c->Gr.as<double>(), c->H.as<double>(), c->gk.as<double>(), gscale, nullptr, 0));
+    AA_CHECK(launch_grad(c, c->Gr.as<double>(), c->H.as<double>(), c->gk.as<double>(), gscale, nullptr, 0, nullptr,
+                         nullptr, -1, setup_in_grad ? sp : nullptr, (double)k));
 
     std::vector<double> sc(SC_COUNT, 0.0);
     int n_iter = -1, flags = 0;
@@ -558,8 +570,14 @@ int aa_set_option(const char *name, int value)
         g_proj_check_always = value != 0;
     } else if (!strcmp(name, "fuse_finalize")) {
         g_fuse_finalize = value != 0;
-    } else if (!strcmp(name, "qp_prefetch_order")) {
-        g_qp_prefetch_order = value != 0;
+    } else if (!strcmp(name, "setup_in_grad")) {
+        g_setup_in_grad = value != 0;
+    } else if (!strcmp(name, "gram_side")) {
+        g_gram_side = value != 0;
+    } else if (!strcmp(name, "fin_in_last")) {
+        g_fin_in_last = value != 0;
+    } else if (!strcmp(name, "qp_fused_order")) {
+        g_qp_fused_order = value != 0;
     } else if (!strcmp(name, "grad_side")) {
         g_grad_side = value != 0;
     } else if (!strcmp(name, "qp_wave_lazy")) {
@@ -697,8 +715,6 @@ int aa_ctx_destroy(aa_ctx *h)
     for (DevBuf *b : all) b->release();
     if (c->evFork2) (void)hipEventDestroy(c->evFork2);
     if (c->evJoin2) (void)hipEventDestroy(c->evJoin2);
-    if (c->evOrderFork) (void)hipEventDestroy(c->evOrderFork);
-    if (c->evOrder) (void)hipEventDestroy(c->evOrder);
     for (int w = 0; w < 2; ++w)
         for (hipEvent_t e : c->gemmEvents[w]) (void)hipEventDestroy(e);
     if (c->evFork) (void)hipEventDestroy(c->evFork);

@@ -3,15 +3,18 @@
 import csv, glob, sys, collections
 d = sys.argv[1]; last = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 import os
-f = max(glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv"), key=os.path.getmtime)
+f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
     n = n.split("(")[0].replace("void aa::", "").replace("aa::", "")
     return n
 names = [short(r["Kernel_Name"]) for r in rows]
-# iteration boundaries: launches of the dictionary set-up kernel (fast path) or k_scale_gram
-marks = [i for i, nm in enumerate(names) if nm.startswith("k_dict_setup") or nm.startswith("k_scale_gram")]
+# iteration boundaries: the launch after the cost kernel that ends an outer iteration (the dictionary set-up used
+# to be a launch of its own and the marker; it is block 0 of the first gradient launch now)
+marks = [i + 1 for i, nm in enumerate(names) if nm.startswith("k_aa_cost") and i + 1 < len(names)]
+if not marks:
+    marks = [i for i, nm in enumerate(names) if nm.startswith("k_dict_setup") or nm.startswith("k_scale_gram")]
 if len(sys.argv) > 3:        # [n] [skip]: n iterations after the first `skip` of the trace (the timed window)
     skip = int(sys.argv[3]); marks = marks[skip:skip + last + 1]
 else:
