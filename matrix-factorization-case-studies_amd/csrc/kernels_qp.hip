@@ -2341,15 +2341,18 @@ __global__ __launch_bounds__(256) void k_qp_wave_ord(QpOrder od, const double *_
                                                      const double *__restrict__ bscale, double *__restrict__ Z,
                                                      int ldz, int k, aa_qp_params p, int *__restrict__ iters,
                                                      QpHeader *__restrict__ hdr, const int *__restrict__ ovf_rows,
-                                                     const QpCarry *__restrict__ ovf)
+                                                     const QpCarry *__restrict__ ovf, int park_at = 1 << 30,
+                                                     unsigned int *__restrict__ n_parked = nullptr,
+                                                     int *__restrict__ park_rows = nullptr,
+                                                     QpCarry *__restrict__ park = nullptr)
 {
     if ((int)blockIdx.x < od.blocks) {
         qp_order_block(od);
         return;
     }
     qp_wave_body<32, true, LAZY>(A, B, stride_j, stride_t, bscale, Z, ldz, (long)-1, k, p, iters, hdr, ovf_rows, ovf,
-                                 (double *)nullptr, (const int *)nullptr, (const unsigned int *)nullptr, 1 << 30,
-                                 (unsigned int *)nullptr, (int *)nullptr, (QpCarry *)nullptr,
+                                 (double *)nullptr, (const int *)nullptr, (const unsigned int *)nullptr, park_at,
+                                 n_parked, park_rows, park,
                                  QpLive{0, 0, 0u, 0u, nullptr, nullptr}, 0, 0L, (unsigned int)od.blocks);
 }
 
@@ -2608,8 +2611,12 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
     // unordered
     int quad_cap = g_qp_quad_cap > 0 ? g_qp_quad_cap : (n >= 65536 ? 32 : 24);
     if (p->memory > 1 || p->max_iterations <= quad_cap) quad_cap = p->max_iterations;
+    // (deferred stragglers: only the two-stage form, whose first stage is an ordinary launch on the main stream)
+    const bool defer_ok = defer_tail && !stats && c->stream2 && ldz == c->KP && KW == 32 && c->dtype == AA_F32 &&
+                          c->tmpTall.bytes >= (size_t)n * 32 * sizeof(double);
+    const bool two_stage = defer_ok && g_qp_tail_cap > quad_cap && g_qp_tail_cap < p->max_iterations;
     const bool fused_order = g_qp_fused_order && g_qp_sort && quad_mode && !A_host && KW == 32 && p->memory <= 1 &&
-                             g_qp_wave_mem1 && !g_qp_live && !defer_tail && quad_cap < p->max_iterations &&
+                             g_qp_wave_mem1 && !g_qp_live && (!defer_ok || two_stage) && quad_cap < p->max_iterations &&
                              p->max_iterations > 2 && n > 4096 &&
                              n <= (long)QP_ORDER_MAX_BLOCKS * QP_SORT_ROWS_PER_BLOCK && iters_dev &&
                              iters_dev == c->qpIters.as<int>();
@@ -2785,23 +2792,42 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
             // left them and launch_qp_tail_fixup adds the rank-m correction afterwards -- the
             // dependent chain of the longest sample (100-450 passes at ~0.9 us) hides behind an
             // HBM-bound pass instead of idling the chip
-            const bool defer = defer_tail && !stats && c->stream2 && ldz == c->KP && KW == 32 &&
-                               c->dtype == AA_F32 && c->tmpTall.bytes >= (size_t)n * 32 * sizeof(double);
+            const bool defer = defer_ok;
             const int tail_cap = g_qp_tail_cap;
             if (defer && tail_cap > cap && tail_cap < p->max_iterations) {
                 // two stages: everything up to tail_cap passes here, at full speed on the whole chip;
                 // the few samples beyond it on the side stream beside the caller's Z'X pass
+                if (fused_order) {
+                    const QpOrder od{iters_dev, c->qpPerm.as<int>(), c->qpPerm.as<int>() + n, n, order_blocks};
+                    const dim3 og((unsigned)(g_qp_wave_blocks + order_blocks));
+                    if (g_qp_wave_lazy)
+                        hipLaunchKernelGGL(k_qp_wave_ord<true>, og, dim3(256), 0, c->stream, od, A2d, Btall, stride_j,
+                                           stride_t, bsd, Ztall, ldz, k, *p, iters_dev, hdr, (const int *)ovf_rows,
+                                           (const QpCarry *)ovf, tail_cap, &hdr->pad, ovf2_rows, ovf2);
+                    else
+                        hipLaunchKernelGGL(k_qp_wave_ord<false>, og, dim3(256), 0, c->stream, od, A2d, Btall, stride_j,
+                                           stride_t, bsd, Ztall, ldz, k, *p, iters_dev, hdr, (const int *)ovf_rows,
+                                           (const QpCarry *)ovf, tail_cap, &hdr->pad, ovf2_rows, ovf2);
+                    c->qp_perm_ready = true;
+                    c->qp_perm_n = n;
+                } else
                 QW32_LAUNCH(dim3((unsigned)g_qp_wave_blocks), dim3(256), 0, c->stream, A2d, Btall,
                                    stride_j, stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                    (const int *)ovf_rows, (const QpCarry *)ovf, (double *)nullptr,
                                    (const int *)nullptr, (const unsigned int *)nullptr, tail_cap, &hdr->pad, ovf2_rows, ovf2);
+                // the handful beyond tail_cap on the side stream.  (Tried: a CU-masked stream pair,
+                // hipExtStreamCreateWithCUMask -- 8 or 16 CUs for these chains alone, the rest of the chip for
+                // the caller's pass, so that the two share no SIMD.  With masked queues alive EVERY launch of the
+                // process, on any stream, took ~45 us longer (k_qp_setup 6 -> 50 us) and the iteration went
+                // from 2.0 to 3.0-3.2 ms: profiles/round4_ab.txt.)
+                hipStream_t ss = c->stream2;
                 AA_CHECK_HIP(hipEventRecord(c->evFork, c->stream));
-                AA_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->evFork, 0));
-                QW32_LAUNCH(dim3(64), dim3(256), 0, c->stream2, A2d, Btall,
+                AA_CHECK_HIP(hipStreamWaitEvent(ss, c->evFork, 0));
+                QW32_LAUNCH(dim3(64), dim3(256), 0, ss, A2d, Btall,
                                    stride_j, stride_t, bsd, Ztall, ldz, (long)-1, k, *p, iters_dev, hdr,
                                    (const int *)ovf2_rows, (const QpCarry *)ovf2, c->tmpTall.as<double>(),
                                    (const int *)nullptr, (const unsigned int *)&hdr->pad);
-                AA_CHECK_HIP(hipEventRecord(c->evJoin, c->stream2));
+                AA_CHECK_HIP(hipEventRecord(c->evJoin, ss));
                 c->qp_tail_pending = true;
                 c->qp_tail_rows = ovf2_rows;
                 c->qp_tail_count = &hdr->pad;
