@@ -191,6 +191,21 @@ struct Ctx {
     P2P *p2p = nullptr;
     int rank = 0, world = 1;
     bool force_comm = false;                   // AA_FORCE_RCCL=1: use RCCL even with one rank
+    // multi-rank: small reductions that ride in the tail of the next all-reduce instead of having one of
+    // their own (pack_comm).  ride_dst: where the rider's values go (the tail of a wide buffer, or the
+    // second region of redGather); ride_count: doubles there; ride: the k_post step owed after the all-reduce
+    struct RidePost {
+        bool on = false;
+        int kind = 0, mode = 0, NV = 0, slot = 0, gated = 0, stage_after = -1;
+        unsigned max_mask = 0u;
+        aa_spg_params sp;
+        double *red = nullptr;
+        ProjState *ps = nullptr;
+    };
+    RidePost ride, ride_grad;
+    double *ride_dst = nullptr;
+    long ride_count = 0;
+    bool ride_grad_next = false;               // the next launch_grad's dot rides with the projection that follows it
 
     // data
     int form = AA_FORM_DATA;
@@ -279,7 +294,9 @@ int launch_grad(Ctx *c, const double *Graw, const double *H, double *gout, doubl
 int launch_tall_axpy_lambda(Ctx *c, double *x, const double *d);             // x += lambda * d
 int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const double *alpha_dev,
                            int slot);   // sum x*H*alpha (alpha_dev nullable => 1)
-int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev); // A'B  (KPxKP)
+int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev, bool local_only = false);
+int launch_ride_post(Ctx *c, Ctx::RidePost *rp, const double *gather);   // the k_post step a rider is owed
+#define AA_WIDE_TAIL(KP) ((size_t)(KP) * (KP) + (size_t)64 * 4 * (KP))   // doubles behind a wide buffer for riders // A'B  (KPxKP)
 int launch_gram_wide(Ctx *c, const double *A, const double *B, double *out_dev); // A B' (KPxKP)
 int launch_scale_gram(Ctx *c, double *dst, const double *src);      // dst = D src D
 // the outer iteration's judge, run by the cost kernel that records the iteration's last cost
@@ -413,7 +430,7 @@ extern int g_qp_refill_min;       // kernels_qp.hip
 extern int g_qp_waves;            // kernels_qp.hip
 extern int g_qp_sort;             // kernels_qp.hip
 extern int g_qp_profile;          // kernels_qp.hip
-extern int g_qp_wave_mem1, g_qp_fused_order, g_qp_wave_lazy, g_fin_in_last, g_gram_side, g_setup_in_grad;
+extern int g_qp_wave_mem1, g_qp_fused_order, g_qp_wave_lazy, g_fin_in_last, g_gram_side, g_setup_in_grad, g_pack_comm;
 extern int g_qp_overlap_tail, g_qp_tail_cap, g_qp_live, g_qp_live_blocks, g_qp_live_occ;     // kernels_qp.hip
 
 // ------------------------------------------------------------------ comm.hip

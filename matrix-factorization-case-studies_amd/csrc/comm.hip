@@ -78,7 +78,7 @@ struct Comm {
 // ------------------------------------------------------------------ one-shot peer-to-peer all-reduce
 #define P2P_MAX_WORLD 8
 #define P2P_MAX_BLOCKS 64
-#define P2P_SLOT_BYTES (1u << 20)                  // per rank and bank: k x p = 32 x 4096 float64
+#define P2P_SLOT_BYTES ((1u << 20) + (1u << 16))    // per rank and bank: k x p = 32 x 4096 float64 and the riders in its tail (pack_comm)
 #define P2P_FLAG_WORDS (2 * P2P_MAX_WORLD * P2P_MAX_BLOCKS)
 
 struct P2P {

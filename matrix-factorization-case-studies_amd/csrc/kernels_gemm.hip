@@ -1281,7 +1281,14 @@ int launch_reduce_rows_finish(Ctx *c, double *out_wide, void *outT, int extra_sl
     }
     AA_CHECK_HIP(hipGetLastError());
     if ((c->world > 1 || c->force_comm)) {
-        AA_CHECK(comm_allreduce(c, out_wide, elems, 0));
+        // riders in the buffer's tail (Ctx::ride*): one all-reduce for the lot
+        long extra = 0;
+        if (c->ride_dst == out_wide + elems) extra = c->ride_count;
+        AA_REQUIRE(extra > 0 || !c->ride.on, AA_ERR_STATE, "a reduction was left waiting for an all-reduce that did not come");
+        AA_CHECK(comm_allreduce(c, out_wide, elems + extra, 0));
+        if (extra && c->ride.on) AA_CHECK(launch_ride_post(c, &c->ride, out_wide + elems));
+        c->ride_dst = nullptr;
+        c->ride_count = 0;
         if (outT && outT != (void *)out_wide) AA_CHECK(launch_wide_to_T(c, out_wide, outT));
     }
     return AA_OK;

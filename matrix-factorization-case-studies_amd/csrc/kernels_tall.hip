@@ -2094,16 +2094,47 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
         // slot, whatever mix of sums and maxima the NV values are; the ranks' values are
         // combined in rank order by k_post.  (When a gated pass has already converged the
         // reduced values are stale but unused: k_post exits.)
-        AA_CHECK(c->redGather.alloc((size_t)c->world * 4 * c->KP * sizeof(double)));
+        AA_CHECK(c->redGather.alloc((size_t)c->world * 5 * c->KP * sizeof(double)));
         double *gather = c->redGather.as<double>();
+        const long region = (long)c->world * 4 * c->KP;
+        // riders (pack_comm): a projection's closing reduction goes with the wide all-reduce that follows it
+        // (ride_dst set by the caller), the gradient's <d, g_new> with the first reduction of the residual
+        // projection behind it (second region of the gather buffer)
+        const bool rides_wide = c->ride_dst && kind == POST_FIN && !gated;
+        const bool rides_first = c->ride_grad_next && kind == POST_SCALAR_SUM && !gated;
+        if (rides_wide) gather = c->ride_dst;
+        if (rides_first) gather += region;
         hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(FIN_NT), 0, c->stream, part, nb, NV,
                            c->KP, max_mask, red, gate, (int)POST_NONE, mode, c->k, ps,
                            c->scalars.as<double>(), slot, gather, c->rank, c->world, -1, spv);
-        AA_CHECK(comm_allreduce(c, gather, (long)c->world * NV * c->KP, 0));
+        if (rides_wide || rides_first) {
+            Ctx::RidePost &rp = rides_wide ? c->ride : c->ride_grad;
+            rp.on = true;
+            rp.kind = kind; rp.mode = mode; rp.NV = NV; rp.slot = slot; rp.gated = 0; rp.stage_after = stage_after;
+            rp.max_mask = max_mask; rp.sp = spv; rp.red = red; rp.ps = ps;
+            if (rides_wide) c->ride_count = (long)c->world * NV * c->KP;
+            c->ride_grad_next = false;
+            AA_CHECK_HIP(hipGetLastError());
+            return AA_OK;
+        }
+        long count = (long)c->world * NV * c->KP;
+        if (c->ride_grad.on) count = region + (long)c->world * c->ride_grad.NV * c->KP;   // (the gap is summed along, unused)
+        AA_CHECK(comm_allreduce(c, gather, count, 0));
+        if (c->ride_grad.on) AA_CHECK(launch_ride_post(c, &c->ride_grad, gather + region));
         hipLaunchKernelGGL(k_post, dim3(1), dim3(256), 0, c->stream, kind, mode, red, c->KP, c->k, ps,
                            c->scalars.as<double>(), slot, gated ? 1 : 0, (const double *)gather,
                            c->world, NV, max_mask, stage_after, spv);
     }
+    AA_CHECK_HIP(hipGetLastError());
+    return AA_OK;
+}
+
+int launch_ride_post(Ctx *c, Ctx::RidePost *rp, const double *gather)
+{
+    rp->on = false;
+    hipLaunchKernelGGL(k_post, dim3(1), dim3(256), 0, c->stream, rp->kind, rp->mode, rp->red, c->KP, c->k, rp->ps,
+                       c->scalars.as<double>(), rp->slot, rp->gated, gather, c->world, rp->NV, rp->max_mask,
+                       rp->stage_after, rp->sp);
     AA_CHECK_HIP(hipGetLastError());
     return AA_OK;
 }
@@ -2142,6 +2173,7 @@ int g_proj_check_always = 0; // multi-rank: 1 = every list projection is checked
                              // ends the fit with an error instead of being handled
 int g_pq_blocks = 128;          // most blocks of k_gram_wide_pq (their partial Grams are summed by ONE block; 64 -> 128:
                                 // C2, p = 25 000, 0.553 -> 0.537 ms per iteration; 256: 0.548)
+int g_pack_comm = 1;            // multi-rank: small reductions ride in the tail of the next all-reduce (Ctx::ride*)
 int g_setup_in_grad = 1;        // the dictionary update's set-up block inside its first gradient launch (DictSetup)
 int g_gram_side = 0;            // Z'Z of the refresh after a weights update on the side stream, beside the Z'X pass
 int g_grad_side = 1;            // one SPG iteration per dictionary update: g_new, x += lambda d and the BB stage on the side stream too
@@ -2459,7 +2491,7 @@ int launch_tall_dot_scaled(Ctx *c, const double *x, const double *H, const doubl
     return AA_OK;
 }
 
-int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev)
+int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev, bool local_only)
 {
     const int want = 256;                                      // one block per CU
     long rpb = round_up((c->n_pad + want - 1) / want, 64);     // 4 row groups per step
@@ -2473,7 +2505,7 @@ int launch_gram_tall(Ctx *c, const double *A, const double *B, double *out_dev)
     hipLaunchKernelGGL(k_gram_finalize, dim3((elems + 63) / 64), dim3(256), 0, c->stream, part,
                        nb, elems, out_dev);
     AA_CHECK_HIP(hipGetLastError());
-    if ((c->world > 1 || c->force_comm)) AA_CHECK(comm_allreduce(c, out_dev, elems, 0));
+    if ((c->world > 1 || c->force_comm) && !local_only) AA_CHECK(comm_allreduce(c, out_dev, elems, 0));
     return AA_OK;
 }
 

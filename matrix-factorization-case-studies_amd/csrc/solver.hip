@@ -54,7 +54,7 @@ static int ensure_problem(Ctx *c, int k)
     c->k = k;
     c->KP = KP;
     const size_t tall = (size_t)(c->n_pad + AA_SLACK_ROWS) * KP * sizeof(double);
-    const size_t wide = (size_t)KP * c->p_pad * sizeof(double);
+    const size_t wide = ((size_t)KP * c->p_pad + AA_WIDE_TAIL(KP)) * sizeof(double);   // (tail: riders of the all-reduce)
     DevBuf *talls[] = {&c->Ct, &c->Zt, &c->Dt, &c->Gr, &c->Gn, &c->gk, &c->gn, &c->H, &c->tmpTall};
     for (DevBuf *b : talls) {
         b->release();
@@ -238,6 +238,8 @@ static int refresh_after_weights(Ctx *c)
         const bool tail = c->qp_tail_pending;
         // Z'Z needs the weights only: on the side stream, beside the HBM-bound pass, instead of 16 us of
         // two small launches between the two passes (joined below, with the dictionary's side work)
+        const bool multi = c->world > 1 || c->force_comm;
+        const bool pack = multi && g_pack_comm;         // Z'Z rides in the tail of the Z'X all-reduce
         const bool gram_on_side = g_gram_side && !tail && !c->slots_aa && side_available(c);
         if (gram_on_side) {
             AA_CHECK(side_begin_behind(c));
@@ -247,9 +249,18 @@ static int refresh_after_weights(Ctx *c)
         }
         AA_CHECK(launch_reduce_rows(c, c->Zt.as<double>(), c->ZtX.as<double>(), operandT(c, c->ZtX, c->Qw), true));
         if (tail) AA_CHECK(launch_qp_tail_fixup(c, c->Zt.as<double>()));
+        if (pack) {
+            double *tailp = c->ZtX.as<double>() + (size_t)c->KP * c->p_pad;
+            AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), tailp, true));
+            c->ride_dst = tailp;
+            c->ride_count = (long)c->KP * c->KP;
+        }
         AA_CHECK(launch_reduce_rows_finish(c, c->ZtX.as<double>(), operandT(c, c->ZtX, c->Qw),
                                            tail ? QP_FIX_SLABS : 0));
-        if (!gram_on_side) AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
+        if (pack)
+            AA_CHECK_HIP(hipMemcpyAsync(dev_ZtZ(c), c->ZtX.as<double>() + (size_t)c->KP * c->p_pad,
+                                        (size_t)c->KP * c->KP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        else if (!gram_on_side) AA_CHECK(launch_gram_tall(c, c->Zt.as<double>(), c->Zt.as<double>(), dev_ZtZ(c)));
         AA_CHECK(join_side(c));                  // the side stream's gradient kernel reads the old H and updates C
         AA_CHECK(launch_row_local(c, operandT(c, c->ZtX, c->Qw), c->H.as<double>()));
     } else {
@@ -396,6 +407,10 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
         if (it == 0 && sp->alpha0 < 0.0) {                                      // spg.py:178-189
             AA_CHECK(launch_proj(c, x, c->gk.as<double>(), 1.0, -1, PROJ_ALPHA, sp, ST_ALPHA));
         }
+        // multi-rank: the closing reduction of this projection (<d,g>, <d,d>, ...: read by the line search
+        // only) rides with the all-reduce of Q = D'X
+        const bool multi = c->world > 1 || c->force_comm;
+        if (multi && g_pack_comm && data && !c->slots_aa) c->ride_dst = c->Q.as<double>() + (size_t)KP * c->p_pad;
         AA_CHECK(launch_proj(c, x, c->gk.as<double>(), 0.0, SC_ALPHA, PROJ_DIR)); // spg.py:191-194,206
         if (data) {
             AA_CHECK(launch_reduce_rows(c, c->Dt.as<double>(), c->Q.as<double>(), nullptr));
@@ -436,6 +451,8 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
             // H) and before C K Z is formed from the updated C.
             grad_on_side = g_grad_side && sp->max_iterations == 1 && !st && side_available(c);
             if (grad_on_side) AA_CHECK(side_begin(c));
+            // multi-rank: <d, g_new> rides with the first reduction of the residual projection below
+            if (multi && g_pack_comm && !c->slots_aa && g_proj_mode == 0 && g_fuse_finalize) c->ride_grad_next = true;
             AA_CHECK(launch_grad(c, c->Gn.as<double>(), c->H.as<double>(), c->gn.as<double>(), gscale,
                                  c->Dt.as<double>(), SC_DGN, x, sp, ST_BB));
         } else {
@@ -570,6 +587,8 @@ int aa_set_option(const char *name, int value)
         g_proj_check_always = value != 0;
     } else if (!strcmp(name, "fuse_finalize")) {
         g_fuse_finalize = value != 0;
+    } else if (!strcmp(name, "pack_comm")) {
+        g_pack_comm = value != 0;
     } else if (!strcmp(name, "setup_in_grad")) {
         g_setup_in_grad = value != 0;
     } else if (!strcmp(name, "gram_side")) {
