@@ -593,12 +593,14 @@ __global__ __launch_bounds__(256) void k_proj_solve(const double *__restrict__ l
     }
 }
 
-// Short columns (n <= 256 * PROJ_SMALL_RPT, single rank): the whole threshold search of a column in
+// Short columns (n <= 16 384, single rank): the whole threshold search of a column in
 // ONE block -- its entries in registers, the lower bound (max - 1, or the Newton step from the
 // previous projection's threshold) and the Michelot fixed point of k_proj_solve on them -- instead
 // of the first pass, its finalize, the candidate lists and their solver (four launches of ~6 us
 // each; three projections per outer iteration are a fifth of the HadISST-shaped problem's time).
-#define PROJ_SMALL_RPT 32
+// PROJ_SMALL_RPT: entries per thread, 32 (n <= 8192) or 64 (n <= 16 384: the 12 500-row shards of the
+// headline problem on 8 GPUs, when run as problems of their own)
+template <int PROJ_SMALL_RPT>
 __global__ __launch_bounds__(256) void k_proj_small(const double *__restrict__ x,
                                                     const double *__restrict__ g, double a_const,
                                                     const double *__restrict__ scal, int a_slot, long n,
@@ -2244,9 +2246,16 @@ int launch_proj(Ctx *c, const double *x, const double *g, double a_const, int a_
     const bool multi = c->world > 1 || c->force_comm;
     // the reductions' second stages in the last block of their pass (FinTail)
     const bool fin_in_last = g_fin_in_last && !multi && g_fuse_finalize && (int)c->tallBlocks > 1;
-    if (g_proj_mode == 0 && !multi && g_proj_small && c->n <= 256L * PROJ_SMALL_RPT) {
-        hipLaunchKernelGGL(k_proj_small, dim3(c->k), dim3(256), 0, c->stream, x, g, a_const, (const double *)scal,
-                           a_slot, c->n, c->KP, c->projWarm[mode] ? mode : 0, ps, c->slots_aa ? c->slots_k : 0);
+    // (the 64-entries-per-thread instantiation would cover the 12 500-row shards; measured there: 0.576 ms per
+    // outer iteration with it against 0.533 with the four list launches -- 32 blocks walking 12 500 strided
+    // entries each are slower than 256 blocks streaming them -- so the default stays at 8192 rows; option proj_small=2)
+    if (g_proj_mode == 0 && !multi && g_proj_small && c->n <= (g_proj_small >= 2 ? 256L * 64 : 256L * 32)) {
+        if (c->n <= 256L * 32)
+            hipLaunchKernelGGL(k_proj_small<32>, dim3(c->k), dim3(256), 0, c->stream, x, g, a_const, (const double *)scal,
+                               a_slot, c->n, c->KP, c->projWarm[mode] ? mode : 0, ps, c->slots_aa ? c->slots_k : 0);
+        else
+            hipLaunchKernelGGL(k_proj_small<64>, dim3(c->k), dim3(256), 0, c->stream, x, g, a_const, (const double *)scal,
+                               a_slot, c->n, c->KP, c->projWarm[mode] ? mode : 0, ps, c->slots_aa ? c->slots_k : 0);
     } else if (g_proj_mode == 0) {
         const int RS = 256 / c->KP;
         const long nseg = (long)c->tallBlocks * RS, segcap = rpb / RS;

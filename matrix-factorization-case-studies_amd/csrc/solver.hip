@@ -616,7 +616,7 @@ int aa_set_option(const char *name, int value)
     } else if (!strcmp(name, "proj_res_side")) {
         g_proj_res_side = value != 0;      // takes effect at the next aa_set_state of a new problem size
     } else if (!strcmp(name, "proj_small")) {
-        g_proj_small = value != 0;
+        g_proj_small = value;
     } else if (!strcmp(name, "qp_profile")) {
         g_qp_profile = value != 0;
     } else if (!strcmp(name, "qp_sort")) {
