@@ -1837,8 +1837,10 @@ __device__ __forceinline__ double qq_threshold(const double (&w)[J], unsigned in
     return (s - 1.0) / (double)c;
 }
 
-template <int MT, bool MEM1>   // M tiles of 16 components: KQ = 16 MT, J = 4 MT components per lane;
+template <int MT, bool MEM1, bool LAZYQ = false>   // M tiles of 16 components: KQ = 16 MT, J = 4 MT components per lane;
                                // MEM1: memory == 1 (the default), no history of f in registers
+                               // LAZYQ: the stopping test of a pass is decided in the next trip, and skipped for
+                               // the whole wave when <d, d> proves it negative for every sample (see qp_wave_body)
 __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda][lda], zero padded*/,
                                              int lda, const double *__restrict__ B, long stride_j,
                                              long stride_t, const double *__restrict__ bscale,
@@ -1867,6 +1869,10 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
     const int lane = threadIdx.x, sl = lane & 15, q = lane >> 4;
     bool sq_ok;
     const double sq_lim = qp_sq_limit(p.epsilon_two, &sq_ok);
+    // LAZYQ: ||P(x - g) - x||_2 >= ||P(x - alpha g) - x||_2 / max(1, alpha); a residual whose square exceeds
+    // 4 max(eps2^2, k eps1^2) passes neither stopping test
+    const double cert = 4.0 * fmax(p.epsilon_two * p.epsilon_two, (double)k * p.epsilon_one * p.epsilon_one);
+    bool pending = false;                           // the test behind this sample's latest pass is still owed
     double H[MT][J];                                // A's operand tiles (constant)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -2006,9 +2012,88 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
 #pragma unroll
             for (int i = 0; i < (MEM1 ? 1 : QP_MAXMEM); ++i) fmem[i] = NAN;
             active = true;                             // its first pass runs in the next trip
+            pending = false;
         }
         if (!__any(was_active)) continue;
-        if (was_active) {
+        // ---- residual of the projected gradient at (x, g), for the samples in `who`   (spg.py:378-396)
+        double q2 = 0.0, qinf = 0.0;
+        auto residual = [&](bool who) {
+            double w[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) w[j] = x[j] - g[j];
+            const double tr = qq_threshold<J>(w, support_r, who);
+            double a2 = 0.0, ai = 0.0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const double r = fmax(w[j] - tr, 0.0) - x[j];
+                a2 = fma(r, r, a2);
+                ai = fmax(ai, fabs(r));
+            }
+            q2 = qq_sum(a2);
+            qinf = qq_max(ai);
+        };
+        // the sample leaves this kernel: finished (its pass count is final) or parked for the wave kernel
+        auto retire = [&](bool finished) {
+            if (live_epoch && !finished) {
+                // live hand-over: a consumer wave of k_qp_wave may pick this sample up while this
+                // kernel is still running, possibly on another XCD: everything it reads goes out
+                // with agent-scope stores, drained before the ready flag
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    if (4 * j + q < k) qp_store_agent(&Z[row * ldz + 4 * j + q], x[j]);
+                unsigned int slot = 0u;
+                if (q == 0) {
+                    slot = atomicAdd(&hdr->n_overflow, 1u);
+                    qp_store_agent(&ovf_rows[slot], (int)row);
+                    double *cd = reinterpret_cast<double *>(&ovf[slot]);
+                    qp_store_agent(cd, alpha);
+                    qp_store_agent(cd + 1, f);
+                    qp_store_agent(cd + 2, __longlong_as_double(((long long)n_feval << 32) | (unsigned int)n_iter));
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (q == 0) qp_store_agent(&ovf_ready[slot], live_epoch);
+            } else {
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    if (4 * j + q < k) Z[row * ldz + 4 * j + q] = x[j];
+                if (q == 0) {
+                    if (finished) {
+                        if (iters) iters[row] = n_iter;
+                        st_total += (unsigned long long)n_iter;
+                        st_max = n_iter > st_max ? n_iter : st_max;
+                    } else {
+                        const unsigned int slot = atomicAdd(&hdr->n_overflow, 1u);
+                        ovf_rows[slot] = (int)row;
+                        QpCarry cr;
+                        cr.alpha = alpha;
+                        cr.f = f;
+                        cr.n_iter = n_iter;
+                        cr.n_feval = n_feval;
+                        ovf[slot] = cr;
+                        // "at least the cap": what the ordering blocks of k_qp_wave_ord may read
+                        // before the wave that finishes this sample has written the final count
+                        if (iters) iters[row] = n_iter;
+                    }
+                }
+            }
+            active = false;
+        };
+        bool upd = was_active;
+        if constexpr (LAZYQ) {
+            // the test owed from the previous pass, on the (x, g) that pass left: run for the samples whose
+            // direction does not rule it out -- for none of them in most trips of a batch of similar samples
+            const double am = fmax(1.0, alpha);
+            const bool need = was_active && pending && !(r1 > cert * am * am);
+            if (__any(need)) {
+                residual(need);
+                if (need && ((sq_ok ? q2 < sq_lim : sqrt(q2) < p.epsilon_two) || (qinf < p.epsilon_one))) {
+                    retire(true);
+                    upd = false;
+                }
+            }
+            pending = false;
+        }
+        if (upd) {
             const double delta = r0, dd = r1, dAd = r2;
             // non-monotone reference value (spg.py:341-344): roll, store, nanmax
             double f_max = f;
@@ -2044,70 +2129,23 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
             f = f_new;
             n_feval += 1;
         }
-        // ---- residual of the projected gradient at the new point              (spg.py:378-396)
-        double q2 = 0.0, qinf = 0.0;
-        {
-            double w[J];
-#pragma unroll
-            for (int j = 0; j < J; ++j) w[j] = x[j] - g[j];
-            const double tr = qq_threshold<J>(w, support_r, was_active);
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const double r = fmax(w[j] - tr, 0.0) - x[j];
-                q2 = fma(r, r, q2);
-                qinf = fmax(qinf, fabs(r));
+        bool test_now = false;
+        if (upd) {
+            n_iter += 1;
+            if constexpr (LAZYQ) {
+                if (n_feval > p.max_feval || n_iter >= p.max_iterations) retire(true);
+                else if (n_iter >= pass_cap) test_now = true;       // finished or parked: decided here
+                else pending = true;
+            } else {
+                test_now = true;
             }
         }
-        q2 = qq_sum(q2);
-        qinf = qq_max(qinf);
-        if (was_active) {
-            n_iter += 1;
-            const bool conv = (sq_ok ? q2 < sq_lim : sqrt(q2) < p.epsilon_two) || (qinf < p.epsilon_one);
-            const bool finished = conv || n_feval > p.max_feval || n_iter >= p.max_iterations;
-            if (finished || n_iter >= pass_cap) {
-                if (live_epoch && !finished) {
-                    // live hand-over: a consumer wave of k_qp_wave may pick this sample up while this
-                    // kernel is still running, possibly on another XCD: everything it reads goes out
-                    // with agent-scope stores, drained before the ready flag
-#pragma unroll
-                    for (int j = 0; j < J; ++j)
-                        if (4 * j + q < k) qp_store_agent(&Z[row * ldz + 4 * j + q], x[j]);
-                    unsigned int slot = 0u;
-                    if (q == 0) {
-                        slot = atomicAdd(&hdr->n_overflow, 1u);
-                        qp_store_agent(&ovf_rows[slot], (int)row);
-                        double *cd = reinterpret_cast<double *>(&ovf[slot]);
-                        qp_store_agent(cd, alpha);
-                        qp_store_agent(cd + 1, f);
-                        qp_store_agent(cd + 2, __longlong_as_double(((long long)n_feval << 32) | (unsigned int)n_iter));
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (q == 0) qp_store_agent(&ovf_ready[slot], live_epoch);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < J; ++j)
-                        if (4 * j + q < k) Z[row * ldz + 4 * j + q] = x[j];
-                    if (q == 0) {
-                        if (finished) {
-                            if (iters) iters[row] = n_iter;
-                            st_total += (unsigned long long)n_iter;
-                            st_max = n_iter > st_max ? n_iter : st_max;
-                        } else {
-                            const unsigned int slot = atomicAdd(&hdr->n_overflow, 1u);
-                            ovf_rows[slot] = (int)row;
-                            QpCarry cr;
-                            cr.alpha = alpha;
-                            cr.f = f;
-                            cr.n_iter = n_iter;
-                            cr.n_feval = n_feval;
-                            ovf[slot] = cr;
-                            // "at least the cap": what the ordering blocks of k_qp_wave_ord may read
-                            // before the wave that finishes this sample has written the final count
-                            if (iters) iters[row] = n_iter;
-                        }
-                    }
-                }
-                active = false;
+        if (__any(test_now)) {
+            residual(test_now);
+            if (test_now) {
+                const bool conv = (sq_ok ? q2 < sq_lim : sqrt(q2) < p.epsilon_two) || (qinf < p.epsilon_one);
+                const bool finished = conv || n_feval > p.max_feval || n_iter >= p.max_iterations;
+                if (finished || n_iter >= pass_cap) retire(finished);
             }
         }
     }
@@ -2140,17 +2178,17 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
                 int live_epoch, int *__restrict__ ovf_ready, int rst_b, long rst_n
 #define QQ_PASS A, lda, B, stride_j, stride_t, bscale, Z, ldz, n, k, p, pass_cap, iters, hdr, ovf_rows, ovf,        \
                 refill_min, perm, max_trips, live_epoch, ovf_ready, rst_b, rst_n
-template <int MT, bool MEM1>
-__global__ __launch_bounds__(64) void k_qp_quad(QQ_ARGS) { qp_quad_body<MT, MEM1>(QQ_PASS); }
-template <int MT, bool MEM1>
+template <int MT, bool MEM1, bool LAZYQ = false>
+__global__ __launch_bounds__(64) void k_qp_quad(QQ_ARGS) { qp_quad_body<MT, MEM1, LAZYQ>(QQ_PASS); }
+template <int MT, bool MEM1, bool LAZYQ = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_qp_quad_w3(QQ_ARGS)
 {
-    qp_quad_body<MT, MEM1>(QQ_PASS);
+    qp_quad_body<MT, MEM1, LAZYQ>(QQ_PASS);
 }
-template <int MT, bool MEM1>
+template <int MT, bool MEM1, bool LAZYQ = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_qp_quad_w4(QQ_ARGS)
 {
-    qp_quad_body<MT, MEM1>(QQ_PASS);
+    qp_quad_body<MT, MEM1, LAZYQ>(QQ_PASS);
 }
 #undef QQ_ARGS
 #undef QQ_PASS
@@ -2187,6 +2225,7 @@ int g_qp_live_occ = 3;         // register budget of k_qp_quad beside the consum
 int g_qp_live_blocks = 48;     // CUs given to the consumers (one block of 16 waves each)
 #define QP_LIVE_LDS 163840     // a CU's LDS
 int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)
+int g_qp_quad_lazy = 0;        // four-lane QP, opt-in: the stopping test of a pass decided in the next trip (LAZYQ) -- same results; 497/497/494 it/s with, 503/498 without at the driver's flags, 524/523 against 522 at the default flags: the wave-wide skip is rare and the kernel spills 22 VGPRs instead of 7
 int g_qp_fused_order = 1;   // four-lane QP: the sample order of the NEXT update is formed by extra blocks of this update's continuation launch (k_qp_wave_ord)
 int g_qp_wave_lazy = 1;        // wave-per-sample kernel: stopping test of a pass decided at the top of the next one, skipped when <d, d> proves it negative (0: after every pass)
 int g_qp_wave_mem1 = 1;        // continuation launches of the wave-per-sample kernel: 1 = the memory-1 instantiation (no f_mem array: 311 fewer SGPR spills), 0 = the generic one (A/B)
@@ -2764,9 +2803,16 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
         const int live_epoch = lv.epoch;
         int *ovf_ready = lv.ready;
 #define QQK(KERN, MTV, M1V)                                                                         \
-    hipLaunchKernelGGL((KERN<MTV, M1V>), dim3((unsigned)waves), dim3(64), quad_lds, s_main, A2d, KW, Btall, \
-                       stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf,   \
-                       refill, perm, max_trips, live_epoch, ovf_ready, 0, 0L)
+    do {                                                                                            \
+        if (g_qp_quad_lazy && !live)                                                                \
+            hipLaunchKernelGGL((KERN<MTV, M1V, true>), dim3((unsigned)waves), dim3(64), quad_lds, s_main, A2d, KW, Btall, \
+                               stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf,   \
+                               refill, perm, max_trips, live_epoch, ovf_ready, 0, 0L);                              \
+        else                                                                                        \
+            hipLaunchKernelGGL((KERN<MTV, M1V, false>), dim3((unsigned)waves), dim3(64), quad_lds, s_main, A2d, KW, Btall, \
+                               stride_j, stride_t, bsd, Ztall, ldz, n, k, *p, cap, iters_dev, hdr, ovf_rows, ovf,   \
+                               refill, perm, max_trips, live_epoch, ovf_ready, 0, 0L);                              \
+    } while (0)
 #define QQL(MTV, M1V)                                                                               \
     do {                                                                                            \
         if (quad_occ >= 4) QQK(k_qp_quad_w4, MTV, M1V);                                             \
