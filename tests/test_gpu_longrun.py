@@ -231,6 +231,50 @@ def test_qp_live_hand_over_is_bit_identical(cdr):
     assert np.array_equal(traces[0], traces[1])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_schedule_knobs_do_not_change_a_bit(dtype):
+    """Round 4 moved work around without touching arithmetic: the sample order of the next weights update is
+    formed inside the previous continuation launch (qp_fused_order), the wave-per-sample and four-lane kernels
+    decide their stopping tests lazily behind a projected-gradient bound (qp_wave_lazy, qp_quad_lazy: the same
+    decisions), the projections' reductions are finalized by the last block of their pass in the fixed order of
+    the finalize kernel (fin_in_last), the dictionary set-up rides in the gradient launch (setup_in_grad) and
+    Z'Z may run on the side stream (gram_side).  Each of them off / on: costs, factors and the QP's pass counts
+    of a 40 000-row fit (the pass kernels of the timed configuration, samples parked at the pass cap) are equal
+    bit for bit."""
+    from convex_dim_red import _backend
+    import bench
+    n = 40000
+    X = bench.synthetic_rows(0, n)
+    C0, Z0 = bench.start_factors(n, K)
+    knobs = [("qp_fused_order", 0), ("qp_wave_lazy", 0), ("qp_quad_lazy", 1), ("fin_in_last", 0),
+             ("setup_in_grad", 0), ("gram_side", 1)]
+    defaults = {"qp_fused_order": 1, "qp_wave_lazy": 1, "qp_quad_lazy": 0, "fin_in_last": 1, "setup_in_grad": 1,
+                "gram_side": 0}
+
+    def run():
+        with _backend.Context(dtype=dtype) as ctx:
+            ctx.set_data(X)
+            ctx.set_state(C0, Z0, np.ones(K))
+            ctx.prepare()
+            costs = np.asarray(ctx.outer_iterations(7, dict(max_iterations=1), {}))
+            C, Z, _ = ctx.get_state()
+            return costs, C, Z
+
+    base = run()
+    assert np.all(np.diff(base[0]) < 0)
+    try:
+        for name, value in knobs:
+            _backend.set_option(name, value)
+            got = run()
+            _backend.set_option(name, defaults[name])
+            for a, b in zip(base, got):
+                assert np.array_equal(a, b), name
+    finally:
+        for name, value in defaults.items():
+            _backend.set_option(name, value)
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("n", [1500, 40000])
 def test_pass_kernels_against_numpy(cdr, dtype, n):
