@@ -1873,6 +1873,7 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
     // 4 max(eps2^2, k eps1^2) passes neither stopping test
     const double cert = 4.0 * fmax(p.epsilon_two * p.epsilon_two, (double)k * p.epsilon_one * p.epsilon_one);
     bool pending = false;                           // the test behind this sample's latest pass is still owed
+    unsigned int lz_trips = 0u, lz_skipped = 0u;    // LAZYQ: trips with an owed test, and those that skipped it (qp_profile)
     double H[MT][J];                                // A's operand tiles (constant)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -2084,6 +2085,10 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
             // direction does not rule it out -- for none of them in most trips of a batch of similar samples
             const double am = fmax(1.0, alpha);
             const bool need = was_active && pending && !(r1 > cert * am * am);
+            if (__any(was_active && pending)) {
+                lz_trips += 1u;
+                if (!__any(need)) lz_skipped += 1u;
+            }
             if (__any(need)) {
                 residual(need);
                 if (need && ((sq_ok ? q2 < sq_lim : sqrt(q2) < p.epsilon_two) || (qinf < p.epsilon_one))) {
@@ -2147,6 +2152,12 @@ __device__ __forceinline__ void qp_quad_body(const double *__restrict__ A /*[lda
                 const bool finished = conv || n_feval > p.max_feval || n_iter >= p.max_iterations;
                 if (finished || n_iter >= pass_cap) retire(finished);
             }
+        }
+    }
+    if constexpr (LAZYQ) {
+        if (threadIdx.x == 0 && lz_trips) {
+            atomicAdd(&hdr->dbg_trips, lz_trips);
+            atomicAdd(&hdr->dbg_rounds, lz_skipped);
         }
     }
     {   // wave totals (fixed-order butterfly), one atomic pair per wave
@@ -2225,7 +2236,7 @@ int g_qp_live_occ = 3;         // register budget of k_qp_quad beside the consum
 int g_qp_live_blocks = 48;     // CUs given to the consumers (one block of 16 waves each)
 #define QP_LIVE_LDS 163840     // a CU's LDS
 int g_qp_quad_occ = 3;         // register budget of k_qp_quad: waves per SIMD (2, 3 or 4)
-int g_qp_quad_lazy = 0;        // four-lane QP, opt-in: the stopping test of a pass decided in the next trip (LAZYQ) -- same results; 497/497/494 it/s with, 503/498 without at the driver's flags, 524/523 against 522 at the default flags: the wave-wide skip is rare and the kernel spills 22 VGPRs instead of 7
+int g_qp_quad_lazy = 0;        // four-lane QP, opt-in: the stopping test of a pass decided in the next trip (LAZYQ) -- same results; 497/497/494 it/s with, 503/498 without at the driver's flags, 524/523 against 522 at the default flags: a third of the trips skip the test for the whole wave (qp_profile: 32 % in iterations 8-14, 31 % around 30), which saves less than the extra partial trip per batch and the 22 VGPR spills (7 without) cost
 int g_qp_fused_order = 1;   // four-lane QP: the sample order of the NEXT update is formed by extra blocks of this update's continuation launch (k_qp_wave_ord)
 int g_qp_wave_lazy = 1;        // wave-per-sample kernel: stopping test of a pass decided at the top of the next one, skipped when <d, d> proves it negative (0: after every pass)
 int g_qp_wave_mem1 = 1;        // continuation launches of the wave-per-sample kernel: 1 = the memory-1 instantiation (no f_mem array: 311 fewer SGPR spills), 0 = the generic one (A/B)
@@ -3003,6 +3014,9 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                     "%u handed over at the pass cap\n", h.dbg_waves, (double)h.dbg_trips / h.dbg_waves,
                     (double)h.dbg_rounds / (4.0 * h.dbg_trips), (double)h.total_passes / (double)n, h.n_long,
                     h.n_overflow);
+        if (g_qp_profile && quad_mode && h.dbg_trips)
+            fprintf(stderr, "[qp_profile] four-lane kernel, lazy stopping test: %u trips owed a test, %u of them (%.1f %%) "
+                    "skipped it for the whole wave\n", h.dbg_trips, h.dbg_rounds, 100.0 * h.dbg_rounds / h.dbg_trips);
         if (g_qp_profile && !row_mode) {
             QpDebug d;
             AA_CHECK_HIP(ctx_memcpy(c, &d, base + 64, sizeof(d), hipMemcpyDeviceToHost));

@@ -9,7 +9,7 @@ X = bench.synthetic_rows(0, n); C0, Z0 = bench.start_factors(n, k)
 ctx = _backend.Context(dtype="float32")
 ctx.set_data(X)
 ctx.set_state(C0, Z0, np.ones(k)); ctx.prepare()
-ctx.outer_iterations(30, dict(max_iterations=1), {})
+ctx.outer_iterations(int(os.environ.get("QP_AT", "30")), dict(max_iterations=1), {})
 print('stream probe: %.4f ms -> %.2f TB/s' % (ctx.time_kernel(2, 20), n * p * 4 / ctx.time_kernel(2, 20) / 1e9), flush=True)
 if os.environ.get('QP_PROFILE'): _backend.set_option('qp_profile', 1)
 for it in range(6):
