@@ -176,7 +176,26 @@ int aa_device_count(int *count);
  *                               WITHOUT a cost buffer returns with its work in flight
  *   "fuse_finalize"     0|1    1 (default): fewer, fatter launches in the dictionary update (set-up
  *                               kernel, scalar stages inside the finalize kernels, two-launch line
- *                               search, x update inside the gradient kernel) */
+ *                               search, x update inside the gradient kernel)
+ * Round 4 -- none of these changes a bit of any result (tests/test_gpu_longrun.py:
+ * test_schedule_knobs_do_not_change_a_bit):
+ *   "qp_fused_order"    0|1    1 (default): the sample order of the NEXT weights update is formed by extra
+ *                               blocks of this update's continuation launch instead of two launches in
+ *                               front of the four-lane kernel
+ *   "qp_wave_lazy"      0|1    1 (default): the wave-per-sample kernel decides the stopping test of a pass at
+ *                               the top of the next one and skips it when <d, d> proves it negative
+ *   "qp_quad_lazy"      0|1    the same in the four-lane kernel (default 0: no gain there)
+ *   "fin_in_last"       0|1    1 (default): the two reductions of a projection are finalized by the last
+ *                               block of their pass (write-through partials), not by a launch of their own
+ *   "setup_in_grad"     0|1    1 (default): the dictionary update's set-up block is block 0 of its first
+ *                               gradient launch
+ *   "gram_side"         0|1    Z'Z of the refresh after a weights update on the side stream (default 0)
+ *   "grad_side"         0|1    1 (default): the tail of a one-iteration dictionary SPG (g_new, x += lambda d,
+ *                               BB stage, residual projection) on the side stream beside the weights QP
+ *   "pack_comm"         0|1    multi-rank, 1 (default): three small reductions ride in the tail of the
+ *                               all-reduce that follows them (11 collectives per outer iteration, not 14)
+ *   "proj_small"        0|1|2  1 (default): columns of <= 8192 rows are projected by one block each;
+ *                               2: up to 16 384 rows (slower at 12 500) */
 int aa_set_option(const char *name, int value);
 
 /* -------------------------------------------- stateless ops (unit-test surface) */
