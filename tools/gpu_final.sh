@@ -17,9 +17,9 @@ python3 -c "import json; b=json.load(open('gpurun_out/final_bench_f64.json')); p
 step "bench 12 500-row shard"
 timeout -k 10 300 python bench.py --n 12500 --no-cpu-baseline --no-f64 > gpurun_out/final_bench_n12500.json 2> gpurun_out/final_bench_n12500.err || exit 1
 python3 -c "import json; b=json.load(open('gpurun_out/final_bench_n12500.json')); print(b['value'], b['ms_per_step'])"
-step "12 500-row shard with the four-lane QP kernel (default there: the row kernel)"
-AA_HIP_OPTIONS=qp_mode=4 timeout -k 10 300 python bench.py --n 12500 --no-cpu-baseline --no-f64 > gpurun_out/final_bench_n12500_quad.json 2> gpurun_out/final_bench_n12500_quad.err || exit 1
-python3 -c "import json; b=json.load(open('gpurun_out/final_bench_n12500_quad.json')); print(b['value'], b['ms_per_step'])"
+step "12 500-row shard with the row QP kernel (default: the four-lane kernel)"
+AA_HIP_OPTIONS=qp_mode=3 timeout -k 10 300 python bench.py --n 12500 --no-cpu-baseline --no-f64 > gpurun_out/final_bench_n12500_row.json 2> gpurun_out/final_bench_n12500_row.err || exit 1
+python3 -c "import json; b=json.load(open('gpurun_out/final_bench_n12500_row.json')); print(b['value'], b['ms_per_step'])"
 step "C2 / C3 stand-ins"
 timeout -k 10 300 python tools/bench_configs.py 200 > gpurun_out/final_configs.jsonl 2> gpurun_out/final_configs.err || { tail -5 gpurun_out/final_configs.err; exit 1; }
 cat gpurun_out/final_configs.jsonl
