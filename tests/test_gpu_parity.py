@@ -888,6 +888,7 @@ def test_rccl_path_single_rank(cdr, orc):
             _backend.set_option("proj_list_cap", 2048)
             _backend.set_option("proj_small", 1)
             _backend.set_option("proj_check", 0)
+            _backend.set_option("pack_comm", 1)
 
     # bit-for-bit: both paths on the candidate-list projection (the single-rank default for
     # columns this short, the one-kernel threshold search, sums in another order)
@@ -902,6 +903,11 @@ def test_rccl_path_single_rank(cdr, orc):
     b1 = run(True, proj_small=0)
     assert b1[0] == b2[0] and np.array_equal(b1[1], b2[1]) and np.array_equal(b1[3], b2[3]) and np.array_equal(b1[4], b2[4])
     assert np.array_equal(b2[5], [1.5, 2.5])
+    # small reductions riding in the tail of the next all-reduce (pack_comm, round 4: 11 collectives per outer
+    # iteration instead of 14) or travelling on their own: the same values reach the same consumers
+    for p2p in (False, True):
+        b3 = run(True, p2p=p2p, proj_small=0, pack_comm=0)
+        assert b1[0] == b3[0] and np.array_equal(b1[1], b3[1]) and np.array_equal(b1[3], b3[3]) and np.array_equal(b1[4], b3[4])
     small = run(False)                                   # one-kernel threshold search: rounding level
     assert abs(small[0] - a[0]) < 1e-12 * abs(a[0]) and np.abs(small[1] - a[1]).max() < 1e-6 * abs(a[0])
     assert np.abs(small[3] - a[3]).max() < 1e-6 and np.abs(small[4] - a[4]).max() < 1e-5
