@@ -411,7 +411,7 @@ extern int g_proj_check_always;   // kernels_tall.hip
 extern int g_proj_list_cap;       // kernels_tall.hip
 extern int g_row_local_variant;   // kernels_gemm.hip
 extern int g_row_local_waves;     // kernels_gemm.hip
-extern int g_row_local_split, g_row_local_chunk, g_row_local_acc64, g_row_local_ring, g_row_local_nt, g_row_local_prio, g_row_local_early;     // kernels_gemm.hip
+extern int g_row_local_split, g_row_local_chunk, g_row_local_acc64, g_row_local_ring, g_row_local_nt, g_row_local_prio, g_row_local_early, g_row_local_reverse;     // kernels_gemm.hip
 extern int g_row_local_stagger;   // kernels_gemm.hip
 extern int g_reduce_rows_unroll;  // kernels_gemm.hip
 extern int g_f64_mfma;            // kernels_gemm.hip

@@ -917,7 +917,11 @@ __global__ __launch_bounds__(1024) void k_row_local_f32_dma(const float *__restr
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     float *bs = dma_smem;                                   // [2][KP * SB]
     float *xs = dma_smem + 2 * KP * SB + wave * (R * 256);  // R pieces of 256 floats, wave-private
-    const long r0 = ((long)blockIdx.x * W + wave) * 32;
+    // prio bit 1 (row_local_reverse): the row tiles from the last to the first -- the pass before this one
+    // (reduce-over-rows) walks the rows upwards and leaves the LAST rows in the memory-side cache, the pass
+    // after it starts at the first rows again
+    const long blk = (prio & 2) ? (long)(gridDim.x - 1 - blockIdx.x) : (long)blockIdx.x;
+    const long r0 = (blk * W + wave) * 32;
     const bool active = r0 < n_pad;
     const long r0c = active ? r0 : n_pad - 32;
     const int h = lane >> 5, j = lane & 31;
@@ -1008,10 +1012,10 @@ __global__ __launch_bounds__(1024) void k_row_local_f32_dma(const float *__restr
         // the four slots of this tile are free again (their reads were waited for before the MFMAs)
         // prio: the wave that is about to put 4 KB in flight goes ahead of the waves that have
         // matrix instructions and float64 sums to issue (experiment, aa_set_option row_local_prio)
-        if (prio) __builtin_amdgcn_s_setprio(3);
+        if (prio & 1) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int i = 0; i < 4; ++i) issue_piece();
-        if (prio) __builtin_amdgcn_s_setprio(0);
+        if (prio & 1) __builtin_amdgcn_s_setprio(0);
     };
     auto flush = [&](f32x16 &acc) {
 #pragma unroll
@@ -1473,6 +1477,7 @@ int g_row_local_ring = 8;      // LDS-DMA kernel: pieces in a wave's ring (8: on
                                // fastest, 0.376 ms back to back against 0.388 at 11; 0: what LDS allows)
 int g_row_local_nt = 0;        // LDS-DMA kernel: non-temporal hint on the X stream
 int g_row_local_early = 0;     // LDS-DMA kernel: fragments to registers first, the next pieces issued before the MFMAs
+int g_row_local_reverse = 0;   // LDS-DMA kernel, experiment: row tiles from the last to the first, so that the rows the previous pass read last come first (memory-side cache reuse between consecutive passes): no effect, 499 / 488 / 493 against 494 / 496 it/s, pass times unchanged
 int g_row_local_prio = 0;      // LDS-DMA kernel: raised wave priority while a wave issues its DMA pieces
 int g_row_local_chunk = 0;     // experiment: force the column chunk of the block-tiled float32 kernel (0: by size)
 int g_row_local_split = 1;     // block-tiled kernels: split the contraction over column chunks when there are few row blocks
@@ -1512,7 +1517,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
             attr_done_e[c->device & 63] = true;                                                    \
         }                                                                                          \
         hipLaunchKernelGGL((k_row_local_f32_dma<8, false, true>), grid, blk, lds, c->stream, c->X.as<float>(), \
-                           c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, g_row_local_prio);   \
+                           c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, (g_row_local_prio ? 1 : 0) | (g_row_local_reverse ? 2 : 0));   \
     } while (0)
 #define RLD(RV, NTV)                                                                               \
     do {                                                                                           \
@@ -1523,7 +1528,7 @@ int launch_row_local(Ctx *c, const void *B_wideT, double *out_tall)
             attr_done[c->device & 63] = true;                                                      \
         }                                                                                          \
         hipLaunchKernelGGL((k_row_local_f32_dma<RV, NTV>), grid, blk, lds, c->stream, c->X.as<float>(),   \
-                           c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, g_row_local_prio);   \
+                           c->p_pad, B, (int)c->p_pad, out_tall, c->n_pad, W, (g_row_local_prio ? 1 : 0) | (g_row_local_reverse ? 2 : 0));   \
     } while (0)
 #define RLD2(RV) do { if (g_row_local_early && RV == 8) RLDE(); else if (g_row_local_nt) RLD(RV, true); else RLD(RV, false); } while (0)
         PASS_NAME(1, "k_row_local_f32_dma<%d>", R);

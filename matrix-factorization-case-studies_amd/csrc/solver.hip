@@ -560,6 +560,8 @@ int aa_set_option(const char *name, int value)
         g_row_local_early = value != 0;
     } else if (!strcmp(name, "row_local_prio")) {
         g_row_local_prio = value != 0;
+    } else if (!strcmp(name, "row_local_reverse")) {
+        g_row_local_reverse = value != 0;
     } else if (!strcmp(name, "row_local_chunk")) {
         AA_REQUIRE(value >= 0, AA_ERR_ARG, "row_local_chunk must be >= 0");
         g_row_local_chunk = value;
