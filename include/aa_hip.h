@@ -192,8 +192,8 @@ int aa_device_count(int *count);
  *   "gram_side"         0|1    Z'Z of the refresh after a weights update on the side stream (default 0)
  *   "grad_side"         0|1    1 (default): the tail of a one-iteration dictionary SPG (g_new, x += lambda d,
  *                               BB stage, residual projection) on the side stream beside the weights QP
- *   "pack_comm"         0|1    multi-rank, 1 (default): three small reductions ride in the tail of the
- *                               all-reduce that follows them (11 collectives per outer iteration, not 14)
+ *   "pack_comm"         0|1    multi-rank, 1 (default): four small reductions ride in the tail of the
+ *                               all-reduce that follows them (10 collectives per outer iteration, not 14)
  *   "proj_small"        0|1|2  1 (default): columns of <= 8192 rows are projected by one block each;
  *                               2: up to 16 384 rows (slower at 12 500) */
 int aa_set_option(const char *name, int value);

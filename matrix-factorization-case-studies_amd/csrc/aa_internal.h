@@ -201,10 +201,14 @@ struct Ctx {
         aa_spg_params sp;
         double *red = nullptr;
         ProjState *ps = nullptr;
+        double *gather = nullptr;              // where its [world][NV][KP] values sit
+        long count = 0;
     };
     RidePost ride, ride_grad;
-    double *ride_dst = nullptr;
-    long ride_count = 0;
+    double *ride_dst = nullptr;                // explicit tail content of a wide buffer (Z'Z behind Z'X): its start
+    long ride_count = 0;                       // ... and length
+    double *ride_gather_next = nullptr;        // the next closing reduction of a projection goes here and waits (ride)
+    bool weights_follow = false;               // a weights update follows this dictionary update in the same iteration
     bool ride_grad_next = false;               // the next launch_grad's dot rides with the projection that follows it
 
     // data

@@ -1286,11 +1286,17 @@ int launch_reduce_rows_finish(Ctx *c, double *out_wide, void *outT, int extra_sl
     AA_CHECK_HIP(hipGetLastError());
     if ((c->world > 1 || c->force_comm)) {
         // riders in the buffer's tail (Ctx::ride*): one all-reduce for the lot
+        double *tail = out_wide + elems;
         long extra = 0;
-        if (c->ride_dst == out_wide + elems) extra = c->ride_count;
-        AA_REQUIRE(extra > 0 || !c->ride.on, AA_ERR_STATE, "a reduction was left waiting for an all-reduce that did not come");
+        if (c->ride_dst == tail) extra = c->ride_count;
+        if (c->ride.on) {
+            AA_REQUIRE(c->ride.gather >= tail && c->ride.gather + c->ride.count <= tail + AA_WIDE_TAIL(c->KP), AA_ERR_STATE,
+                       "a reduction was left waiting for an all-reduce that did not come");
+            const long end = (long)(c->ride.gather - tail) + c->ride.count;
+            if (end > extra) extra = end;
+        }
         AA_CHECK(comm_allreduce(c, out_wide, elems + extra, 0));
-        if (extra && c->ride.on) AA_CHECK(launch_ride_post(c, &c->ride, out_wide + elems));
+        if (c->ride.on) AA_CHECK(launch_ride_post(c, &c->ride, c->ride.gather));
         c->ride_dst = nullptr;
         c->ride_count = 0;
         if (outT && outT != (void *)out_wide) AA_CHECK(launch_wide_to_T(c, out_wide, outT));

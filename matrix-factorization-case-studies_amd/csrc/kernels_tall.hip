@@ -2102,9 +2102,9 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
         // riders (pack_comm): a projection's closing reduction goes with the wide all-reduce that follows it
         // (ride_dst set by the caller), the gradient's <d, g_new> with the first reduction of the residual
         // projection behind it (second region of the gather buffer)
-        const bool rides_wide = c->ride_dst && kind == POST_FIN && !gated;
+        const bool rides_wide = c->ride_gather_next && kind == POST_FIN && !gated;
         const bool rides_first = c->ride_grad_next && kind == POST_SCALAR_SUM && !gated;
-        if (rides_wide) gather = c->ride_dst;
+        if (rides_wide) gather = c->ride_gather_next;
         if (rides_first) gather += region;
         hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(FIN_NT), 0, c->stream, part, nb, NV,
                            c->KP, max_mask, red, gate, (int)POST_NONE, mode, c->k, ps,
@@ -2114,8 +2114,9 @@ static int finalize_and_post(Ctx *c, int NV, unsigned max_mask, int kind, int mo
             rp.on = true;
             rp.kind = kind; rp.mode = mode; rp.NV = NV; rp.slot = slot; rp.gated = 0; rp.stage_after = stage_after;
             rp.max_mask = max_mask; rp.sp = spv; rp.red = red; rp.ps = ps;
-            if (rides_wide) c->ride_count = (long)c->world * NV * c->KP;
-            c->ride_grad_next = false;
+            rp.gather = gather; rp.count = (long)c->world * NV * c->KP;
+            if (rides_wide) c->ride_gather_next = nullptr;
+            else c->ride_grad_next = false;
             AA_CHECK_HIP(hipGetLastError());
             return AA_OK;
         }

@@ -410,7 +410,7 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
         // multi-rank: the closing reduction of this projection (<d,g>, <d,d>, ...: read by the line search
         // only) rides with the all-reduce of Q = D'X
         const bool multi = c->world > 1 || c->force_comm;
-        if (multi && g_pack_comm && data && !c->slots_aa) c->ride_dst = c->Q.as<double>() + (size_t)KP * c->p_pad;
+        if (multi && g_pack_comm && data && !c->slots_aa) c->ride_gather_next = c->Q.as<double>() + (size_t)KP * c->p_pad;
         AA_CHECK(launch_proj(c, x, c->gk.as<double>(), 0.0, SC_ALPHA, PROJ_DIR)); // spg.py:191-194,206
         if (data) {
             AA_CHECK(launch_reduce_rows(c, c->Dt.as<double>(), c->Q.as<double>(), nullptr));
@@ -461,6 +461,11 @@ static int dictionary_update(Ctx *c, const aa_spg_params *sp, aa_spg_stats *st, 
             AA_CHECK(launch_grad(c, c->Gr.as<double>(), c->H.as<double>(), c->gn.as<double>(), gscale,
                                  c->Dt.as<double>(), SC_DGN, nullptr, sp, ST_BB));
         }
+        // multi-rank, a weights update next: the closing sums of the residual projection (convergence flags
+        // only: read by the judge behind the weights update) wait for the Z'X all-reduce and ride behind Z'Z
+        if (multi && g_pack_comm && data && !c->slots_aa && c->weights_follow && sp->max_iterations == 1 && !st &&
+            g_fuse_finalize)
+            c->ride_gather_next = c->ZtX.as<double>() + (size_t)KP * c->p_pad + (size_t)KP * KP;
         // spg.py:250-276; with one SPG iteration per update nobody waits for the flags: side stream
         if (grad_on_side) {
             const int rc = launch_proj(c, x, c->gn.as<double>(), 1.0, -1, PROJ_RES, sp, ST_CONV);
@@ -1175,7 +1180,10 @@ int aa_outer_iterations(aa_ctx *h, int n_outer, const aa_spg_params *spg, const 
     AA_CHECK_HIP(hipMemsetAsync(slot, 0, sizeof(int), c->stream));
     auto one_iteration = [&]() -> int {
         bool recorded = false;
-        AA_CHECK(dictionary_update(c, spg, nullptr, true, costs ? cd : nullptr, slot, &recorded));
+        c->weights_follow = true;
+        const int rcd = dictionary_update(c, spg, nullptr, true, costs ? cd : nullptr, slot, &recorded);
+        c->weights_follow = false;
+        AA_CHECK(rcd);
         if (costs && !recorded) {
             AA_CHECK(ensure_ckz(c));
             AA_CHECK(launch_aa_cost(c, cd, slot));
@@ -1270,7 +1278,10 @@ int aa_iterate(aa_ctx *h, const aa_iter_params *ip, const aa_spg_params *spg, co
             }
             if (ip->update_dictionary) {
                 bool recorded = false;
-                AA_CHECK(dictionary_update(c, spg, nullptr, true, cd, slot, &recorded));
+                c->weights_follow = ip->update_weights != 0;
+                const int rcd = dictionary_update(c, spg, nullptr, true, cd, slot, &recorded);
+                c->weights_follow = false;
+                AA_CHECK(rcd);
                 if (!recorded) {
                     AA_CHECK(ensure_ckz(c));
                     AA_CHECK(launch_aa_cost(c, cd, slot));

@@ -903,7 +903,7 @@ def test_rccl_path_single_rank(cdr, orc):
     b1 = run(True, proj_small=0)
     assert b1[0] == b2[0] and np.array_equal(b1[1], b2[1]) and np.array_equal(b1[3], b2[3]) and np.array_equal(b1[4], b2[4])
     assert np.array_equal(b2[5], [1.5, 2.5])
-    # small reductions riding in the tail of the next all-reduce (pack_comm, round 4: 11 collectives per outer
+    # small reductions riding in the tail of the next all-reduce (pack_comm, round 4: 10 collectives per outer
     # iteration instead of 14) or travelling on their own: the same values reach the same consumers
     for p2p in (False, True):
         b3 = run(True, p2p=p2p, proj_small=0, pack_comm=0)
