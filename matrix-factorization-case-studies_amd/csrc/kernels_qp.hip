@@ -1019,6 +1019,12 @@ __device__ __forceinline__ void qp_wave_body(const double *__restrict__ A /*[KQ]
     unsigned int static_slot = wave_id;
     // next slot of this wave, or 0xffffffff: static stride (mode 0 / 2), tickets (mode 1)
     auto next_slot = [&]() -> unsigned int {
+        if (lv.mode == 3) {                            // plain tickets (qp_wave_queue): a wave takes the next slot when it is free
+            unsigned int tk = 0u;
+            if (lane == 0) tk = atomicAdd(&hdr->next_overflow, 1u);
+            tk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
+            return tk < count ? tk : 0xffffffffu;
+        }
         if (lv.mode != 1) {
             while (static_slot < count) {
                 const unsigned int sl = static_slot;
@@ -2230,6 +2236,7 @@ int g_qp_quad_refill = 16;     // idle sample slots (of 16) of a wave that trigg
 int g_qp_quad_cap = 0;         // passes after which k_qp_quad parks a sample for the wave kernel; 0: by size --
                                // 32 from 65 536 samples per GPU (100 000: 1.985 against 2.010 ms per outer
                                // iteration), 24 below (12 500: 0.572 against 0.582)
+int g_qp_wave_queue = 0;        // continuation launch, experiment: waves take the parked samples by ticket instead of fixed strides (slower: 492-494 against 496-499 it/s; the chains are latency-bound and four waves share a SIMD at almost no cost)
 int g_qp_wave_blocks = 1024;   // blocks (4 waves each) of the wave-per-sample kernel when it finishes parked samples
 int g_qp_live = 0;             // k_qp_quad hands parked samples to a concurrent k_qp_wave launch (QpLive)
 int g_qp_live_occ = 3;         // register budget of k_qp_quad beside the consumers (waves per SIMD)
@@ -2394,7 +2401,7 @@ __global__ __launch_bounds__(256) void k_qp_wave_ord(QpOrder od, const double *_
                                                      const QpCarry *__restrict__ ovf, int park_at = 1 << 30,
                                                      unsigned int *__restrict__ n_parked = nullptr,
                                                      int *__restrict__ park_rows = nullptr,
-                                                     QpCarry *__restrict__ park = nullptr)
+                                                     QpCarry *__restrict__ park = nullptr, int queue = 0)
 {
     if ((int)blockIdx.x < od.blocks) {
         qp_order_block(od);
@@ -2403,7 +2410,7 @@ __global__ __launch_bounds__(256) void k_qp_wave_ord(QpOrder od, const double *_
     qp_wave_body<32, true, LAZY>(A, B, stride_j, stride_t, bscale, Z, ldz, (long)-1, k, p, iters, hdr, ovf_rows, ovf,
                                  (double *)nullptr, (const int *)nullptr, (const unsigned int *)nullptr, park_at,
                                  n_parked, park_rows, park,
-                                 QpLive{0, 0, 0u, 0u, nullptr, nullptr}, 0, 0L, (unsigned int)od.blocks);
+                                 QpLive{queue ? 3 : 0, 0, 0u, 0u, nullptr, nullptr}, 0, 0L, (unsigned int)od.blocks);
 }
 
 // device-side set-up of the QP scratch: header zeroed, A = D G D padded to KQ and KW,
@@ -2903,11 +2910,13 @@ int launch_qp(Ctx *c, const double *A_host, const double *Btall, long stride_j, 
                     if (g_qp_wave_lazy)
                         hipLaunchKernelGGL(k_qp_wave_ord<true>, og, dim3(256), 0, s2, od, A2d, Btall, stride_j, stride_t,
                                            bsd, Ztall, ldz, k, *p, iters_dev, hdr, (const int *)ovf_rows,
-                                           (const QpCarry *)ovf);
+                                           (const QpCarry *)ovf, 1 << 30, (unsigned int *)nullptr, (int *)nullptr,
+                                           (QpCarry *)nullptr, g_qp_wave_queue);
                     else
                         hipLaunchKernelGGL(k_qp_wave_ord<false>, og, dim3(256), 0, s2, od, A2d, Btall, stride_j, stride_t,
                                            bsd, Ztall, ldz, k, *p, iters_dev, hdr, (const int *)ovf_rows,
-                                           (const QpCarry *)ovf);
+                                           (const QpCarry *)ovf, 1 << 30, (unsigned int *)nullptr, (int *)nullptr,
+                                           (QpCarry *)nullptr, g_qp_wave_queue);
                     c->qp_perm_ready = true;
                     c->qp_perm_n = n;
                 } else

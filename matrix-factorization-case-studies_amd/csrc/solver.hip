@@ -594,6 +594,8 @@ int aa_set_option(const char *name, int value)
         g_proj_check_always = value != 0;
     } else if (!strcmp(name, "fuse_finalize")) {
         g_fuse_finalize = value != 0;
+    } else if (!strcmp(name, "qp_wave_queue")) {
+        g_qp_wave_queue = value != 0;
     } else if (!strcmp(name, "qp_quad_lazy")) {
         g_qp_quad_lazy = value != 0;
     } else if (!strcmp(name, "pack_comm")) {
