@@ -4,15 +4,16 @@
 models one after the other, all drawing their starting factors from ONE shared ``RandomState``,
 and keep the one with the lowest cost.  For the problems those drivers run (161 MB / 15 MB
 matrices) one fit leaves most of an MI355X idle -- an outer iteration is a few dozen dependent
-launches of a few microseconds each -- so ``fit_restarts`` draws the starting factors of all
-restarts first, in the drivers' order (so every restart starts exactly where it would in the
-sequential loop), and then
+launches of a few microseconds each -- so ``fit_restarts`` draws the starting factors of the
+restarts in the drivers' order (so every restart starts exactly where it would in the sequential
+loop; a worker thread draws while the device already iterates on the first restarts: ``_RestartFeed``),
+and
 
 * GPNH models, and AA models with the drivers' settings (one SPG iteration per dictionary update,
   any delta, fewer than 65 536 samples, k <= 16): lays the restarts SIDE BY SIDE in the component slots of
   one set of device arrays, where they share every launch of an outer iteration; a restart that stops
   hands its slot to the next one (``_fit_gpnh_slots`` / aa_gpnh_slots_*, ``_fit_aa_slots`` /
-  aa_slots_*): 3.5-5x the sequential loop's speed on the JRA-55- and HadISST-shaped problems with
+  aa_slots_*): 3.4-6x the sequential loop's speed on the JRA-55- and HadISST-shaped problems with
   ``n_init = 100``;
 * other AA settings: runs the fits on worker threads, each on its own device context; the contexts
   of a device share one resident copy of the data (useful with ``devices=[...]``: whole restarts
@@ -54,17 +55,28 @@ def _print_tables(models, tables, title, rule):
             print('*** Converged at iteration {:d} ***'.format(len(finals)))
 
 
-def _slots_eligible(models, data):
-    """GPNH restarts that can share one set of device arrays: same hyper-parameters, at least four
+_GPNH_KEYS = ("n_components", "lambda_W", "tolerance", "max_iterations", "stopping_criterion", "verbose",
+              "require_monotonic_cost_decrease", "dtype", "weights_solver_kwargs", "dictionary_solver_kwargs")
+_AA_KEYS = ("n_components", "delta", "tolerance", "max_iterations", "stopping_criterion", "verbose",
+            "require_monotonic_cost_decrease", "dtype", "weights_solver_kwargs", "dictionary_solver_kwargs",
+            "scale_factors_solver_kwargs")
+
+
+def _same_settings(m, m0):
+    """A later restart can sit beside the first one: same class, same hyper-parameters."""
+    if type(m) is not type(m0):
+        return False
+    keys = _AA_KEYS if isinstance(m0, ArchetypalAnalysis) else _GPNH_KEYS
+    return all(getattr(m, a) == getattr(m0, a) for a in keys)
+
+
+def _slots_eligible(m0, n_models, data):
+    """GPNH restarts that can share one set of device arrays (every restart with the first one's
+    hyper-parameters: _same_settings; the others take the generic path), at least two
     restarts of k components in the 64 component slots of the tall arrays.  Mirrors the
     preconditions of aa_gpnh_slots_begin (csrc/solver.hip): QPs of more than four passes take the
     AA slots' four-lane / wave-per-sample launch, which exists for fewer than 65 536 samples."""
-    m0 = models[0]
-    if not all(isinstance(m, GPNHConvexCoding) for m in models) or len(models) < 2:
-        return False
-    keys = ("n_components", "lambda_W", "tolerance", "max_iterations", "stopping_criterion", "verbose",
-            "require_monotonic_cost_decrease", "dtype", "weights_solver_kwargs", "dictionary_solver_kwargs")
-    if any(getattr(m, a) != getattr(m0, a) for m in models[1:] for a in keys):
+    if not isinstance(m0, GPNHConvexCoding) or n_models < 2:
         return False
     k = m0.n_components
     # (weights QPs of at most four SPG passes -- the drivers' setting is one -- run in the
@@ -90,6 +102,101 @@ def _gpnh_slot_count(m0, n_samples, n_slots):
         room = 32
     cap = max(1, room // k)
     return cap if n_slots is None else max(1, min(int(n_slots), cap))
+
+
+class _RestartFeed(object):
+    """The models and starting factors of the restarts, produced in the drivers' order -- make_model(),
+    then that model's draws from the shared ``RandomState``, restart after restart exactly as the
+    sequential loop interleaves them -- by ONE worker thread, so that the device iterates on the first
+    restarts while the host draws the later ones (a draw is 1-3 ms: the reference's RNG order asks for a
+    fresh n x k weights matrix per restart, a FurthestSum start for a chain of device launches on a
+    context of its own).  ``wait(i)`` blocks until restart i is there and re-raises what the producer
+    raised."""
+
+    def __init__(self, make_model, data, n_init):
+        self.models = [None] * n_init
+        self.starts = [None] * n_init
+        self.same = [True] * n_init               # same class and hyper-parameters as the first restart
+        self._ready = [threading.Event() for _ in range(n_init)]
+        self._error = None
+        self._make, self._data = make_model, data
+        _backend.load_library()
+        _backend.release_device_cache()
+        self._thread = threading.Thread(target=self._produce, name="restart-draws")
+        self._thread.daemon = True
+        self._thread.start()
+
+    def _produce(self):
+        data, cache = self._data, {}              # data-dependent constants of the initialisers: |X| mean,
+        draw_ctx = None                           # FurthestSum's distance columns; ONE context for all draws
+        try:
+            for i in range(len(self.models)):     # RNG draws in the sequential loop's order
+                m = self._make()
+                if not isinstance(m, (ArchetypalAnalysis, GPNHConvexCoding)):
+                    raise TypeError("fit_restarts handles ArchetypalAnalysis and GPNHConvexCoding models")
+                needs_device = (m.init == 'furthest_sum' or (m.init is None and isinstance(m, ArchetypalAnalysis)))
+                if needs_device and draw_ctx is None and _backend.distributed_env() is None:
+                    draw_ctx = _backend.Context(dtype=m.dtype)
+                    draw_ctx.set_data(data)
+                extra = dict(_draw_ctx=draw_ctx) if (needs_device and draw_ctx is not None) else {}
+                if isinstance(m, ArchetypalAnalysis):
+                    C0, Z0, a0 = m._aa(data, _draw_only=True, _cache=cache, **extra)
+                    start = dict(dictionary=C0, weights=Z0, alpha=a0)
+                else:
+                    W0, Z0 = m._gpnh_convex_coding(data, _draw_only=True, _cache=cache, **extra)
+                    start = dict(dictionary=W0, weights=Z0)
+                if i > 0:
+                    self.same[i] = _same_settings(m, self.models[0])
+                self.models[i], self.starts[i] = m, start
+                self._ready[i].set()
+        except BaseException as e:                # handed to whoever waits
+            self._error = e
+        finally:
+            if draw_ctx is not None:
+                draw_ctx.close()
+            for ev in self._ready:
+                ev.set()
+
+    def wait(self, i):
+        self._ready[i].wait()
+        if self.models[i] is None:
+            raise self._error
+        return i
+
+    def join(self):
+        self._thread.join()
+        if self._error is not None:
+            raise self._error
+
+
+class _FeedView(object):
+    """models / starts of a share of the restarts as the slot loops index them: item j is restart idx[j],
+    and asking for it waits until the feed has produced it."""
+
+    def __init__(self, feed, idx, what):
+        self._feed, self._idx, self._what = feed, idx, what
+
+    def __len__(self):
+        return len(self._idx)
+
+    def __getitem__(self, j):
+        i = self._feed.wait(self._idx[j])
+        return (self._feed.models if self._what == "models" else self._feed.starts)[i]
+
+    def same(self, j):
+        i = self._feed.wait(self._idx[j])
+        return self._feed.same[i]
+
+
+def _next_pending(pending, models, left):
+    """The next restart that can sit beside the first one; restarts with other settings go to `left`
+    (the generic path runs them)."""
+    while pending:
+        i = pending.pop(0)
+        if not hasattr(models, "same") or models.same(i):
+            return i
+        left.append(i)
+    return None
 
 
 def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
@@ -123,9 +230,12 @@ def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
         prof.update(load=0.0, run=0.0, fetch=0.0, polls=0, slots=n_slots)
 
         def load(r):
-            i = pending.pop(0)
+            i = _next_pending(pending, models, fallback)
+            if i is None:
+                return
+            start = starts[i]                     # (waits for the draw if the feed is behind)
             t0 = time.perf_counter()
-            ctx.gpnh_slots_load(r, starts[i]["dictionary"], starts[i]["weights"])
+            ctx.gpnh_slots_load(r, start["dictionary"], start["weights"])
             owner[r] = i
             loaded_at[r] = time.perf_counter()
             prof["load"] += loaded_at[r] - t0
@@ -176,16 +286,11 @@ def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
     return fallback
 
 
-def _aa_slots_eligible(models, data):
+def _aa_slots_eligible(m0, n_models, data):
     """AA restarts that can share one set of device arrays (aa_slots_*): the drivers' setting -- one SPG
-    iteration per dictionary update -- same hyper-parameters, fewer than 65 536 samples, k <= 16."""
-    m0 = models[0]
-    if not all(type(m) is ArchetypalAnalysis for m in models) or len(models) < 2:
-        return False
-    keys = ("n_components", "delta", "tolerance", "max_iterations", "stopping_criterion", "verbose",
-            "require_monotonic_cost_decrease", "dtype", "weights_solver_kwargs", "dictionary_solver_kwargs",
-            "scale_factors_solver_kwargs")
-    if any(getattr(m, a) != getattr(m0, a) for m in models[1:] for a in keys):
+    iteration per dictionary update -- fewer than 65 536 samples, k <= 16 (and every restart with the
+    first one's hyper-parameters: _same_settings)."""
+    if type(m0) is not ArchetypalAnalysis or n_models < 2:
         return False
     k = m0.n_components
     dkw = dict(m0.dictionary_solver_kwargs)
@@ -217,7 +322,7 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
     prof = slots_profile
     prof.update(load=0.0, run=0.0, fetch=0.0, polls=0, slots=n_slots)
     ctx = _backend.Context(dtype=m0.dtype, device=device)
-    errors = {}
+    errors, left = {}, []
     try:
         ctx.set_data(data)
         mono_tol = m0.tolerance
@@ -233,8 +338,11 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
                            m0.weights_solver_kwargs, mono_tolerance=mono_tol, delta=m0.delta,
                            scale_kw=m0.scale_factors_solver_kwargs)
         for r in range(n_slots):                  # the first group starts together
-            i = pending.pop(0)
-            ctx.aa_slots_load(r, starts[i]["dictionary"], starts[i]["weights"], starts[i]["alpha"])
+            i = _next_pending(pending, models, left)
+            if i is None:
+                break
+            start = starts[i]
+            ctx.aa_slots_load(r, start["dictionary"], start["weights"], start["alpha"])
             owner[r] = i
             loaded_at[r] = time.perf_counter()
         prof["load"] += time.perf_counter() - t0
@@ -272,10 +380,11 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
                         warnings.warn('Maximum number of iterations %d reached.' % m.max_iterations, UserWarning)
                 prof["fetch"] += time.perf_counter() - t0
                 owner[r] = None
-                if pending:
+                i = _next_pending(pending, models, left)
+                if i is not None:
+                    start = starts[i]             # (waits for the draw if the feed is behind)
                     t0 = time.perf_counter()
-                    i = pending.pop(0)
-                    ctx.aa_slots_reload(r, starts[i]["dictionary"], starts[i]["weights"], starts[i]["alpha"])
+                    ctx.aa_slots_reload(r, start["dictionary"], start["weights"], start["alpha"])
                     owner[r] = i
                     loaded_at[r] = time.perf_counter()
                     prof["load"] += loaded_at[r] - t0
@@ -286,7 +395,7 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
         _print_tables(models, tables, "*** AA: n_components = {:d} ***", 80)
     if errors:
         raise errors[min(errors)]
-    return []
+    return left
 
 
 def fit_restarts(make_model, data, n_init, n_jobs=None, devices=None, side_by_side=True, n_slots=None):
@@ -306,58 +415,44 @@ def fit_restarts(make_model, data, n_init, n_jobs=None, devices=None, side_by_si
     Returns ``(models, best)``: the fitted models in restart order and the index of the first one
     with the lowest cost (the model the drivers' ``if cost < best_cost`` loop keeps)."""
     data = np.asarray(data)
-    models, starts = [], []
-    cache = {}                                    # data-dependent constants of the initialisers: |X| mean,
-                                                  # FurthestSum's distance columns (the same matrix every time)
-    draw_ctx = None                               # FurthestSum starts: ONE context for all draws
-    try:
-        for _ in range(n_init):                   # RNG draws in the sequential loop's order
-            m = make_model()
-            if not isinstance(m, (ArchetypalAnalysis, GPNHConvexCoding)):
-                raise TypeError("fit_restarts handles ArchetypalAnalysis and GPNHConvexCoding models")
-            needs_device = (m.init == 'furthest_sum' or (m.init is None and isinstance(m, ArchetypalAnalysis)))
-            if needs_device and draw_ctx is None and _backend.distributed_env() is None:
-                _backend.release_device_cache()
-                draw_ctx = _backend.Context(dtype=m.dtype)
-                draw_ctx.set_data(data)
-            extra = dict(_draw_ctx=draw_ctx) if (needs_device and draw_ctx is not None) else {}
-            if isinstance(m, ArchetypalAnalysis):
-                C0, Z0, a0 = m._aa(data, _draw_only=True, _cache=cache, **extra)
-                starts.append(dict(dictionary=C0, weights=Z0, alpha=a0))
-            else:
-                W0, Z0 = m._gpnh_convex_coding(data, _draw_only=True, _cache=cache, **extra)
-                starts.append(dict(dictionary=W0, weights=Z0))
-            models.append(m)
-    finally:
-        if draw_ctx is not None:
-            draw_ctx.close()
-    _backend.release_device_cache()               # the workers bring their own contexts
+    feed = _RestartFeed(make_model, data, n_init)     # models and draws in the sequential loop's order, on a thread
     devices = [_backend.device_index()] if devices is None else [int(d) for d in devices]
     todo = list(range(n_init))
-    slot_fit = None
-    if side_by_side and _aa_slots_eligible(models, data):
-        slot_fit = _fit_aa_slots          # AA: groups of restarts share every launch (aa_slots_*)
-    elif side_by_side and _slots_eligible(models, data):
-        slot_fit = _fit_gpnh_slots        # GPNH: slots refilled as restarts stop (aa_gpnh_slots_*)
-    if slot_fit is not None:
-        # the restarts are dealt over the devices (restart i on device i mod G), every device runs its
-        # share side by side on its own copy of the data; no collective anywhere
-        shares = [list(range(d, n_init, len(devices))) for d in range(len(devices))]
-        shares = [sh for sh in shares if sh]
+    try:
+        feed.wait(0)
+        m0 = feed.models[0]
+        slot_fit = None
+        if side_by_side and _aa_slots_eligible(m0, n_init, data):
+            slot_fit = _fit_aa_slots          # AA: groups of restarts share every launch (aa_slots_*)
+        elif side_by_side and _slots_eligible(m0, n_init, data):
+            slot_fit = _fit_gpnh_slots        # GPNH: slots refilled as restarts stop (aa_gpnh_slots_*)
+        if slot_fit is not None:
+            # the restarts are dealt over the devices (restart i on device i mod G), every device runs its
+            # share side by side on its own copy of the data; no collective anywhere.  The device iterates on
+            # the first restarts while the feed draws the later ones.
+            shares = [list(range(d, n_init, len(devices))) for d in range(len(devices))]
+            shares = [sh for sh in shares if sh]
 
-        def on_device(d):
-            idx = shares[d]
-            left = slot_fit([models[i] for i in idx], [starts[i] for i in idx], data, devices[d], n_slots=n_slots)
-            return [idx[j] for j in left]
+            def on_device(d):
+                idx = shares[d]
+                left = slot_fit(_FeedView(feed, idx, "models"), _FeedView(feed, idx, "starts"), data, devices[d],
+                                n_slots=n_slots)
+                return [idx[j] for j in left]
 
-        if len(shares) == 1:
-            todo = on_device(0)
-        else:
-            with ThreadPoolExecutor(max_workers=len(shares)) as pool:
-                todo = sorted(i for left in pool.map(on_device, range(len(shares))) for i in left)
-        if not todo:
-            costs = [m.cost for m in models]
-            return models, int(np.argmin(costs))
+            if len(shares) == 1:
+                todo = on_device(0)
+            else:
+                with ThreadPoolExecutor(max_workers=len(shares)) as pool:
+                    todo = sorted(i for left in pool.map(on_device, range(len(shares))) for i in left)
+    except BaseException:
+        feed._thread.join()                       # the producer closes its context before the error travels on
+        raise
+    feed.join()                                   # every draw made (or the producer's error raised)
+    models, starts = feed.models, feed.starts
+    if not todo:
+        costs = [m.cost for m in models]
+        return models, int(np.argmin(costs))
+    _backend.release_device_cache()               # the workers bring their own contexts
     local = threading.local()
     lock = threading.Lock()
     owners = {}                                   # device -> context that holds the data matrix
