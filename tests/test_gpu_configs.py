@@ -738,6 +738,52 @@ def test_aa_restarts_side_by_side(cdr, orc, case):
 
 
 @pytest.mark.parametrize("family", ["aa", "gpnh"])
+def test_restarts_with_mixed_settings(cdr, orc, family):
+    """The starting factors are drawn by a worker thread while the slots already iterate (round 4:
+    restarts.py: _RestartFeed), so whether a later restart has the first one's hyper-parameters is
+    known only when its turn comes: the ones that do sit side by side, the others (every third one
+    here: another tolerance) are left to the generic path.  Restart by restart the sequential loop's
+    result, bit for bit, and the draws in its order (a FurthestSum start, on a context of the feed's
+    own, in the AA case)."""
+    import warnings
+    from convex_dim_red import restarts
+    rng = np.random.RandomState(23)
+    n, p, k, n_init = 800, 70, 4, 10
+    X = orc.right_stochastic_matrix((n, k), rng).dot(rng.standard_normal((k, p))) + 0.1 * rng.standard_normal((n, p))
+    count = [0]
+
+    def make(rs):
+        i = count[0]
+        count[0] += 1
+        tol = 1e-4 if i % 3 == 2 else 1e-5
+        if family == "aa":
+            return cdr.ArchetypalAnalysis(k, init="furthest_sum", tolerance=tol, max_iterations=300, random_state=rs,
+                                          dictionary_solver_kwargs=dict(max_iterations=1))
+        return cdr.GPNHConvexCoding(k, lambda_W=0.3, init="random", tolerance=tol, max_iterations=300,
+                                    random_state=rs, stopping_criterion="rel_delta_f",
+                                    weights_solver_kwargs=dict(max_iterations=1))
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        shared = np.random.RandomState(9)
+        seq = []
+        for _ in range(n_init):
+            m = make(shared)
+            m.fit_transform(X)
+            seq.append(m)
+        count[0] = 0
+        shared = np.random.RandomState(9)
+        restarts.slots_profile.clear()
+        models, best = cdr.fit_restarts(lambda: make(shared), X, n_init)
+    assert restarts.slots_profile.get("slots", 0) >= 2               # the slots path ran for the like-minded ones
+    assert [m.tolerance for m in models] == [m.tolerance for m in seq]
+    for a, b in zip(seq, models):
+        assert a.cost == b.cost and a.n_iter == b.n_iter
+        assert np.array_equal(a.weights, b.weights) and np.array_equal(a.dictionary, b.dictionary)
+    assert best == int(np.argmin([m.cost for m in seq]))
+
+
+@pytest.mark.parametrize("family", ["aa", "gpnh"])
 def test_restarts_side_by_side_over_devices(cdr, orc, family):
     """devices=[...]: restart i goes to device i mod G and every device runs its share side by side
     (two contexts on the one GPU of the development box stand in for two devices): same results as on
