@@ -30,6 +30,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import _backend
+from . import archetypal_analysis as _aa_module
 from .archetypal_analysis import ArchetypalAnalysis
 from .gpnh_convex_coding import GPNHConvexCoding
 from .preprocessing import DeviceData
@@ -104,6 +105,44 @@ def _gpnh_slot_count(m0, n_samples, n_slots):
     return cap if n_slots is None else max(1, min(int(n_slots), cap))
 
 
+class _SelectionRecorder(object):
+    """Stands in for the draw context of a FurthestSum start on the feed's thread: notes what the
+    selection is asked for and answers with a placeholder.  The selection -- a chain of ~60 device
+    launches, no random numbers -- runs when the restart takes its slot, on the slots' own context
+    (``_resolve_start``): beside the slots' launches, on a context of its own, the chains of 100
+    restarts stretched the slots' 0.74 s to 0.87 s (JRA-55-shaped problem)."""
+
+    def __init__(self, n, p, dtype_code):
+        self.n, self.p, self.dtype_code = n, p, dtype_code
+        self.request = None
+
+    def set_linear_kernel(self, on):
+        pass
+
+    def furthest_sum(self, n_components, start_index, exclude=None, extra_steps=1):
+        self.request = (int(n_components), int(start_index), [int(e) for e in ([] if exclude is None else exclude)],
+                        int(extra_steps))
+        return np.arange(int(n_components), dtype=np.int64)
+
+
+def _resolve_start(ctx, start, data, m):
+    """The start factors of a restart with its FurthestSum selection made now, on ``ctx`` (same data,
+    same dtype as the feed's draw context would have had: the same picks)."""
+    request = start.get("selection")
+    if request is None:
+        return start
+    from .archetypal_analysis import _furthest_sum_on_device, _one_hot_rows
+    k, start_index, exclude, extra = request
+    selected = _furthest_sum_on_device(ctx, data.shape[0], k, start_index, extra, np.asarray(exclude, dtype='i8'))
+    start = dict(start)
+    del start["selection"]
+    if isinstance(m, ArchetypalAnalysis):
+        start["dictionary"] = _one_hot_rows(selected, data.shape[0], np.float64)
+    else:
+        start["dictionary"] = np.ascontiguousarray(np.asarray(data, dtype=np.float64)[selected].T)
+    return start
+
+
 class _RestartFeed(object):
     """The models and starting factors of the restarts, produced in the drivers' order -- make_model(),
     then that model's draws from the shared ``RandomState``, restart after restart exactly as the
@@ -135,16 +174,31 @@ class _RestartFeed(object):
                 if not isinstance(m, (ArchetypalAnalysis, GPNHConvexCoding)):
                     raise TypeError("fit_restarts handles ArchetypalAnalysis and GPNHConvexCoding models")
                 needs_device = (m.init == 'furthest_sum' or (m.init is None and isinstance(m, ArchetypalAnalysis)))
-                if needs_device and draw_ctx is None and _backend.distributed_env() is None:
+                # a selection that would run as a chain of device launches is left to whoever loads the
+                # restart (_SelectionRecorder); one that reads distance columns out of the shared cache
+                # (short and wide matrices: archetypal_analysis._furthest_sum_on_device) stays here
+                code = _backend.dtype_code(m.dtype)
+                column_bytes = float(data.shape[0]) * float(data.shape[1]) * (4 if code == _backend.AA_F32 else 8)
+                recorder = None
+                if (needs_device and _backend.distributed_env() is None and _aa_module._FURTHEST_SUM_ON_DEVICE
+                        and column_bytes <= 64e6 and data.ndim == 2):
+                    recorder = _SelectionRecorder(data.shape[0], data.shape[1], code)
+                elif needs_device and draw_ctx is None and _backend.distributed_env() is None:
                     draw_ctx = _backend.Context(dtype=m.dtype)
                     draw_ctx.set_data(data)
-                extra = dict(_draw_ctx=draw_ctx) if (needs_device and draw_ctx is not None) else {}
+                extra = {}
+                if recorder is not None:
+                    extra = dict(_draw_ctx=recorder)
+                elif needs_device and draw_ctx is not None:
+                    extra = dict(_draw_ctx=draw_ctx)
                 if isinstance(m, ArchetypalAnalysis):
                     C0, Z0, a0 = m._aa(data, _draw_only=True, _cache=cache, **extra)
                     start = dict(dictionary=C0, weights=Z0, alpha=a0)
                 else:
                     W0, Z0 = m._gpnh_convex_coding(data, _draw_only=True, _cache=cache, **extra)
                     start = dict(dictionary=W0, weights=Z0)
+                if recorder is not None and recorder.request is not None:
+                    start["selection"] = recorder.request      # its dictionary is a placeholder until then
                 if i > 0:
                     self.same[i] = _same_settings(m, self.models[0])
                 self.models[i], self.starts[i] = m, start
@@ -235,6 +289,7 @@ def _fit_gpnh_slots(models, starts, data, device, poll_every=8, n_slots=None):
                 return
             start = starts[i]                     # (waits for the draw if the feed is behind)
             t0 = time.perf_counter()
+            start = _resolve_start(ctx, start, data, models[i])
             ctx.gpnh_slots_load(r, start["dictionary"], start["weights"])
             owner[r] = i
             loaded_at[r] = time.perf_counter()
@@ -341,7 +396,7 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
             i = _next_pending(pending, models, left)
             if i is None:
                 break
-            start = starts[i]
+            start = _resolve_start(ctx, starts[i], data, models[i])
             ctx.aa_slots_load(r, start["dictionary"], start["weights"], start["alpha"])
             owner[r] = i
             loaded_at[r] = time.perf_counter()
@@ -384,6 +439,7 @@ def _fit_aa_slots(models, starts, data, device, poll_every=8, n_slots=None):
                 if i is not None:
                     start = starts[i]             # (waits for the draw if the feed is behind)
                     t0 = time.perf_counter()
+                    start = _resolve_start(ctx, start, data, models[i])
                     ctx.aa_slots_reload(r, start["dictionary"], start["weights"], start["alpha"])
                     owner[r] = i
                     loaded_at[r] = time.perf_counter()
@@ -477,7 +533,7 @@ def fit_restarts(make_model, data, n_init, n_jobs=None, devices=None, side_by_si
         init = m.init
         m.init = 'custom'
         try:
-            m.fit_transform(local.dd, **starts[i])
+            m.fit_transform(local.dd, **_resolve_start(local.dd._ctx, starts[i], data, m))
         finally:
             m.init = init
         return m.cost
