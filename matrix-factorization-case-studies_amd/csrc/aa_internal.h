@@ -434,7 +434,7 @@ extern int g_qp_refill_min;       // kernels_qp.hip
 extern int g_qp_waves;            // kernels_qp.hip
 extern int g_qp_sort;             // kernels_qp.hip
 extern int g_qp_profile;          // kernels_qp.hip
-extern int g_qp_wave_mem1, g_qp_fused_order, g_qp_wave_lazy, g_fin_in_last, g_gram_side, g_setup_in_grad, g_pack_comm, g_qp_quad_lazy, g_qp_wave_queue;
+extern int g_qp_wave_mem1, g_qp_fused_order, g_qp_wave_lazy, g_fin_in_last, g_gram_side, g_setup_in_grad, g_pack_comm, g_qp_quad_lazy, g_qp_wave_queue, g_pq_mfma;
 extern int g_qp_overlap_tail, g_qp_tail_cap, g_qp_live, g_qp_live_blocks, g_qp_live_occ;     // kernels_qp.hip
 
 // ------------------------------------------------------------------ comm.hip

@@ -1670,6 +1670,56 @@ __global__ __launch_bounds__(256) void k_gram_wide_pq(const double *__restrict__
     }
 }
 
+// The same two Grams on the f64 matrix cores (round 4, pq_mfma): a wave owns 16 x 16 tiles of both
+// (one tile at KP = 32), v_mfma_f64_16x16x4 with A = rows of P (or Q), B = rows of Q, four columns per
+// instruction, thirty-two columns of loads in flight.  An entry's chain over the columns does not depend on
+// where its tile sits, so restarts side by side (diagonal blocks of the stacked Gram) keep the bits of a
+// single fit.  18 -> 7 us on the critical path of every outer iteration.
+template <int KP>
+__global__ __launch_bounds__(256) void k_gram_wide_pq_mfma(const double *__restrict__ P,
+                                                           const double *__restrict__ Q, int ld,
+                                                           double *__restrict__ partial, int cols_per_block)
+{
+    constexpr int T = KP / 16, GS = KP * KP;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane >> 4, lc = lane & 15;
+    const int c0 = blockIdx.x * cols_per_block;
+    int span = ld - c0;
+    if (span > cols_per_block) span = cols_per_block;          // a multiple of 128 either way
+    double *dst = partial + (size_t)blockIdx.x * 2 * GS;
+    for (int tile = wave; tile < T * T; tile += 4) {
+        const int mi = tile / T, nj = tile % T;
+        // the contraction index is free to be permuted as long as both operands agree: lane (lc, lr) takes the
+        // four CONSECUTIVE columns 16 it + 4 lr .. + 3 of its row (one 32-byte load; a row's 128 bytes come from
+        // four lanes) and instruction u of the group multiplies everybody's u-th column
+        const double *pa = P + (long)(16 * mi + lc) * ld + c0 + 4 * lr;
+        const double *qa = Q + (long)(16 * mi + lc) * ld + c0 + 4 * lr;
+        const double *qb = Q + (long)(16 * nj + lc) * ld + c0 + 4 * lr;
+        f64x4 a1 = (f64x4){0.0, 0.0, 0.0, 0.0}, a2 = (f64x4){0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < span; s += 32) {                   // two groups of sixteen columns in flight
+            f64x4 pv[2], qv[2], bv[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                pv[g] = *reinterpret_cast<const f64x4 *>(pa + s + 16 * g);
+                qv[g] = *reinterpret_cast<const f64x4 *>(qa + s + 16 * g);
+                bv[g] = *reinterpret_cast<const f64x4 *>(qb + s + 16 * g);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pv[g][u], bv[g][u], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(qv[g][u], bv[g][u], a2, 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int e = (16 * mi + lr + 4 * reg) * KP + 16 * nj + lc;
+            dst[e] = a1[reg];
+            dst[GS + e] = a2[reg];
+        }
+    }
+}
+
 // one block of 1024 threads: partials -> gram[1], gram[2], line search, Gram of the accepted
 // point, cost
 __global__ __launch_bounds__(1024) void k_linesearch_fin(const double *__restrict__ partial, int nb,
@@ -2174,6 +2224,7 @@ int g_proj_check_always = 0; // multi-rank: 1 = every list projection is checked
                              // projection have been short -- faster, but a list that outgrows its slot between two
                              // polls (seen: the residual projection a few iterations after a FurthestSum start) then
                              // ends the fit with an error instead of being handled
+int g_pq_mfma = 1;              // the line search's two wide Grams on the f64 matrix cores (k_gram_wide_pq_mfma)
 int g_pq_blocks = 128;          // most blocks of k_gram_wide_pq (their partial Grams are summed by ONE block; 64 -> 128:
                                 // C2, p = 25 000, 0.553 -> 0.537 ms per iteration; 256: 0.548)
 int g_pack_comm = 1;            // multi-rank: small reductions ride in the tail of the next all-reduce (Ctx::ride*)
@@ -3641,7 +3692,15 @@ int launch_linesearch_fused(Ctx *c, const aa_spg_params *sp, double *cost_out, i
     const int nb = (int)((c->p_pad + cpb - 1) / cpb);
     double *part = c->redPartial.as<double>();
     double *ckct = c->gramState.as<double>() + (size_t)c->KP * c->KP;
-    if (c->KP == 32)
+    if (g_pq_mfma && c->KP == 32)
+        hipLaunchKernelGGL(k_gram_wide_pq_mfma<32>, dim3(nb), dim3(256), 0, c->stream,
+                           (const double *)c->P.as<double>(), (const double *)c->Q.as<double>(),
+                           (int)c->p_pad, part, cpb);
+    else if (g_pq_mfma)
+        hipLaunchKernelGGL(k_gram_wide_pq_mfma<64>, dim3(nb), dim3(256), 0, c->stream,
+                           (const double *)c->P.as<double>(), (const double *)c->Q.as<double>(),
+                           (int)c->p_pad, part, cpb);
+    else if (c->KP == 32)
         hipLaunchKernelGGL(k_gram_wide_pq<32>, dim3(nb), dim3(256), 0, c->stream,
                            (const double *)c->P.as<double>(), (const double *)c->Q.as<double>(),
                            (int)c->p_pad, part, cpb, c->k);

@@ -621,6 +621,8 @@ int aa_set_option(const char *name, int value)
         g_qp_tail_cap = value;
     } else if (!strcmp(name, "use_graph")) {
         g_use_graph = value != 0;
+    } else if (!strcmp(name, "pq_mfma")) {
+        g_pq_mfma = value != 0;
     } else if (!strcmp(name, "pq_blocks")) {
         AA_REQUIRE(value >= 1 && value <= 1024, AA_ERR_ARG, "pq_blocks must be in 1..1024");
         g_pq_blocks = value;
