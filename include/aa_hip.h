@@ -194,6 +194,8 @@ int aa_device_count(int *count);
  *                               BB stage, residual projection) on the side stream beside the weights QP
  *   "pack_comm"         0|1    multi-rank, 1 (default): four small reductions ride in the tail of the
  *                               all-reduce that follows them (10 collectives per outer iteration, not 14)
+ *   "pq_mfma"           0|1    1 (default): the two wide Grams of the line search on the f64 matrix cores (another
+ *                               summation order than the LDS / VALU kernel: results differ at rounding level)
  *   "proj_small"        0|1|2  1 (default): columns of <= 8192 rows are projected by one block each;
  *                               2: up to 16 384 rows (slower at 12 500) */
 int aa_set_option(const char *name, int value);
