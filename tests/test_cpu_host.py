@@ -290,3 +290,59 @@ def test_more_than_64_components_is_refused_before_any_data_moves():
         cdr.ArchetypalAnalysis(65).fit_transform(np.ones((100, 70)))
     with pytest.raises(ValueError, match="n_components = 70 exceeds.*n_features"):
         cdr.GPNHConvexCoding(None).fit_transform(np.ones((100, 70)))
+
+
+def test_restart_feed_draws_in_the_sequential_loops_order():
+    """restarts.py: _RestartFeed makes the models and draws their starting factors on a worker thread
+    (round 4: the device iterates on the first restarts meanwhile).  Random starts need no device: the
+    feed's factors are, restart by restart, the ones the drivers' sequential loop draws from the shared
+    RandomState; a restart with other hyper-parameters than the first one is flagged (the slot loops
+    leave it to the generic path: _next_pending), and what the producer raises reaches whoever waits."""
+    from convex_dim_red import restarts
+    rng = np.random.RandomState(0)
+    X = rng.standard_normal((40, 7))
+    k, n_init = 3, 6
+
+    def make(rs, i):
+        return cdr.GPNHConvexCoding(k, lambda_W=0.1, init="random", random_state=rs,
+                                    tolerance=1e-4 if i == 4 else 1e-6)
+
+    shared = np.random.RandomState(11)
+    want = []
+    for i in range(n_init):
+        m = make(shared, i)
+        want.append(m._gpnh_convex_coding(X, _draw_only=True))
+    shared = np.random.RandomState(11)
+    count = [0]
+
+    def factory():
+        count[0] += 1
+        return make(shared, count[0] - 1)
+
+    feed = restarts._RestartFeed(factory, X, n_init)
+    feed.join()
+    for (W0, Z0), start in zip(want, feed.starts):
+        assert np.array_equal(W0, start["dictionary"]) and np.array_equal(Z0, start["weights"])
+        assert "selection" not in start
+    assert feed.same == [True, True, True, True, False, True]
+    # the view a slot loop indexes, and the routing of the odd restart
+    models = restarts._FeedView(feed, [1, 3, 4, 5], "models")
+    starts = restarts._FeedView(feed, [1, 3, 4, 5], "starts")
+    assert len(models) == 4 and models[2] is feed.models[4] and starts[0] is feed.starts[1]
+    pending, left, taken = [0, 1, 2, 3], [], []
+    while True:
+        j = restarts._next_pending(pending, models, left)
+        if j is None:
+            break
+        taken.append(j)
+    assert taken == [0, 1, 3] and left == [2]
+    assert restarts._next_pending([5], [None] * 6, []) == 5      # plain lists: nothing to check
+
+    def broken():
+        raise KeyError("no model today")
+
+    bad = restarts._RestartFeed(broken, X, 3)
+    with pytest.raises(KeyError):
+        bad.wait(1)
+    with pytest.raises(KeyError):
+        bad.join()
